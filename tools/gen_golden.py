@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under ``tests/golden`` by EVALUATING the reference's own torch/numpy
+arithmetic (imported from /root/reference under the sys.modules stubs of ``reference_stubs.py``).
+
+Run in the build container only (the reference never travels to the GPU box):
+
+    python tools/gen_golden.py
+
+Outputs (small .npz files, data only -- inputs and the reference's outputs):
+
+* ``ackermann.npz``   -- AckermannAction2.process_actions/ackermann     (ackermann_actions.py:226-322)
+* ``mdp_terms.npz``   -- 3 obs + 7 reward + 3 termination term functions  (observations.py, rewards.py,
+                          terminations.py)
+* ``heightmap.npz``   -- HeightmapManager.mesh_to_heightmap / get_height_at (terrain_utils.py:23-84),
+                          TerrainManager.check_if_target_is_valid (:202-223),
+                          TerrainManager.random_rover_spawns(seed=41) (:330-385)
+
+Functions that live in third-party code absent from the container (ORBIT math utils, PhysX, Warp
+ray-caster, cv2 morphology) cannot be evaluated and are NOT covered here; see DESIGN.md "parity".
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import reference_stubs  # noqa: E402
+
+reference_stubs.install()
+
+from rover_envs.mdp.actions import ackermann_actions as ref_aa  # noqa: E402
+import rover_envs.envs.navigation.mdp as ref_mdp  # noqa: E402
+from rover_envs.envs.navigation.utils.terrains import terrain_utils as ref_tu  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(1)
+
+
+# --------------------------------------------------------------------------------------- ackermann
+def gen_ackermann():
+    cls = ref_aa.AckermannAction2
+    term = cls.__new__(cls)
+    # AAU rover cfg: rover_envs/envs/navigation/robots/aau_rover/env_cfg.py:21-31
+    term._wheel_radius = 0.1
+    term._rear_and_front_wheel_distance = 0.77
+    term._middle_wheel_distance = 0.894
+    term._wheelbase_length = 0.849
+    cls.device = "cpu"
+    term._scale = torch.tensor((1.0, 1.0)).unsqueeze(0)
+    term._offset = torch.tensor(-0.0135).unsqueeze(0)
+
+    g = torch.Generator().manual_seed(1234)
+    raw = torch.rand(512, 2, generator=g) * 2 - 1
+    edge = torch.tensor([
+        [0.0, 0.0], [1.0, 0.0], [1.0, 1.0], [-1.0, 0.5], [0.2, -1.0], [0.0135, 0.0135], [0.5, 0.0135],
+        [0.0135, 0.7], [0.0135, -0.7], [-1.0, -1.0], [1.0, -1.0], [-0.3, 0.0135], [0.9, 0.95],
+        [0.7287, 1.0135], [0.9075, 1.0135], [0.65, 0.9], [-0.65, 0.9], [1e-4, 1e-4], [0.0136, 0.0134],
+    ])
+    # larger-than-unit actions: step() does not clip (SURVEY 8b last row)
+    wide = (torch.rand(64, 2, generator=g) * 2 - 1) * 3.0
+    raw = torch.cat([edge, raw, wide], 0).to(torch.float32)
+
+    term._raw_actions = torch.zeros_like(raw)
+    term.process_actions(raw)
+    processed = term._processed_actions.clone()
+    steer, wheel = term.ackermann(processed[:, 0], processed[:, 1])
+    np.savez(os.path.join(OUT, "ackermann.npz"),
+             raw=raw.numpy(), processed=processed.numpy(), steer=steer.numpy(), wheel=wheel.numpy(),
+             cfg=np.array([0.1, 0.77, 0.894, 0.849, 1.0, 1.0, -0.0135], dtype=np.float64))
+    print("ackermann:", raw.shape, steer.shape, wheel.shape)
+
+
+# --------------------------------------------------------------------------------------- mdp terms
+class _Env:
+    pass
+
+
+def _make_env(cmd, action, prev_action, ep_len, force, pos_w, hits, max_len=750):
+    env = _Env()
+    env.num_envs = cmd.shape[0]
+    env.device = "cpu"
+    env.max_episode_length = max_len
+    env.episode_length_buf = ep_len
+    env.command_manager = types.SimpleNamespace(get_command=lambda name: cmd)
+    env.action_manager = types.SimpleNamespace(action=action, prev_action=prev_action)
+    contact = types.SimpleNamespace(data=types.SimpleNamespace(force_matrix_w=force))
+    scanner = types.SimpleNamespace(data=types.SimpleNamespace(pos_w=pos_w, ray_hits_w=hits))
+    env.scene = types.SimpleNamespace(sensors={"contact_sensor": contact, "height_scanner": scanner})
+    return env
+
+
+NSCAN = 16
+
+
+def gen_mdp_terms():
+    g = torch.Generator().manual_seed(4321)
+    n = 256
+    cmd = (torch.rand(n, 3, generator=g) * 2 - 1) * torch.tensor([12.5, 12.5, 0.5])
+    # rows that sit on / around every threshold used by the terms
+    cmd[:12] = torch.tensor([
+        [9.0, 0.0, 0.1], [0.1, 0.1, 0.0], [-3.0, -0.2, 0.0], [0.0, 12.0, 0.0], [0.18, 0.0, 0.0],
+        [0.17999, 0.0, 0.0], [11.0, 0.0, 0.0], [11.0001, 0.0, 0.0], [0.0, 0.0, 0.0], [-1.0, 0.0, 0.0],
+        [-1.0, -1e-8, 0.0], [-0.5, 1.0926, 0.0],
+    ])
+    action = torch.rand(n, 2, generator=g) * 2 - 1
+    prev_action = torch.rand(n, 2, generator=g) * 2 - 1
+    action[:4] = torch.tensor([[0.5, 0.2], [-0.3, 0.1], [1.0, -1.0], [0.0, 0.0]])
+    prev_action[:4] = torch.tensor([[0.4, 0.1], [0.3, 0.1], [0.0, 0.0], [0.0, 0.0]])
+    prev_action[4] = action[4] - 0.05 / 3        # exactly at the oscillation threshold
+    prev_action[5] = action[5] - 0.017
+    ep_len = torch.randint(0, 751, (n,), generator=g)
+    ep_len[:4] = torch.tensor([0, 10, 700, 749])
+    force = torch.zeros(n, 13, 1, 3)
+    hit = torch.rand(n, generator=g) < 0.3
+    force[hit] = (torch.rand(int(hit.sum()), 13, 1, 3, generator=g) * 2 - 1) * \
+        (torch.rand(int(hit.sum()), 1, 1, 1, generator=g) * 3.0)
+    force[:4] = 0.0
+    force[2, 3, 0] = torch.tensor([0.0, 2.0, 0.0])
+    force[6, 9, 0] = torch.tensor([0.6, 0.3, 0.1])        # sum of per-axis norms == 1.0 -> not > 1
+    force[7, 9, 0] = torch.tensor([0.6, 0.3, 0.1001])
+    pos_w = torch.rand(n, 3, generator=g) * torch.tensor([100.0, 100.0, 2.0])
+    hits = torch.rand(n, 961, 3, generator=g) * torch.tensor([100.0, 100.0, 1.5])
+    hits[3, 17, 2] = float("inf")                             # a ray miss (ORBIT: +inf)
+    pos_w[0, 2] = 10.5
+    hits[0, :, 2] = 0.3
+
+    env = _make_env(cmd, action, prev_action, ep_len, force, pos_w, hits)
+    sensor = types.SimpleNamespace(name="contact_sensor")
+    scanner = types.SimpleNamespace(name="height_scanner")
+    out = {
+        "obs_angle": ref_mdp.angle_to_target_observation(env, "target_pose"),
+        "obs_distance": ref_mdp.distance_to_target_euclidean(env, "target_pose"),
+        "obs_height_scan": ref_mdp.height_scan_rover(env, scanner),
+        "rew_distance_to_target": ref_mdp.distance_to_target_reward(env, "target_pose"),
+        "rew_reached_target": ref_mdp.reached_target(env, "target_pose", 0.18),
+        "rew_oscillation": ref_mdp.oscillation_penalty(env),
+        "rew_angle_to_target": ref_mdp.angle_to_target_penalty(env, "target_pose"),
+        "rew_heading_soft_contraint": ref_mdp.heading_soft_contraint(env, types.SimpleNamespace(name="robot")),
+        "rew_collision": ref_mdp.collision_penalty(env, sensor, 1.0),
+        "rew_far_from_target": ref_mdp.far_from_target_reward(env, "target_pose", 11.0),
+        "term_is_success": ref_mdp.is_success(env, "target_pose", 0.18),
+        "term_far_from_target": ref_mdp.far_from_target(env, "target_pose", 11.0),
+        "term_collision": ref_mdp.collision_with_obstacles(env, sensor, 1.0),
+    }
+    arrays = {k: v.numpy() for k, v in out.items()}
+    arrays["obs_height_scan"] = arrays["obs_height_scan"][:NSCAN]      # keep the fixture small
+    # threshold params are IGNORED by the reference's collision terms (rewards.py:123, terminations.py:62)
+    arrays["rew_collision_thr100"] = ref_mdp.collision_penalty(env, sensor, 100.0).numpy()
+    np.savez_compressed(os.path.join(OUT, "mdp_terms.npz"),
+                        cmd=cmd.numpy(), action=action.numpy(), prev_action=prev_action.numpy(),
+                        episode_length_buf=ep_len.numpy().astype(np.int64),
+                        force_matrix_w=force.numpy(), pos_w=pos_w[:NSCAN].numpy(),
+                        ray_hits_z=hits[:NSCAN, :, 2].numpy(), max_episode_length=np.int64(750), **arrays)
+    print("mdp_terms:", {k: tuple(v.shape) for k, v in arrays.items()})
+
+
+# --------------------------------------------------------------------------------------- heightmap
+def _grid_mesh(nx, ny, size_x, size_y, zfun, x0=0.0, y0=0.0):
+    xs = np.linspace(x0, x0 + size_x, nx)
+    ys = np.linspace(y0, y0 + size_y, ny)
+    X, Y = np.meshgrid(xs, ys, indexing="xy")
+    Z = zfun(X, Y)
+    verts = np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1).astype(np.float32)
+    faces = []
+    for j in range(ny - 1):
+        for i in range(nx - 1):
+            a = j * nx + i
+            faces.append([a, a + 1, a + nx])
+            faces.append([a + 1, a + nx + 1, a + nx])
+    return verts, np.asarray(faces, dtype=np.uint32)
+
+
+def gen_heightmap():
+    out = {}
+    # (1) SURVEY App. D known answer: 4 verts / 2 faces -> (41, 41) all 2.0
+    v = np.array([[0, 0, 0], [4, 0, 0], [0, 4, 1], [4, 4, 2]], dtype=np.float32)
+    f = np.array([[0, 1, 2], [1, 3, 2]], dtype=np.uint32)
+    hm = ref_tu.HeightmapManager(0.05, v, f)
+    out["quad_vertices"], out["quad_faces"] = v, f
+    out["quad_heightmap"] = hm.heightmap
+    out["quad_bounds"] = np.array([hm.min_x, hm.min_y, hm.max_x, hm.max_y], dtype=np.float64)
+
+    # (2) a 7 m x 6 m wavy sheet, 0.25 m triangles, non-zero mesh origin
+    verts, faces = _grid_mesh(29, 25, 7.0, 6.0,
+                              lambda X, Y: 0.3 * np.sin(1.3 * X) * np.cos(0.9 * Y) + 0.05 * X, x0=-0.5, y0=0.25)
+    hm = ref_tu.HeightmapManager(0.05, verts, faces)
+    out["wavy_vertices"], out["wavy_faces"] = verts, faces
+    out["wavy_heightmap"] = hm.heightmap
+    out["wavy_bounds"] = np.array([hm.min_x, hm.min_y, hm.max_x, hm.max_y], dtype=np.float64)
+
+    # get_height_at / check_if_target_is_valid need the tensors the reference only creates on CUDA
+    # (terrain_utils.py:19-21) -> inject CPU tensors by hand.
+    hm.heightmap_tensor = torch.from_numpy(hm.heightmap)
+    hm.offset_tensor = torch.tensor([hm.min_x, hm.min_y])
+    g = torch.Generator().manual_seed(99)
+    pos = torch.rand(300, 2, generator=g) * torch.tensor([9.0, 8.0]) - 1.5     # includes out-of-range
+    out["wavy_query_xy"] = pos.numpy()
+    out["wavy_query_height"] = hm.get_height_at(pos.clone()).numpy()
+
+    tm = ref_tu.TerrainManager.__new__(ref_tu.TerrainManager)
+    tm._heightmap_manager = hm
+    tm.resolution_in_m = 0.05
+    rng = np.random.RandomState(7)
+    mask = (rng.rand(*hm.heightmap.shape) < 0.35).astype(np.uint8)
+    tm.rock_mask_tensor = torch.from_numpy(mask).unsqueeze(-1)
+    env_ids = torch.arange(300)
+    bad_ids, bad_len = tm.check_if_target_is_valid(env_ids, pos.clone(), device="cpu")
+    out["wavy_mask"] = mask
+    invalid = np.zeros(300, dtype=np.uint8)
+    invalid[bad_ids.numpy()] = 1
+    out["wavy_query_invalid"] = invalid
+    assert bad_len == int(invalid.sum())
+
+    # (3) random_rover_spawns(seed=41): needs a map larger than 2 x 20 m border -> 1000 x 900 cells
+    rng = np.random.RandomState(3)
+    H, W = 1000, 900
+    big_h = rng.rand(H, W).astype(np.float32)
+    big_mask = (rng.rand(H, W) < 0.4).astype(np.uint8)
+    hm2 = types.SimpleNamespace(min_x=1.0, min_y=1.5)
+    tm2 = ref_tu.TerrainManager.__new__(ref_tu.TerrainManager)
+    tm2._heightmap_manager = hm2
+    tm2.resolution_in_m = 0.05
+    spawns = tm2.random_rover_spawns(rock_mask=big_mask, heightmap=big_h, n_spawns=64, seed=41)
+    out["spawn_seed_hm"] = np.int64(3)      # heightmap = RandomState(3).rand(H, W); mask = next rand(H, W) < 0.4
+    out["spawn_shape"] = np.array([H, W], dtype=np.int64)
+    out["spawn_min_xy"] = np.array([1.0, 1.5])
+    out["spawn_locations"] = spawns
+    np.savez_compressed(os.path.join(OUT, "heightmap.npz"), **out)
+    print("heightmap:", {k: getattr(v, "shape", ()) for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    gen_ackermann()
+    gen_mdp_terms()
+    gen_heightmap()
+    for fn in sorted(os.listdir(OUT)):
+        print(fn, os.path.getsize(os.path.join(OUT, fn)))
