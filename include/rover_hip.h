@@ -1,0 +1,155 @@
+/*
+ * rover_hip.h -- C ABI of the MI355X-native AAURoverEnv-v0 hot path (librover_hip.so).
+ *
+ * The reference (abmoRobotics/isaac_rover_orbit) has NO native / FFI boundary on this path: its "operator API" is the
+ * Python object protocol between the skrl / gymnasium consumers and the ORBIT `RLTaskEnv` subclass
+ *     rover_envs/envs/navigation/entrypoints/rover_env.py:12-102   (RoverEnv.__init__ / _reset_idx / step)
+ * Each entry point below names the reference interface it replaces.  The Python class that reproduces the reference
+ * protocol on top of this ABI is isaac_rover_orbit_amd/envs/rover_env.py (see INTEGRATION.md for the ctypes stub).
+ *
+ * Conventions
+ *   - plain C: opaque handle, pointers + sizes, int return codes (0 = ROVER_OK); rover_last_error() gives the text
+ *     of the last failure on the calling thread.  No exceptions, no torch types.
+ *   - every buffer is CALLER-OWNED DEVICE memory (e.g. torch-ROCm tensors); the library never allocates outputs and
+ *     keeps only the pointers it is given.  `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - all calls are asynchronous on `stream` and never synchronise the host (the reference's host syncs at
+ *     rover_env.py:89-90 and terrain_importer.py:143 are gone).
+ *   - one handle per GPU per process; calls on one handle must be serialised by the caller.
+ *
+ * State layout: SoA, fp32 words, state[word * num_envs + env]; word indices = ROVER_* below (int fields are the raw
+ * 32-bit pattern).  get/set_state of the reference does not exist (env state is never checkpointed there); here the
+ * state tensor is simply owned by the caller.
+ */
+#ifndef ROVER_HIP_H
+#define ROVER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    ROVER_OK = 0,
+    ROVER_ERR_INVALID = 1,     /* bad argument / shape                                   */
+    ROVER_ERR_STATE = 2,       /* call order (terrain or buffers not bound)              */
+    ROVER_ERR_HIP = 3,         /* a HIP runtime call failed                              */
+    ROVER_ERR_UNSUPPORTED = 4  /* configuration outside what the kernels were built for  */
+};
+
+/* per-env state words (identical numbering to the CPU oracle's AoS words) */
+enum {
+    ROVER_POS = 0, ROVER_QUAT = 3, ROVER_LINVEL = 7, ROVER_ANGVEL = 10,
+    ROVER_BOGIE_Q = 13, ROVER_STEER_Q = 16, ROVER_WHEEL_Q = 20,
+    ROVER_BOGIE_QD = 26, ROVER_STEER_QD = 29, ROVER_WHEEL_QD = 33,
+    ROVER_TARGET_W = 39, ROVER_HEADING_CMD_W = 42, ROVER_ENV_ORIGIN = 43,
+    ROVER_ACTION = 46, ROVER_PREV_ACTION = 48, ROVER_TIME_LEFT = 50, ROVER_EP_LEN = 51,
+    ROVER_CMD_B = 52, ROVER_HEADING_CMD_B = 55, ROVER_EP_SUM = 56,
+    ROVER_METRIC_POS = 63, ROVER_METRIC_HEAD = 64, ROVER_LAMBDA_N = 65, ROVER_RESET_COUNT = 71,
+    ROVER_STATE_WORDS = 72
+};
+enum { ROVER_NUM_REW = 7, ROVER_NUM_TERM = 4, ROVER_NUM_BODIES = 13, ROVER_LOG_WORDS = 16 };
+
+/* Declarative MDP parameters.  Replaces the @configclass tables of
+ *   rover_envs/envs/navigation/rover_env_cfg.py:97-278 (observations, rewards, terminations, commands, timing),
+ *   rover_envs/mdp/actions/actions_cfg.py:9-51 + robots/aau_rover/env_cfg.py:21-31 (Ackermann geometry / offset),
+ *   rover_envs/envs/navigation/mdp/randomizations.py:12 (z_offset).                                              */
+typedef struct rover_config {
+    float scale_lin, scale_ang, offset_lin, offset_ang;
+    float wheel_radius, d_fr, d_mw, wheelbase;
+    float sim_dt;
+    int32_t decimation;
+    int32_t max_episode_length;
+    float max_episode_length_s;
+    float success_threshold, far_threshold, target_distance;
+    float heading_lo, heading_hi, resample_time;
+    float rew_weight[ROVER_NUM_REW]; /* distance_to_target, reached_target, oscillation, angle_to_target,
+                                        heading_soft_contraint, collision, far_from_target */
+    float obs_scale_distance, obs_scale_heading;
+    float scan_resolution, scan_size_x, scan_size_y, scan_height_offset;
+    int32_t scan_nx, scan_ny;
+    float reset_z_offset;
+    int32_t reset_mode;      /* 0 = reference behaviour (root pose only); 1 = also zero velocities and joints */
+    uint32_t seed_lo, seed_hi;
+    float friction_mu;
+    int32_t solver_iterations;
+    int32_t max_target_tries;
+} rover_config;
+
+typedef struct rover_sim rover_sim;
+
+/* Fills `cfg` with the AAURoverEnv-v0 defaults (the values of the cfg files cited above). */
+int rover_default_config(rover_config *cfg);
+
+/* Replaces RoverEnv.__init__ -> RLTaskEnv.__init__ (rover_env.py:18-25): creates the per-process simulation handle
+ * for `num_envs` environments whose GLOBAL ids are env_id_offset .. env_id_offset + num_envs - 1 (multi-GPU sharding;
+ * the RNG is keyed by global id so results do not depend on the sharding).  `device` is the HIP device ordinal. */
+int rover_create(const rover_config *cfg, int32_t num_envs, int32_t env_id_offset, int32_t device, rover_sim **out);
+int rover_destroy(rover_sim *sim);
+
+/* Replaces RoverTerrainImporter / TerrainManager.__init__ (terrain_importer.py:127-132, terrain_utils.py:92-127):
+ * binds the shared read-only terrain data (device pointers, row-major [y][x]).
+ *   height     (H, W) fp32  merged surface (ground + obstacles)  -- wheels + ray-caster
+ *   obstacle   (H, W) fp32  obstacle layer (0 = no rock)          -- contact-sensor filter (rover_env_cfg.py:72-75)
+ *   safe_mask  (H, W) u8    1 = target not allowed                -- safe_rock_mask (terrain_utils.py:311)
+ *   spawns     (n_spawns, 3) fp32 spawn table                     -- terrain_utils.py:330-385                   */
+int rover_set_terrain(rover_sim *sim, const float *height, const float *obstacle, const uint8_t *safe_mask, int32_t H,
+                      int32_t W, float resolution, float min_x, float min_y, const float *spawns, int32_t n_spawns);
+
+/* Scratch the library needs from the caller (per-wave log partials); bytes. */
+size_t rover_workspace_bytes(const rover_sim *sim);
+
+/* Binds the caller-owned persistent buffers: state (ROVER_STATE_WORDS x num_envs fp32, SoA) and workspace. */
+int rover_bind(rover_sim *sim, float *state, void *workspace, size_t workspace_bytes);
+
+/* Replaces env.reset() (ORBIT RLTaskEnv.reset -> _reset_idx(all), rover_env.py:27-39): resets every env and writes
+ * the first observation.  obs: (num_envs, 4 + scan_nx * scan_ny) fp32 row-major. */
+int rover_reset(rover_sim *sim, float *obs, void *stream);
+
+/* Replaces RoverEnv.step (rover_env.py:42-102), including the in-step reset of finished envs (_reset_idx :27-39,
+ * reset_root_state_rover randomizations.py:12-39, TerrainBasedPositionCommand._resample_command
+ * terrain_importer.py:74-95) and the command / observation managers.
+ *   action      (num_envs, 2) fp32 in            -- (lin, ang), not clipped (as in the reference)
+ *   obs         (num_envs, 4 + rays) fp32 out    -- [last_action(2), distance*0.11, heading/pi, height_scan]
+ *   reward      (num_envs,) fp32 out
+ *   terminated  (num_envs,) u8 out               -- termination_manager.terminated
+ *   truncated   (num_envs,) u8 out               -- termination_manager.time_outs
+ *   force       (13 * 3, num_envs) fp32 out or NULL -- contact_sensor.data.force_matrix_w (obstacle filter), stored
+ *                  SoA: force[(body * 3 + xyz) * num_envs + env]; a (num_envs, 13, 1, 3) strided view of it satisfies
+ *                  the `.view(num_envs, -1, 3)` of rewards.py:119 / terminations.py:59
+ *   log         (ROVER_LOG_WORDS,) fp32 in/out   -- extras["log"]: [0..6] Episode Reward/<term>, [7..10] Episode
+ *                  Termination/<term> (time_limit, is_success, far_from_target, collision), [11..12] Metrics/
+ *                  target_pose/{error_pos,error_heading}, [13] number of envs reset in this step; entries 0..12 are
+ *                  only rewritten when [13] > 0 (the reference rebuilds extras["log"] only inside _reset_idx).      */
+int rover_step(rover_sim *sim, const float *action, float *obs, float *reward, uint8_t *terminated, uint8_t *truncated,
+               float *force, float *log, void *stream);
+
+/* Profiling twin of rover_step: identical launches, bracketed by HIP events recorded on `stream`; returns the device
+ * time of the two kernels in milliseconds.  Synchronises the host -- measurement only (bench.py roofline leg). */
+int rover_profile_step(rover_sim *sim, const float *action, float *obs, float *reward, uint8_t *terminated,
+                       uint8_t *truncated, float *force, float *log, void *stream, float *ms_step_kernel,
+                       float *ms_scan_kernel);
+
+/* Unit entry points used by the parity tests (same kernels' device functions, one env per lane):
+ *   rover_ackermann      -- AckermannAction2.process_actions + ackermann (ackermann_actions.py:226-322)
+ *                           steer (n,4) [FL,RL,RR,FR], wheel (n,6) [ML,FL,RL,RR,MR,FR] as the reference stacks them
+ *   rover_height_scan    -- RayCaster + height_scan_rover (rover_env_cfg.py:78-86, observations.py:35-45) for the
+ *                           bound state; scan (num_envs, rays)
+ *   rover_physics        -- `substeps` x (write_data_to_sim, sim.step, scene.update) (rover_env.py:64-72) on the bound
+ *                           state with explicit joint targets in MODEL order (steer FL,FR,RL,RR; wheels FL,FR,CL,CR,RL,RR) */
+int rover_ackermann(rover_sim *sim, int32_t n, const float *raw, float *processed, float *steer, float *wheel, void *stream);
+int rover_height_scan(rover_sim *sim, float *scan, void *stream);
+int rover_physics(rover_sim *sim, const float *steer_target, const float *wheel_target, int32_t substeps, float *force,
+                  void *stream);
+
+/* Model constant table (same order as the oracle's rvo_model_constants); returns the count. Host only. */
+int rover_model_constants(float *out, int32_t cap);
+int rover_state_words(void);
+const char *rover_last_error(void);
+const char *rover_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROVER_HIP_H */

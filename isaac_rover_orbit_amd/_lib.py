@@ -1,0 +1,99 @@
+"""ctypes loader of the C-ABI HIP library ``librover_hip.so`` (declared in ``include/rover_hip.h``).
+
+The product path has NO CPU fallback: if the library is missing or a call fails, a ``RoverHipError`` is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "librover_hip.so")
+
+NUM_REW, NUM_TERM, NUM_BODIES, LOG_WORDS, STATE_WORDS = 7, 4, 13, 16, 72
+
+# state word offsets (include/rover_hip.h)
+POS, QUAT, LINVEL, ANGVEL = 0, 3, 7, 10
+BOGIE_Q, STEER_Q, WHEEL_Q, BOGIE_QD, STEER_QD, WHEEL_QD = 13, 16, 20, 26, 29, 33
+TARGET_W, HEADING_CMD_W, ENV_ORIGIN, ACTION, PREV_ACTION, TIME_LEFT, EP_LEN = 39, 42, 43, 46, 48, 50, 51
+CMD_B, HEADING_CMD_B, EP_SUM, METRIC_POS, METRIC_HEAD, LAMBDA_N, RESET_COUNT = 52, 55, 56, 63, 64, 65, 71
+
+EXPORTS = [
+    "rover_default_config", "rover_create", "rover_destroy", "rover_set_terrain", "rover_workspace_bytes", "rover_bind",
+    "rover_reset", "rover_step", "rover_profile_step", "rover_ackermann", "rover_height_scan", "rover_physics", "rover_model_constants",
+    "rover_state_words", "rover_last_error", "rover_version",
+]
+
+
+class RoverHipError(RuntimeError):
+    pass
+
+
+class RoverConfig(C.Structure):
+    """Mirror of ``struct rover_config``."""
+    _fields_ = [
+        ("scale_lin", C.c_float), ("scale_ang", C.c_float), ("offset_lin", C.c_float), ("offset_ang", C.c_float),
+        ("wheel_radius", C.c_float), ("d_fr", C.c_float), ("d_mw", C.c_float), ("wheelbase", C.c_float),
+        ("sim_dt", C.c_float), ("decimation", C.c_int32), ("max_episode_length", C.c_int32),
+        ("max_episode_length_s", C.c_float),
+        ("success_threshold", C.c_float), ("far_threshold", C.c_float), ("target_distance", C.c_float),
+        ("heading_lo", C.c_float), ("heading_hi", C.c_float), ("resample_time", C.c_float),
+        ("rew_weight", C.c_float * NUM_REW),
+        ("obs_scale_distance", C.c_float), ("obs_scale_heading", C.c_float),
+        ("scan_resolution", C.c_float), ("scan_size_x", C.c_float), ("scan_size_y", C.c_float),
+        ("scan_height_offset", C.c_float), ("scan_nx", C.c_int32), ("scan_ny", C.c_int32),
+        ("reset_z_offset", C.c_float), ("reset_mode", C.c_int32), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
+        ("friction_mu", C.c_float), ("solver_iterations", C.c_int32), ("max_target_tries", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load ``librover_hip.so`` (built in-tree by ``__graft_entry__.build()`` / ``isaac_rover_orbit_amd.build``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RoverHipError(
+            f"{LIB_PATH} not found: build it with `python -m isaac_rover_orbit_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the rover hot path.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
+    lib.rover_default_config.argtypes = [C.POINTER(RoverConfig)]
+    lib.rover_create.argtypes = [C.POINTER(RoverConfig), i32, i32, i32, C.POINTER(vp)]
+    lib.rover_destroy.argtypes = [vp]
+    lib.rover_set_terrain.argtypes = [vp, vp, vp, vp, i32, i32, f32, f32, f32, vp, i32]
+    lib.rover_workspace_bytes.argtypes = [vp]
+    lib.rover_workspace_bytes.restype = C.c_size_t
+    lib.rover_bind.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.rover_reset.argtypes = [vp, vp, vp]
+    lib.rover_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.rover_profile_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.rover_ackermann.argtypes = [vp, i32, vp, vp, vp, vp, vp]
+    lib.rover_height_scan.argtypes = [vp, vp, vp]
+    lib.rover_physics.argtypes = [vp, vp, vp, i32, vp, vp]
+    lib.rover_model_constants.argtypes = [vp, i32]
+    lib.rover_last_error.restype = C.c_char_p
+    lib.rover_version.restype = C.c_char_p
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int:
+            fn.restype = C.c_int
+    if lib.rover_state_words() != STATE_WORDS:
+        raise RoverHipError("librover_hip.so state layout does not match the Python binding")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().rover_last_error().decode("utf-8", "replace")
+        raise RoverHipError(f"{what} failed (code {rc}): {msg}")
+
+
+def default_config() -> RoverConfig:
+    cfg = RoverConfig()
+    check(load().rover_default_config(C.byref(cfg)), "rover_default_config")
+    return cfg

@@ -1,0 +1,223 @@
+"""Declarative configuration of ``AAURoverEnv-v0`` in the *shape* of the reference's ORBIT ``@configclass`` tables
+(term name -> func / weight / params), so that user cfg edits carry over:
+
+* ``RoverEnvCfg``          <- ``rover_envs/envs/navigation/rover_env_cfg.py:228-278``
+* ``AckermannActionCfg``   <- ``rover_envs/mdp/actions/actions_cfg.py:9-51``
+* ``AAURoverEnvCfg``       <- ``rover_envs/envs/navigation/robots/aau_rover/env_cfg.py:10-31``
+
+The term *functions* are fused into the HIP kernels; the cfg carries their names (strings), weights, scales and
+thresholds, which are compiled into the kernel parameter block (``_lib.RoverConfig``).  A term name the kernels do not
+know raises at construction time -- there is no slow Python path.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Any
+
+from . import _lib
+
+
+@dataclass
+class TermCfg:
+    func: str
+    weight: float = 1.0
+    scale: float = 1.0
+    params: dict = field(default_factory=dict)
+    time_out: bool = False
+
+
+@dataclass
+class SceneCfg:
+    num_envs: int = 256          # rover_env_cfg.py:233-234
+    env_spacing: float = 4.0
+    replicate_physics: bool = False
+
+
+@dataclass
+class SimCfg:
+    dt: float = 1.0 / 30.0       # rover_env_cfg.py:269
+    device: str = "cuda:0"
+    use_gpu_pipeline: bool = True
+
+
+@dataclass
+class RayCasterCfg:
+    """``height_scanner`` (rover_env_cfg.py:78-86)."""
+    resolution: float = 0.1
+    size: tuple = (3.0, 3.0)
+    offset_z: float = 10.0
+    attach_yaw_only: bool = True
+    max_distance: float = 100.0
+    height_offset: float = 0.26878   # observations.py:45
+
+    @property
+    def grid(self):
+        # ORBIT patterns.grid_pattern: arange(-size/2, size/2 + 1e-9, resolution)
+        nx = int(math.floor((self.size[0] + 1e-9) / self.resolution)) + 1
+        ny = int(math.floor((self.size[1] + 1e-9) / self.resolution)) + 1
+        return nx, ny
+
+
+@dataclass
+class AckermannActionCfg:
+    """actions_cfg.py:9-51 with the AAU values of aau_rover/env_cfg.py:21-31."""
+    asset_name: str = "robot"
+    scale: tuple = (1.0, 1.0)
+    offset: Any = -0.0135            # scalar => broadcast to both channels (reference quirk B-4)
+    wheelbase_length: float = 0.849
+    middle_wheel_distance: float = 0.894
+    rear_and_front_wheel_distance: float = 0.77
+    wheel_radius: float = 0.1
+    min_steering_radius: float = 0.8
+    steering_joint_names: tuple = (".*Steer_Revolute",)
+    drive_joint_names: tuple = (".*Drive_Continuous",)
+
+
+@dataclass
+class CommandCfg:
+    """CommandsCfg.target_pose (rover_env_cfg.py:187-200) + RoverTerrainImporter.target_distance (terrain_importer.py:132)."""
+    resampling_time_range: tuple = (150.0, 150.0)
+    heading_range: tuple = (-math.pi, math.pi)
+    simple_heading: bool = False
+    target_distance: float = 9.0
+    max_target_tries: int = 32
+
+
+@dataclass
+class TerrainCfg:
+    """Synthetic stand-in for the missing terrain USDs: ``kind`` in {"procedural", "flat", "custom"}."""
+    kind: str = "procedural"
+    shape: tuple = (2048, 2048)
+    seed: int = 1234
+    sigma_z: float = 0.15
+    n_rocks: int = 400
+    terrain: Any = None              # an isaac_rover_orbit_amd.terrain.Terrain for kind == "custom"
+    spawn_seed: int = 41
+
+
+def _default_observations():
+    return {
+        "actions": TermCfg("last_action"),
+        "distance": TermCfg("distance_to_target_euclidean", scale=0.11, params={"command_name": "target_pose"}),
+        "heading": TermCfg("angle_to_target_observation", scale=1 / math.pi, params={"command_name": "target_pose"}),
+        "height_scan": TermCfg("height_scan_rover", scale=1, params={"sensor_cfg": "height_scanner"}),
+    }
+
+
+def _default_rewards():
+    return {
+        "distance_to_target": TermCfg("distance_to_target_reward", weight=5.0, params={"command_name": "target_pose"}),
+        "reached_target": TermCfg("reached_target", weight=5.0, params={"command_name": "target_pose", "threshold": 0.18}),
+        "oscillation": TermCfg("oscillation_penalty", weight=-0.1),
+        "angle_to_target": TermCfg("angle_to_target_penalty", weight=-1.5, params={"command_name": "target_pose"}),
+        "heading_soft_contraint": TermCfg("heading_soft_contraint", weight=-0.5, params={"asset_cfg": "robot"}),
+        "collision": TermCfg("collision_penalty", weight=-2.0, params={"sensor_cfg": "contact_sensor", "threshold": 1.0}),
+        "far_from_target": TermCfg("far_from_target_reward", weight=-2.0, params={"command_name": "target_pose", "threshold": 11.0}),
+    }
+
+
+def _default_terminations():
+    return {
+        "time_limit": TermCfg("time_out", time_out=True),
+        "is_success": TermCfg("is_success", params={"command_name": "target_pose", "threshold": 0.18}),
+        "far_from_target": TermCfg("far_from_target", params={"command_name": "target_pose", "threshold": 11.0}),
+        "collision": TermCfg("collision_with_obstacles", params={"sensor_cfg": "contact_sensor", "threshold": 1.0}),
+    }
+
+
+REWARD_ORDER = ["distance_to_target", "reached_target", "oscillation", "angle_to_target", "heading_soft_contraint",
+                "collision", "far_from_target"]
+REWARD_FUNCS = ["distance_to_target_reward", "reached_target", "oscillation_penalty", "angle_to_target_penalty",
+                "heading_soft_contraint", "collision_penalty", "far_from_target_reward"]
+TERMINATION_ORDER = ["time_limit", "is_success", "far_from_target", "collision"]
+TERMINATION_FUNCS = ["time_out", "is_success", "far_from_target", "collision_with_obstacles"]
+OBS_ORDER = ["actions", "distance", "heading", "height_scan"]
+OBS_FUNCS = ["last_action", "distance_to_target_euclidean", "angle_to_target_observation", "height_scan_rover"]
+
+
+@dataclass
+class RoverEnvCfg:
+    scene: SceneCfg = field(default_factory=SceneCfg)
+    sim: SimCfg = field(default_factory=SimCfg)
+    decimation: int = 6                      # rover_env_cfg.py:270
+    episode_length_s: float = 150.0          # rover_env_cfg.py:271
+    height_scanner: RayCasterCfg = field(default_factory=RayCasterCfg)
+    actions: AckermannActionCfg = field(default_factory=AckermannActionCfg)
+    commands: CommandCfg = field(default_factory=CommandCfg)
+    observations: dict = field(default_factory=_default_observations)
+    rewards: dict = field(default_factory=_default_rewards)
+    terminations: dict = field(default_factory=_default_terminations)
+    terrain: TerrainCfg = field(default_factory=TerrainCfg)
+    reset_z_offset: float = 0.5              # randomizations.py:12
+    reset_velocities: str = "reference"      # "reference" (root pose only, B-17) | "zero"
+    seed: int = 0
+    friction: float = 0.75
+    solver_iterations: int = 8
+    record_contact_forces: bool = True       # materialise contact_sensor.data.force_matrix_w every step
+    # multi-GPU sharding: this process simulates global env ids [env_id_offset, env_id_offset + num_envs)
+    env_id_offset: int = 0
+    global_num_envs: int | None = None
+
+    # ------------------------------------------------------------------------------------------------------------
+    def validate(self):
+        for table, order, funcs, what in ((self.rewards, REWARD_ORDER, REWARD_FUNCS, "reward"),
+                                          (self.terminations, TERMINATION_ORDER, TERMINATION_FUNCS, "termination"),
+                                          (self.observations, OBS_ORDER, OBS_FUNCS, "observation")):
+            if list(table.keys()) != order:
+                raise ValueError(f"{what} terms must be exactly {order} (fused in the HIP kernels); got {list(table)}")
+            for name, fn in zip(order, funcs):
+                if table[name].func != fn:
+                    raise ValueError(f"{what} term '{name}' must use func '{fn}' (got '{table[name].func}')")
+        if self.reset_velocities not in ("reference", "zero"):
+            raise ValueError("reset_velocities must be 'reference' or 'zero'")
+        if self.commands.simple_heading:
+            raise ValueError("simple_heading=True is not supported (the reference cfg uses False, rover_env_cfg.py:195)")
+
+    @property
+    def max_episode_length(self) -> int:
+        # ORBIT: ceil(episode_length_s / (sim.dt * decimation))
+        return math.ceil(self.episode_length_s / (self.sim.dt * self.decimation))
+
+    def to_native(self) -> "_lib.RoverConfig":
+        self.validate()
+        c = _lib.default_config()
+        a = self.actions
+        off = a.offset if isinstance(a.offset, (tuple, list)) else (a.offset, a.offset)
+        c.scale_lin, c.scale_ang = float(a.scale[0]), float(a.scale[1])
+        c.offset_lin, c.offset_ang = float(off[0]), float(off[1])
+        c.wheel_radius, c.d_fr = a.wheel_radius, a.rear_and_front_wheel_distance
+        c.d_mw, c.wheelbase = a.middle_wheel_distance, a.wheelbase_length
+        c.sim_dt, c.decimation = self.sim.dt, self.decimation
+        c.max_episode_length = self.max_episode_length
+        c.max_episode_length_s = self.episode_length_s
+        succ = self.terminations["is_success"].params["threshold"]
+        far = self.terminations["far_from_target"].params["threshold"]
+        c.success_threshold, c.far_threshold = succ, far
+        if self.rewards["reached_target"].params["threshold"] != succ or self.rewards["far_from_target"].params["threshold"] != far:
+            raise ValueError("reward and termination thresholds must agree (as in rover_env_cfg.py:136,162,173,177)")
+        c.target_distance = self.commands.target_distance
+        c.heading_lo, c.heading_hi = self.commands.heading_range
+        if self.commands.resampling_time_range[0] != self.commands.resampling_time_range[1]:
+            raise ValueError("resampling_time_range must be a single value (rover_env_cfg.py:196)")
+        c.resample_time = self.commands.resampling_time_range[0]
+        for i, name in enumerate(REWARD_ORDER):
+            c.rew_weight[i] = self.rewards[name].weight
+        c.obs_scale_distance = self.observations["distance"].scale
+        c.obs_scale_heading = self.observations["heading"].scale
+        hs = self.height_scanner
+        c.scan_resolution, c.scan_size_x, c.scan_size_y = hs.resolution, hs.size[0], hs.size[1]
+        c.scan_nx, c.scan_ny = hs.grid
+        c.scan_height_offset = hs.height_offset
+        c.reset_z_offset = self.reset_z_offset
+        c.reset_mode = 0 if self.reset_velocities == "reference" else 1
+        c.seed_lo, c.seed_hi = self.seed & 0xFFFFFFFF, (self.seed >> 32) & 0xFFFFFFFF
+        c.friction_mu = self.friction
+        c.solver_iterations = self.solver_iterations
+        c.max_target_tries = self.commands.max_target_tries
+        return c
+
+
+@dataclass
+class AAURoverEnvCfg(RoverEnvCfg):
+    """``AAURoverEnv-v0`` (robots/aau_rover/env_cfg.py:10-31): the defaults above already are the AAU values."""

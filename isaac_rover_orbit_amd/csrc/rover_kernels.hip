@@ -1,0 +1,1142 @@
+// rover_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) + C ABI of the AAURoverEnv-v0 hot path.
+//
+// Two launches per env.step():
+//   K1  rover_step_kernel     one env per LANE, SoA state (state[word * N + env] => every load/store is a coalesced
+//                             256-B wave access).  process_action -> Ackermann -> 6 x {implicit-PD steer joints,
+//                             6-wheel contact PGS against the bilinear heightfield, wheel motors, integration} ->
+//                             counters -> terminations -> rewards -> in-lane reset (Philox) -> command update.
+//                             Wave-level butterfly reductions produce the per-wave partials of extras["log"].
+//   K2  rover_scan_obs_kernel one env per 256-thread WORKGROUP: stages the yaw-rotated 3 x 3 m terrain window in LDS
+//                             (<= 92 x 92 fp32), evaluates the 31 x 31 vertical rays by bilinear gather from LDS and
+//                             writes the 965-float observation row with coalesced stores; one extra workgroup
+//                             reduces the log partials in a fixed order (deterministic).
+// There is no matrix-shaped work on this path (gather / integrate / scatter) => no MFMA; the bound is HBM/latency.
+//
+// Reference behaviour being replaced (file:line in /root/reference): RoverEnv.step entrypoints/rover_env.py:42-102;
+// AckermannAction2 mdp/actions/ackermann_actions.py:226-322; mdp terms envs/navigation/mdp/{observations,rewards,
+// terminations,randomizations}.py; TerrainBasedPositionCommand utils/terrains/terrain_importer.py:74-175;
+// HeightmapManager.get_height_at / check_if_target_is_valid utils/terrains/terrain_utils.py:62-84,202-223.
+// Physics / ray-caster / contact sensor are third-party in the reference (PhysX, Warp); the reduced rover model used
+// here is specified in DESIGN.md.  All arithmetic is fp32 with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/rover_hip.h"
+#include "rover_model.hpp"
+
+namespace {
+
+struct RvParams {
+    rover_config cfg;
+    const float *height;
+    const float *obstacle;
+    const uint8_t *safe_mask;
+    const float *spawns;
+    int H, W, n_spawns;
+    float res, min_x, min_y;
+    int n, env_id_offset;
+    int rays, obs_w;
+    int tile_dim;  // LDS tile edge (cells) for the scan kernel
+};
+
+// ------------------------------------------------------------------------------------------------ small helpers
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+__device__ __forceinline__ float dot3(const float *a, const float *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ void cross3(const float *a, const float *b, float *o)
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ float sign_torch(float x) { return (float)((x > 0.0f) - (x < 0.0f)); }
+__device__ __forceinline__ void quat_to_mat(const float *q, float R[3][3])
+{
+    const float w = q[0], x = q[1], y = q[2], z = q[3];
+    R[0][0] = 1.0f - 2.0f * (y * y + z * z);
+    R[0][1] = 2.0f * (x * y - w * z);
+    R[0][2] = 2.0f * (x * z + w * y);
+    R[1][0] = 2.0f * (x * y + w * z);
+    R[1][1] = 1.0f - 2.0f * (x * x + z * z);
+    R[1][2] = 2.0f * (y * z - w * x);
+    R[2][0] = 2.0f * (x * z - w * y);
+    R[2][1] = 2.0f * (y * z + w * x);
+    R[2][2] = 1.0f - 2.0f * (x * x + y * y);
+}
+__device__ __forceinline__ void mat_vec(const float R[3][3], const float *v, float *o)
+{
+    o[0] = R[0][0] * v[0] + R[0][1] * v[1] + R[0][2] * v[2];
+    o[1] = R[1][0] * v[0] + R[1][1] * v[1] + R[1][2] * v[2];
+    o[2] = R[2][0] * v[0] + R[2][1] * v[1] + R[2][2] * v[2];
+}
+
+__device__ __forceinline__ void mat_tvec(const float R[3][3], const float *v, float *o)  // o = R^T v
+{
+    o[0] = R[0][0] * v[0] + R[1][0] * v[1] + R[2][0] * v[2];
+    o[1] = R[0][1] * v[0] + R[1][1] * v[1] + R[2][1] * v[2];
+    o[2] = R[0][2] * v[0] + R[1][2] * v[1] + R[2][2] * v[2];
+}
+__device__ __forceinline__ float wdot3(const float *a, const float *w) { return a[0] * a[0] * w[0] + a[1] * a[1] * w[1] + a[2] * a[2] * w[2]; }
+
+// Philox4x32-10, counter = (global env id, reset count, draw block, stream), key = seed
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                           uint32_t out[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float u01(uint32_t u) { return (float)(u >> 8) * (1.0f / 16777216.0f); }
+
+// ------------------------------------------------------------------------------------------------ (a2) Ackermann
+// AckermannAction2.process_actions / ackermann, ackermann_actions.py:226-322 (quirks B-4, B-5 kept)
+__device__ __forceinline__ void ackermann_one(const rover_config &c, const float *raw, float *processed, float *steer,
+                                              float *wheel)
+{
+    processed[0] = raw[0] * c.scale_lin + c.offset_lin;
+    processed[1] = raw[1] * c.scale_ang + c.offset_ang;
+    float lin = processed[0], ang = processed[1];
+    const float d_fr = c.d_fr, d_mw = c.d_mw, wl = c.wheelbase;
+    float direction = sign_torch(lin);
+    const float turn = sign_torch(ang);
+    if (direction == 0.0f) direction = direction + 1.0f;
+    lin = fabsf(lin);
+    ang = fabsf(ang);
+    const bool not_zero = (ang != 0.0f) || (lin != 0.0f);
+    const float min_radius = d_mw * 0.8f;
+    float R = not_zero ? lin / ang : INFINITY;
+    if (R < min_radius) R = min_radius;
+    const float r_ML = R - (d_mw / 2.0f), r_MR = R + (d_mw / 2.0f);
+    const float r_FL = R - (d_fr / 2.0f), r_FR = R + (d_fr / 2.0f);
+    const float r_RL = R - (d_fr / 2.0f), r_RR = R + (d_fr / 2.0f);
+    const bool point = R < d_mw;
+    const float pt = (lin + 1.0f) * turn;
+    const bool az = ang == 0.0f;
+    const float v_FL = point ? -pt : (az ? lin : (r_FL * ang)) * direction;
+    const float v_FR = point ? pt : (az ? lin : (r_FR * ang)) * direction;
+    const float v_RL = point ? -pt : (az ? lin : (r_RL * ang)) * direction;
+    const float v_RR = point ? pt : (az ? lin : (r_RR * ang)) * direction;
+    const float v_ML = point ? -pt : (az ? lin : (r_ML * ang)) * direction;
+    const float v_MR = point ? pt : (az ? lin : (r_MR * ang)) * direction;
+    const float th = atan2f(wl, r_FL) * turn;
+    const float q = RV_PI_F / 4.0f;
+    wheel[0] = v_ML / c.wheel_radius; wheel[1] = v_FL / c.wheel_radius; wheel[2] = v_RL / c.wheel_radius;
+    wheel[3] = v_RR / c.wheel_radius; wheel[4] = v_MR / c.wheel_radius; wheel[5] = v_FR / c.wheel_radius;
+    steer[0] = point ? -q : th;  // FL
+    steer[1] = point ? q : th;   // RL
+    steer[2] = point ? -q : th;  // RR
+    steer[3] = point ? q : th;   // FR
+}
+
+// ------------------------------------------------------------------------------------------------ terrain look-ups
+// index quirk of get_height_at / check_if_target_is_valid: long(xy / res + [min_x, min_y]) (terrain_utils.py:75,211)
+__device__ __forceinline__ void quirk_cell(const RvParams &p, float x, float y, int &cx, int &cy)
+{
+    const float sx = x / p.res + p.min_x;
+    const float sy = y / p.res + p.min_y;
+    long long ix = (long long)sx, iy = (long long)sy;
+    if (ix < 0) ix = 0;
+    if (ix > p.W - 1) ix = p.W - 1;
+    if (iy < 0) iy = 0;
+    if (iy > p.H - 1) iy = p.H - 1;
+    cx = (int)ix;
+    cy = (int)iy;
+}
+
+// bilinear patch of the 0.05 m grid under (x, y): height, gradient and obstacle-layer height; 4 + 4 gathers
+template <bool WANT_OBST>
+__device__ __forceinline__ void terrain_sample(const RvParams &p, float x, float y, float &h, float &gx, float &gy,
+                                               float &obst)
+{
+    const float inv_res = 1.0f / p.res;
+    float u = (x - p.min_x) * inv_res;
+    float v = (y - p.min_y) * inv_res;
+    u = clampf(u, 0.0f, (float)(p.W - 1));
+    v = clampf(v, 0.0f, (float)(p.H - 1));
+    int j0 = (int)u, i0 = (int)v;
+    if (j0 > p.W - 2) j0 = p.W - 2;
+    if (i0 > p.H - 2) i0 = p.H - 2;
+    const float fx = u - (float)j0, fy = v - (float)i0;
+    const size_t base = (size_t)i0 * p.W + j0;
+    const float *q = p.height + base;
+    const float h00 = q[0], h01 = q[1], h10 = q[p.W], h11 = q[p.W + 1];
+    const float dx0 = h01 - h00, dx1 = h11 - h10, dy0 = h10 - h00, dy1 = h11 - h01;
+    const float hx0 = h00 + fx * dx0;
+    const float hx1 = h10 + fx * dx1;
+    h = hx0 + fy * (hx1 - hx0);
+    gx = (dx0 + fy * (dx1 - dx0)) * inv_res;
+    gy = (dy0 + fx * (dy1 - dy0)) * inv_res;
+    if (WANT_OBST) {
+        const float *o = p.obstacle + base;
+        const float o00 = o[0], o01 = o[1], o10 = o[p.W], o11 = o[p.W + 1];
+        const float o0 = o00 + fx * (o01 - o00);
+        const float o1 = o10 + fx * (o11 - o10);
+        obst = o0 + fy * (o1 - o0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ (a6) command
+__device__ __forceinline__ float wrap_to_pi(float a)
+{
+    float r = fmodf(a, RV_TWO_PI_F);
+    if (r != 0.0f && r < 0.0f) r += RV_TWO_PI_F;
+    if (r > RV_PI_F) r -= RV_TWO_PI_F;
+    return r;
+}
+__device__ __forceinline__ float heading_of(const float *q)
+{
+    const float w = q[0], x = q[1], y = q[2], z = q[3];
+    const float fx = 1.0f - 2.0f * (y * y + z * z);
+    const float fy = 2.0f * (w * z + x * y);
+    return atan2f(fy, fx);
+}
+// TerrainBasedPositionCommand._update_command, terrain_importer.py:97-101 (ORBIT yaw_quat + quat_rotate_inverse)
+__device__ __forceinline__ void update_command_one(const float *pos, const float *quat, const float *target_w,
+                                                   float heading_cmd_w, float *cmd_b, float *heading_b)
+{
+    const float qw = quat[0], qx = quat[1], qy = quat[2], qz = quat[3];
+    const float yaw = atan2f(2.0f * (qw * qz + qx * qy), 1.0f - 2.0f * (qy * qy + qz * qz));
+    float yw = cosf(yaw / 2.0f), yz = sinf(yaw / 2.0f);
+    const float nrm = sqrtf(yw * yw + yz * yz);
+    yw = yw / nrm;
+    yz = yz / nrm;
+    const float v[3] = {target_w[0] - pos[0], target_w[1] - pos[1], target_w[2] - pos[2]};
+    const float s = 2.0f * yw * yw - 1.0f;
+    const float qv[3] = {0.0f, 0.0f, yz};
+    float cr[3];
+    cross3(qv, v, cr);
+    const float dt = qv[0] * v[0] + qv[1] * v[1] + qv[2] * v[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) cmd_b[i] = v[i] * s - cr[i] * yw * 2.0f + qv[i] * dt * 2.0f;
+    *heading_b = wrap_to_pi(heading_cmd_w - heading_of(quat));
+}
+
+// ------------------------------------------------------------------------------------------------ (a9-a11) mdp terms
+__device__ __forceinline__ float collision_measure(const float *F /* 13 x 3 */)
+{
+    float acc = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float s = 0.0f;
+#pragma unroll
+        for (int b = 0; b < ROVER_NUM_BODIES; ++b) s += F[b * 3 + c] * F[b * 3 + c];
+        acc += sqrtf(s);
+    }
+    return acc;
+}
+
+// rewards.py:14-137, terminations.py:14-64, ORBIT mdp.time_out; rew = unweighted term values
+__device__ __forceinline__ void mdp_terms_one(const rover_config &c, const float *cmd_b, const float *action,
+                                              const float *prev_action, int ep_len, const float *F, float *rew,
+                                              bool *term)
+{
+    const float L = (float)c.max_episode_length;
+    const float d = sqrtf(cmd_b[0] * cmd_b[0] + cmd_b[1] * cmd_b[1]);
+    const float angle = atan2f(cmd_b[1], cmd_b[0]);
+    rew[0] = (1.0f / (1.0f + (0.11f * d * d))) / L;
+    rew[1] = (d < c.success_threshold) ? (float)(c.max_episode_length - ep_len) / L : 0.0f;
+    {
+        const float linear_diff = action[1] - prev_action[1];
+        const float angular_diff = action[0] - prev_action[0];
+        float ap = (angular_diff * 3.0f > 0.05f) ? (angular_diff * 3.0f) * (angular_diff * 3.0f) : 0.0f;
+        float lp = (linear_diff * 3.0f > 0.05f) ? (linear_diff * 3.0f) * (linear_diff * 3.0f) : 0.0f;
+        ap = ap * ap;
+        lp = lp * lp;
+        rew[2] = (ap + lp) / L;
+    }
+    rew[3] = (fabsf(angle) > 2.0f) ? fabsf(angle) / L : 0.0f;
+    rew[4] = (action[0] < 0.0f) ? (float)(1.0 / (double)c.max_episode_length) : 0.0f;
+    const bool coll = collision_measure(F) > 1.0f;  // hard-coded 1, `threshold` ignored (B-8)
+    rew[5] = coll ? 1.0f : 0.0f;
+    rew[6] = (d > c.far_threshold) ? 1.0f : 0.0f;
+    term[0] = ep_len >= c.max_episode_length;
+    term[1] = d < c.success_threshold;
+    term[2] = d > c.far_threshold;
+    term[3] = coll;
+}
+
+// ------------------------------------------------------------------------------------------------ (a3, a5) dynamics
+struct Contact {
+    float n[3], t[3], s[3];
+    float jn_a[3], jt_a[3], js_a[3];  // angular Jacobians R^T (r x dir), in the BODY frame (diagonal inertia)
+    float jn_b, jt_b, js_b;
+    float mn, mt, ms;
+    float bias;
+    float ln, lt, ls;
+    float obst;
+};
+
+// One physics substep (dt = sim_dt) of the reduced rover model; S = the env's state words in registers.
+// Mirrors oracle/rover_oracle.c physics_substep operation for operation.
+template <bool RECORD_FORCE>
+__device__ __forceinline__ void physics_substep(const RvParams &p, float *S, const float *steer_t, const float *wheel_t,
+                                                float *F /* 39, only if RECORD_FORCE */)
+{
+    constexpr float COM_B[3] = RV_COM_B_INIT;
+    constexpr float INERTIA_B[3] = RV_INERTIA_B_INIT;
+    constexpr float WHEEL_B[6][3] = RV_WHEEL_B_INIT;
+    constexpr int WHEEL_BOGIE[6] = RV_WHEEL_BOGIE_INIT;
+    constexpr int WHEEL_STEER[6] = RV_WHEEL_STEER_INIT;
+    constexpr int WHEEL_BODY[6] = RV_WHEEL_BODY_INIT;
+    constexpr float BOGIE_PIVOT[3][3] = RV_BOGIE_PIVOT_INIT;
+    constexpr float BOGIE_AXIS[3][3] = RV_BOGIE_AXIS_INIT;
+    constexpr float BOGIE_INERTIA[3] = RV_BOGIE_INERTIA_INIT;
+
+    const float h = p.cfg.sim_dt;
+    const float mu = p.cfg.friction_mu;
+    // ---- 1. steering joints: implicit PD
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const float q0 = S[ROVER_STEER_Q + s], qd0 = S[ROVER_STEER_QD + s];
+        const float e = steer_t[s] - q0;
+        float qd = (RV_STEER_INERTIA * qd0 + h * RV_STEER_KP * e) / (RV_STEER_INERTIA + h * RV_STEER_KD + h * h * RV_STEER_KP);
+        const float tau = (qd - qd0) * RV_STEER_INERTIA / h;
+        if (tau > RV_STEER_EFFORT) qd = qd0 + RV_STEER_EFFORT * h / RV_STEER_INERTIA;
+        if (tau < -RV_STEER_EFFORT) qd = qd0 - RV_STEER_EFFORT * h / RV_STEER_INERTIA;
+        qd = clampf(qd, -RV_STEER_VLIM, RV_STEER_VLIM);
+        float q = q0 + h * qd;
+        if (q > RV_STEER_QLIM) { q = RV_STEER_QLIM; qd = 0.0f; }
+        if (q < -RV_STEER_QLIM) { q = -RV_STEER_QLIM; qd = 0.0f; }
+        S[ROVER_STEER_Q + s] = q;
+        S[ROVER_STEER_QD + s] = qd;
+    }
+    // ---- 2. chassis frame, world inverse inertia, gravity
+    float R[3][3];
+    quat_to_mat(S + ROVER_QUAT, R);
+    float com_off[3], com_w[3];
+    mat_vec(R, COM_B, com_off);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) com_w[i] = S[ROVER_POS + i] + com_off[i];
+    const float inv_I[3] = {1.0f / INERTIA_B[0], 1.0f / INERTIA_B[1], 1.0f / INERTIA_B[2]};
+    float v[3] = {S[ROVER_LINVEL], S[ROVER_LINVEL + 1], S[ROVER_LINVEL + 2] - RV_GRAVITY * h};
+    float w[3];
+    mat_tvec(R, S + ROVER_ANGVEL, w);
+    float bd[3], bq[3], b_winv[3];
+    bool at_hi[3], at_lo[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        bq[j] = S[ROVER_BOGIE_Q + j];
+        bd[j] = S[ROVER_BOGIE_QD + j] / (1.0f + h * RV_BOGIE_DAMPING / BOGIE_INERTIA[j]);
+        b_winv[j] = 1.0f / BOGIE_INERTIA[j];
+        at_hi[j] = bq[j] >= RV_BOGIE_QLIM - 1.0e-5f;
+        at_lo[j] = bq[j] <= -RV_BOGIE_QLIM + 1.0e-5f;
+    }
+    const float inv_m = 1.0f / RV_M_TOTAL;
+    // ---- 3. contact geometry
+    Contact C[6];
+    float wheel_w[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        Contact &ct = C[k];
+        const int j = WHEEL_BOGIE[k];
+        const float P[3] = {BOGIE_PIVOT[j][0], BOGIE_PIVOT[j][1], BOGIE_PIVOT[j][2]};
+        const float ax[3] = {BOGIE_AXIS[j][0], BOGIE_AXIS[j][1], BOGIE_AXIS[j][2]};
+        const float d0[3] = {WHEEL_B[k][0] - P[0], WHEEL_B[k][1] - P[1], WHEEL_B[k][2] - P[2]};
+        const float cb = cosf(bq[j]), sb = sinf(bq[j]);
+        float axd[3];
+        cross3(ax, d0, axd);
+        const float ad = dot3(ax, d0);
+        float cen_b[3], cen_w[3], piv_w[3], ax_w[3], tmp[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) cen_b[i] = P[i] + (d0[i] * cb + axd[i] * sb + ax[i] * (ad * (1.0f - cb)));
+        mat_vec(R, cen_b, tmp);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) cen_w[i] = S[ROVER_POS + i] + tmp[i];
+        mat_vec(R, P, tmp);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) piv_w[i] = S[ROVER_POS + i] + tmp[i];
+        mat_vec(R, ax, ax_w);
+        float hgt, gx, gy;
+        ct.obst = 0.0f;
+        terrain_sample<RECORD_FORCE>(p, cen_w[0], cen_w[1], hgt, gx, gy, ct.obst);
+        const float inv = 1.0f / sqrtf(gx * gx + gy * gy + 1.0f);
+        ct.n[0] = -gx * inv; ct.n[1] = -gy * inv; ct.n[2] = inv;
+        const float gap = (cen_w[2] - hgt) * ct.n[2] - RV_WHEEL_CONTACT_RADIUS;
+        float cp[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) cp[i] = cen_w[i] - RV_WHEEL_CONTACT_RADIUS * ct.n[i];
+        const int si = WHEEL_STEER[k];
+        float fwd_b[3] = {1.0f, 0.0f, 0.0f}, fwd[3];
+        if (si >= 0) { fwd_b[0] = cosf(S[ROVER_STEER_Q + (si >= 0 ? si : 0)]); fwd_b[1] = sinf(S[ROVER_STEER_Q + (si >= 0 ? si : 0)]); }
+        mat_vec(R, fwd_b, fwd);
+        const float fn = dot3(fwd, ct.n);
+        float tl = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { ct.t[i] = fwd[i] - fn * ct.n[i]; tl += ct.t[i] * ct.t[i]; }
+        const float tinv = 1.0f / sqrtf(tl > 1.0e-12f ? tl : 1.0e-12f);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ct.t[i] *= tinv;
+        cross3(ct.n, ct.t, ct.s);
+        float r[3], rp[3], x[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { r[i] = cp[i] - com_w[i]; rp[i] = cp[i] - piv_w[i]; }
+        cross3(r, ct.n, x); mat_tvec(R, x, ct.jn_a);
+        cross3(r, ct.t, x); mat_tvec(R, x, ct.jt_a);
+        cross3(r, ct.s, x); mat_tvec(R, x, ct.js_a);
+        cross3(rp, ct.n, x); ct.jn_b = dot3(ax_w, x);
+        cross3(rp, ct.t, x); ct.jt_b = dot3(ax_w, x);
+        cross3(rp, ct.s, x); ct.js_b = dot3(ax_w, x);
+        if ((at_hi[j] && ct.jn_b > 0.0f) || (at_lo[j] && ct.jn_b < 0.0f)) ct.jn_b = 0.0f;
+        if (at_hi[j] || at_lo[j]) { ct.jt_b = 0.0f; ct.js_b = 0.0f; }
+        ct.mn = 1.0f / (inv_m + wdot3(ct.jn_a, inv_I) + ct.jn_b * ct.jn_b * b_winv[j]);
+        ct.mt = 1.0f / (inv_m + wdot3(ct.jt_a, inv_I) + ct.jt_b * ct.jt_b * b_winv[j]);
+        ct.ms = 1.0f / (inv_m + wdot3(ct.js_a, inv_I) + ct.js_b * ct.js_b * b_winv[j]);
+        if (gap > 0.0f) {
+            ct.bias = -gap / h;
+        } else {
+            const float push = RV_BAUMGARTE * (-gap) / h;
+            ct.bias = push < RV_MAX_DEPENETRATION_VEL ? push : RV_MAX_DEPENETRATION_VEL;
+        }
+        ct.ln = RV_WARM_START * S[ROVER_LAMBDA_N + k];
+        ct.lt = 0.0f;
+        ct.ls = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { v[i] += ct.n[i] * (ct.ln * inv_m); w[i] += ct.jn_a[i] * (inv_I[i] * ct.ln); }
+        bd[j] += ct.jn_b * b_winv[j] * ct.ln;
+        wheel_w[k] = S[ROVER_WHEEL_QD + k];
+    }
+    // ---- 4. projected Gauss-Seidel over {normal, longitudinal, lateral} x 6 wheels
+    const float lt_motor = RV_WHEEL_EFFORT * h / RV_WHEEL_CONTACT_RADIUS;
+    for (int it = 0; it < p.cfg.solver_iterations; ++it) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            Contact &ct = C[k];
+            const int j = WHEEL_BOGIE[k];
+            {
+                const float vrel = dot3(ct.n, v) + dot3(ct.jn_a, w) + ct.jn_b * bd[j];
+                float ln = ct.ln - (vrel - ct.bias) * ct.mn;
+                if (ln < 0.0f) ln = 0.0f;
+                const float d = ln - ct.ln;
+                ct.ln = ln;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { v[i] += ct.n[i] * (d * inv_m); w[i] += ct.jn_a[i] * (inv_I[i] * d); }
+                bd[j] += ct.jn_b * b_winv[j] * d;
+            }
+            const float lim = mu * ct.ln;
+            {
+                const float vrel = dot3(ct.t, v) + dot3(ct.jt_a, w) + ct.jt_b * bd[j] - RV_WHEEL_CONTACT_RADIUS * wheel_w[k];
+                const float lmax = lim < lt_motor ? lim : lt_motor;
+                const float lt = clampf(ct.lt - vrel * ct.mt, -lmax, lmax);
+                const float d = lt - ct.lt;
+                ct.lt = lt;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { v[i] += ct.t[i] * (d * inv_m); w[i] += ct.jt_a[i] * (inv_I[i] * d); }
+                bd[j] += ct.jt_b * b_winv[j] * d;
+            }
+            {
+                const float vrel = dot3(ct.s, v) + dot3(ct.js_a, w) + ct.js_b * bd[j];
+                const float ls = clampf(ct.ls - vrel * ct.ms, -lim, lim);
+                const float d = ls - ct.ls;
+                ct.ls = ls;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { v[i] += ct.s[i] * (d * inv_m); w[i] += ct.js_a[i] * (inv_I[i] * d); }
+                bd[j] += ct.js_b * b_winv[j] * d;
+            }
+        }
+    }
+    // ---- 5. wheel motors: implicit PD about q* = 0 with velocity target
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const float q0 = S[ROVER_WHEEL_Q + k], qd0 = S[ROVER_WHEEL_QD + k];
+        const float tgt = clampf(wheel_t[k], -RV_WHEEL_VLIM, RV_WHEEL_VLIM);
+        const float tau_ext = -RV_WHEEL_CONTACT_RADIUS * C[k].lt / h;
+        float qd = (RV_WHEEL_INERTIA * qd0 + h * (RV_WHEEL_KP * (0.0f - q0) + RV_WHEEL_KD * tgt + tau_ext)) /
+                   (RV_WHEEL_INERTIA + h * RV_WHEEL_KD + h * h * RV_WHEEL_KP);
+        const float tau = RV_WHEEL_KP * (0.0f - q0 - h * qd) + RV_WHEEL_KD * (tgt - qd);
+        if (tau > RV_WHEEL_EFFORT) qd = qd0 + h * (RV_WHEEL_EFFORT + tau_ext) / RV_WHEEL_INERTIA;
+        if (tau < -RV_WHEEL_EFFORT) qd = qd0 + h * (-RV_WHEEL_EFFORT + tau_ext) / RV_WHEEL_INERTIA;
+        qd = clampf(qd, -RV_WHEEL_VLIM, RV_WHEEL_VLIM);
+        float q = q0 + h * qd;
+        if (q > RV_TWO_PI_F) q -= RV_TWO_PI_F;
+        if (q < -RV_TWO_PI_F) q += RV_TWO_PI_F;
+        S[ROVER_WHEEL_Q + k] = q;
+        S[ROVER_WHEEL_QD + k] = qd;
+        S[ROVER_LAMBDA_N + k] = C[k].ln;
+    }
+    // ---- 6. obstacle contact report (forces on the Drive bodies that touch the obstacle layer)
+    if (RECORD_FORCE) {
+#pragma unroll
+        for (int i = 0; i < ROVER_NUM_BODIES * 3; ++i) F[i] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            if (C[k].obst > RV_OBSTACLE_EPS) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    F[WHEEL_BODY[k] * 3 + i] = (C[k].n[i] * C[k].ln + C[k].t[i] * C[k].lt + C[k].s[i] * C[k].ls) / h;
+            }
+        }
+    }
+    // ---- 7. integrate
+    const float sp = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    if (sp > RV_MAX_LINEAR_VEL) {
+        const float sc = RV_MAX_LINEAR_VEL / sp;
+        v[0] *= sc; v[1] *= sc; v[2] *= sc;
+    }
+    {
+        float ww[3];
+        mat_vec(R, w, ww);  // back to the world frame
+        w[0] = ww[0]; w[1] = ww[1]; w[2] = ww[2];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { com_w[i] += h * v[i]; S[ROVER_LINVEL + i] = v[i]; S[ROVER_ANGVEL + i] = w[i]; }
+    {
+        float *q = S + ROVER_QUAT;
+        const float qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+        const float hh = 0.5f * h;
+        const float nw = qw + hh * (-w[0] * qx - w[1] * qy - w[2] * qz);
+        const float nx = qx + hh * (w[0] * qw + w[1] * qz - w[2] * qy);
+        const float ny = qy + hh * (w[1] * qw + w[2] * qx - w[0] * qz);
+        const float nz = qz + hh * (w[2] * qw + w[0] * qy - w[1] * qx);
+        const float inv = 1.0f / sqrtf(nw * nw + nx * nx + ny * ny + nz * nz);
+        q[0] = nw * inv; q[1] = nx * inv; q[2] = ny * inv; q[3] = nz * inv;
+    }
+    quat_to_mat(S + ROVER_QUAT, R);
+    mat_vec(R, COM_B, com_off);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) S[ROVER_POS + i] = com_w[i] - com_off[i];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float q = bq[j] + h * bd[j];
+        float qd = bd[j];
+        if (q > RV_BOGIE_QLIM) { q = RV_BOGIE_QLIM; if (qd > 0.0f) qd = 0.0f; }
+        if (q < -RV_BOGIE_QLIM) { q = -RV_BOGIE_QLIM; if (qd < 0.0f) qd = 0.0f; }
+        S[ROVER_BOGIE_Q + j] = q;
+        S[ROVER_BOGIE_QD + j] = qd;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ (a7, a8) reset
+// target on the 9 m circle with rejection on the safe rock mask (terrain_importer.py:134-175), heading ~ U(lo, hi)
+__device__ __forceinline__ void resample_command(const RvParams &p, float *S, uint32_t gid, uint32_t count, float heading_u)
+{
+    const rover_config &c = p.cfg;
+    float tx = 0.0f, ty = 0.0f;
+    int tries = 0;
+    bool done = false;
+    for (uint32_t blk = 1; !done; ++blk) {
+        uint32_t r[4];
+        philox4x32(gid, count, blk, 0u, c.seed_lo, c.seed_hi, r);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (!done) {
+                const float theta = u01(r[i]) * 2.0f * RV_PI_F;
+                tx = cosf(theta) * c.target_distance + S[ROVER_ENV_ORIGIN + 0];
+                ty = sinf(theta) * c.target_distance + S[ROVER_ENV_ORIGIN + 1];
+                int cx, cy;
+                quirk_cell(p, tx, ty, cx, cy);
+                ++tries;
+                if (p.safe_mask[(size_t)cy * p.W + cx] != 1 || tries >= c.max_target_tries) done = true;
+            }
+        }
+    }
+    int cx, cy;
+    quirk_cell(p, tx, ty, cx, cy);
+    S[ROVER_TARGET_W + 0] = tx;
+    S[ROVER_TARGET_W + 1] = ty;
+    S[ROVER_TARGET_W + 2] = p.height[(size_t)cy * p.W + cx] + 0.0f;
+    S[ROVER_HEADING_CMD_W] = heading_u * (c.heading_hi - c.heading_lo) + c.heading_lo;
+    S[ROVER_TIME_LEFT] = c.resample_time;
+}
+
+// reset_root_state_rover (randomizations.py:12-39) + ORBIT manager resets (RLTaskEnv._reset_idx)
+__device__ __forceinline__ void reset_one(const RvParams &p, float *S, uint32_t gid)
+{
+    const rover_config &c = p.cfg;
+    const uint32_t count = __float_as_uint(S[ROVER_RESET_COUNT]);
+    uint32_t r[4];
+    philox4x32(gid, count, 0u, 0u, c.seed_lo, c.seed_hi, r);
+    const uint32_t row = r[0] % (uint32_t)p.n_spawns;
+    const float px = p.spawns[3 * row + 0], py = p.spawns[3 * row + 1];
+    const float pz = p.spawns[3 * row + 2] + c.reset_z_offset;
+    const float angle = u01(r[1]) * 2.0f * RV_PI_F;
+    S[ROVER_POS + 0] = px; S[ROVER_POS + 1] = py; S[ROVER_POS + 2] = pz;
+    S[ROVER_QUAT + 0] = cosf(angle / 2.0f); S[ROVER_QUAT + 1] = 0.0f; S[ROVER_QUAT + 2] = 0.0f;
+    S[ROVER_QUAT + 3] = sinf(angle / 2.0f);
+    S[ROVER_ENV_ORIGIN + 0] = px; S[ROVER_ENV_ORIGIN + 1] = py; S[ROVER_ENV_ORIGIN + 2] = pz;
+    if (c.reset_mode == 1) {
+#pragma unroll
+        for (int i = ROVER_LINVEL; i < ROVER_TARGET_W; ++i) S[i] = 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) S[ROVER_LAMBDA_N + k] = 0.0f;
+    S[ROVER_ACTION] = S[ROVER_ACTION + 1] = 0.0f;
+    S[ROVER_PREV_ACTION] = S[ROVER_PREV_ACTION + 1] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < ROVER_NUM_REW; ++i) S[ROVER_EP_SUM + i] = 0.0f;
+    S[ROVER_METRIC_POS] = 0.0f;
+    S[ROVER_METRIC_HEAD] = 0.0f;
+    resample_command(p, S, gid, count, u01(r[2]));
+    S[ROVER_EP_LEN] = __int_as_float(0);
+    S[ROVER_RESET_COUNT] = __uint_as_float(count + 1u);
+}
+
+// CommandTerm.compute: metrics -> timer -> (resample) -> update (terrain_importer.py:97-106)
+__device__ __forceinline__ void command_compute(const RvParams &p, float *S, uint32_t gid, float step_dt)
+{
+    {
+        const float dx = S[ROVER_TARGET_W] - S[ROVER_POS], dy = S[ROVER_TARGET_W + 1] - S[ROVER_POS + 1],
+                    dz = S[ROVER_TARGET_W + 2] - S[ROVER_POS + 2];
+        S[ROVER_METRIC_POS] = sqrtf(dx * dx + dy * dy + dz * dz);
+        S[ROVER_METRIC_HEAD] = fabsf(wrap_to_pi(S[ROVER_HEADING_CMD_W] - heading_of(S + ROVER_QUAT)));
+    }
+    S[ROVER_TIME_LEFT] -= step_dt;
+    if (S[ROVER_TIME_LEFT] <= 0.0f) {
+        const uint32_t count = __float_as_uint(S[ROVER_RESET_COUNT]);
+        uint32_t r[4];
+        philox4x32(gid, count, 0u, 1u, p.cfg.seed_lo, p.cfg.seed_hi, r);
+        resample_command(p, S, gid, count ^ 0x80000000u, u01(r[2]));
+    }
+    update_command_one(S + ROVER_POS, S + ROVER_QUAT, S + ROVER_TARGET_W, S[ROVER_HEADING_CMD_W], S + ROVER_CMD_B,
+                       S + ROVER_HEADING_CMD_B);
+}
+
+__device__ __forceinline__ float wave_sum(float x)
+{
+    // 64-lane butterfly: every lane ends with the same (order-deterministic) sum
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+    return x;
+}
+
+// ================================================================================================ K1: step kernel
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void rover_step_kernel(RvParams p, float *__restrict__ state,
+                                                        const float *__restrict__ action, float *__restrict__ reward,
+                                                        uint8_t *__restrict__ terminated, uint8_t *__restrict__ truncated,
+                                                        float *__restrict__ force, float *__restrict__ log_partial)
+{
+    const int e_raw = blockIdx.x * 64 + threadIdx.x;
+    const bool active = e_raw < p.n;
+    const int e = active ? e_raw : p.n - 1;  // idle tail lanes shadow the last env and store nothing
+    const int N = p.n;
+    const rover_config &c = p.cfg;
+
+    // physics words first (pose, velocities, joints, actions, contact cache); manager words after the physics so that
+    // they do not occupy registers across the solver
+    float S[ROVER_STATE_WORDS];
+#pragma unroll
+    for (int i = 0; i < ROVER_TARGET_W; ++i) S[i] = state[(size_t)i * N + e];
+#pragma unroll
+    for (int i = ROVER_ACTION; i < ROVER_ACTION + 2; ++i) S[i] = state[(size_t)i * N + e];
+#pragma unroll
+    for (int i = ROVER_LAMBDA_N; i < ROVER_LAMBDA_N + 6; ++i) S[i] = state[(size_t)i * N + e];
+
+    // rover_env.py:62 ActionManager.process_action
+    S[ROVER_PREV_ACTION] = S[ROVER_ACTION];
+    S[ROVER_PREV_ACTION + 1] = S[ROVER_ACTION + 1];
+    const float2 a = reinterpret_cast<const float2 *>(action)[e];
+    S[ROVER_ACTION] = a.x;
+    S[ROVER_ACTION + 1] = a.y;
+    float steer_m[4], wheel_m[6];
+    {
+        float processed[2], steer[4], wheel[6];
+        ackermann_one(c, S + ROVER_ACTION, processed, steer, wheel);
+        steer_m[0] = steer[0]; steer_m[1] = steer[3]; steer_m[2] = steer[1]; steer_m[3] = steer[2];  // FL, FR, RL, RR
+        wheel_m[0] = wheel[1]; wheel_m[1] = wheel[5]; wheel_m[2] = wheel[0];                            // FL, FR, CL,
+        wheel_m[3] = wheel[4]; wheel_m[4] = wheel[2]; wheel_m[5] = wheel[3];                            // CR, RL, RR
+    }
+
+    // rover_env.py:64-72 decimation loop; the contact report is the one of the last physics step
+    float F[ROVER_NUM_BODIES * 3];
+    for (int s = 0; s < c.decimation - 1; ++s) physics_substep<false>(p, S, steer_m, wheel_m, nullptr);
+    if (c.decimation > 0) {
+        physics_substep<true>(p, S, steer_m, wheel_m, F);
+    } else {
+#pragma unroll
+        for (int i = 0; i < ROVER_NUM_BODIES * 3; ++i) F[i] = 0.0f;
+    }
+
+#pragma unroll
+    for (int i = ROVER_TARGET_W; i < ROVER_ACTION; ++i) S[i] = state[(size_t)i * N + e];
+#pragma unroll
+    for (int i = ROVER_TIME_LEFT; i < ROVER_LAMBDA_N; ++i) S[i] = state[(size_t)i * N + e];
+    S[ROVER_RESET_COUNT] = state[(size_t)ROVER_RESET_COUNT * N + e];
+
+    // :79
+    const int ep_len = __float_as_int(S[ROVER_EP_LEN]) + 1;
+    S[ROVER_EP_LEN] = __int_as_float(ep_len);
+    // :82-86 terminations + rewards on the command of the PREVIOUS step (B-13)
+    float rew[ROVER_NUM_REW];
+    bool term[ROVER_NUM_TERM];
+    mdp_terms_one(c, S + ROVER_CMD_B, S + ROVER_ACTION, S + ROVER_PREV_ACTION, ep_len, F, rew, term);
+    const bool time_out = term[0];
+    const bool term_any = term[1] | term[2] | term[3];
+    const float step_dt = c.sim_dt * (float)c.decimation;
+    float total = 0.0f;
+#pragma unroll
+    for (int i = 0; i < ROVER_NUM_REW; ++i) {
+        if (c.rew_weight[i] != 0.0f) {
+            const float val = rew[i] * c.rew_weight[i] * step_dt;
+            total += val;
+            S[ROVER_EP_SUM + i] += val;
+        }
+    }
+    // :89-91 reset, with the episodic log contributions captured first
+    const bool do_reset = term_any | time_out;
+    float lg[14];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) lg[i] = 0.0f;
+    if (do_reset && active) {
+#pragma unroll
+        for (int i = 0; i < ROVER_NUM_REW; ++i) lg[i] = S[ROVER_EP_SUM + i];
+#pragma unroll
+        for (int i = 0; i < ROVER_NUM_TERM; ++i) lg[7 + i] = term[i] ? 1.0f : 0.0f;
+        lg[11] = S[ROVER_METRIC_POS];
+        lg[12] = S[ROVER_METRIC_HEAD];
+        lg[13] = 1.0f;
+    }
+    const uint32_t gid = (uint32_t)(p.env_id_offset + e);
+    if (do_reset) reset_one(p, S, gid);
+    // :93 command update
+    command_compute(p, S, gid, step_dt);
+
+    // wavefront reductions of the log partials (one row per wave)
+#pragma unroll
+    for (int i = 0; i < 14; ++i) lg[i] = wave_sum(lg[i]);
+    if (threadIdx.x < 14) {
+        float vsel = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 14; ++i) vsel = (threadIdx.x == i) ? lg[i] : vsel;
+        log_partial[(size_t)blockIdx.x * ROVER_LOG_WORDS + threadIdx.x] = vsel;
+    }
+
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < ROVER_STATE_WORDS; ++i) state[(size_t)i * N + e] = S[i];
+        reward[e] = total;
+        terminated[e] = term_any ? 1 : 0;
+        truncated[e] = time_out ? 1 : 0;
+        if (force) {
+#pragma unroll
+            for (int i = 0; i < ROVER_NUM_BODIES * 3; ++i) force[(size_t)i * N + e] = F[i];
+        }
+    }
+}
+
+// reset of every env (env.reset()): reset_one + _update_command, no physics
+__global__ __launch_bounds__(64) void rover_reset_kernel(RvParams p, float *__restrict__ state)
+{
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= p.n) return;
+    const int N = p.n;
+    float S[ROVER_STATE_WORDS];
+#pragma unroll
+    for (int i = 0; i < ROVER_STATE_WORDS; ++i) S[i] = state[(size_t)i * N + e];
+    reset_one(p, S, (uint32_t)(p.env_id_offset + e));
+    update_command_one(S + ROVER_POS, S + ROVER_QUAT, S + ROVER_TARGET_W, S[ROVER_HEADING_CMD_W], S + ROVER_CMD_B,
+                       S + ROVER_HEADING_CMD_B);
+#pragma unroll
+    for (int i = 0; i < ROVER_STATE_WORDS; ++i) state[(size_t)i * N + e] = S[i];
+}
+
+// ================================================================================================ K2: scan + obs
+// One workgroup per env.  out row = out + env * row_stride; scan values start at column col0.
+// WRITE_HEAD: also write [last_action(2), distance * 0.11, heading / pi] (ObservationCfg, rover_env_cfg.py:97-123)
+// and let block `n` reduce the log partials.
+template <bool WRITE_HEAD>
+__global__ __launch_bounds__(256) void rover_scan_obs_kernel(RvParams p, const float *__restrict__ state,
+                                                             float *__restrict__ out, int row_stride, int col0,
+                                                             const float *__restrict__ log_partial, int n_waves,
+                                                             float *__restrict__ log_out)
+{
+    extern __shared__ __align__(16) float lds[];
+    const int tid = threadIdx.x;
+    const int N = p.n;
+    if (WRITE_HEAD && (int)blockIdx.x == N) {
+        // deterministic reduction of the per-wave log partials: 16 groups x 16 words, then a fixed-order tree
+        const int word = tid & 15, grp = tid >> 4;
+        float acc = 0.0f;
+        for (int w = grp; w < n_waves; w += 16) acc += log_partial[(size_t)w * ROVER_LOG_WORDS + word];
+        lds[grp * 16 + word] = acc;
+        __syncthreads();
+        if (tid < 16) {
+            float s = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) s += lds[g * 16 + tid];
+            lds[256 + tid] = s;
+        }
+        __syncthreads();
+        if (tid < 14) {
+            const float cnt = lds[256 + 13];
+            if (tid == 13) {
+                log_out[13] = cnt;
+            } else if (cnt > 0.0f) {
+                const float s = lds[256 + tid];
+                float val;
+                if (tid < ROVER_NUM_REW) val = s / cnt / p.cfg.max_episode_length_s;  // Episode Reward/<term>
+                else if (tid < 11) val = s;                                            // Episode Termination/<term>
+                else val = s / cnt;                                                    // Metrics/target_pose/*
+                log_out[tid] = val;
+            }
+        }
+        return;
+    }
+    const int e = blockIdx.x;
+    const rover_config &c = p.cfg;
+    const float px = state[(size_t)(ROVER_POS + 0) * N + e];
+    const float py = state[(size_t)(ROVER_POS + 1) * N + e];
+    const float pz = state[(size_t)(ROVER_POS + 2) * N + e];
+    const float qw = state[(size_t)(ROVER_QUAT + 0) * N + e];
+    const float qx = state[(size_t)(ROVER_QUAT + 1) * N + e];
+    const float qy = state[(size_t)(ROVER_QUAT + 2) * N + e];
+    const float qz = state[(size_t)(ROVER_QUAT + 3) * N + e];
+    // yaw-only attachment (rover_env_cfg.py:81): (cos, sin)(yaw) straight from the quaternion
+    const float a = 1.0f - 2.0f * (qy * qy + qz * qz);
+    const float b = 2.0f * (qw * qz + qx * qy);
+    const float inv = 1.0f / sqrtf(a * a + b * b);
+    const float cy = a * inv, sy = b * inv;
+    const float inv_res = 1.0f / p.res;
+
+    // window of the heightfield covered by the rotated pattern (+ 2 cells of slack), clamped to the map
+    const float hx = 0.5f * c.scan_size_x, hy = 0.5f * c.scan_size_y;
+    const float ex = fabsf(cy) * hx + fabsf(sy) * hy, ey = fabsf(sy) * hx + fabsf(cy) * hy;
+    int j_lo = (int)floorf((px - ex - p.min_x) * inv_res) - 1;
+    int i_lo = (int)floorf((py - ey - p.min_y) * inv_res) - 1;
+    int j_hi = (int)floorf((px + ex - p.min_x) * inv_res) + 2;
+    int i_hi = (int)floorf((py + ey - p.min_y) * inv_res) + 2;
+    j_lo = max(0, min(j_lo, p.W - 1)); j_hi = max(0, min(j_hi, p.W - 1));
+    i_lo = max(0, min(i_lo, p.H - 1)); i_hi = max(0, min(i_hi, p.H - 1));
+    const int td = p.tile_dim;
+    const int tw = min(j_hi - j_lo + 1, td), th = min(i_hi - i_lo + 1, td);
+    const int pitch = td + 1;
+    // stage the window: consecutive lanes read consecutive cells of a row (coalesced 4-B loads)
+    for (int idx = tid; idx < th * tw; idx += 256) {
+        const int r = idx / tw, cc = idx - r * tw;
+        lds[r * pitch + cc] = p.height[(size_t)(i_lo + r) * p.W + (j_lo + cc)];
+    }
+    __syncthreads();
+
+    const float x_max = p.min_x + (float)(p.W - 1) * p.res;
+    const float y_max = p.min_y + (float)(p.H - 1) * p.res;
+    float *row = out + (size_t)e * row_stride + col0;
+    for (int ray = tid; ray < p.rays; ray += 256) {
+        const int i = ray / c.scan_nx, j = ray - i * c.scan_nx;
+        // ORBIT grid_pattern: arange(-size/2, size/2 + 1e-9, res), x fastest (App. C)
+        const float oy = (float)(-0.5 * (double)c.scan_size_y + (double)c.scan_resolution * (double)i);
+        const float ox = (float)(-0.5 * (double)c.scan_size_x + (double)c.scan_resolution * (double)j);
+        const float x = px + (cy * ox - sy * oy);
+        const float y = py + (sy * ox + cy * oy);
+        float hgt;
+        if (x < p.min_x || x > x_max || y < p.min_y || y > y_max) {
+            hgt = INFINITY;  // ray leaves the terrain: ORBIT RayCaster reports +inf
+        } else {
+            float u = (x - p.min_x) * inv_res;
+            float v = (y - p.min_y) * inv_res;
+            u = clampf(u, 0.0f, (float)(p.W - 1));
+            v = clampf(v, 0.0f, (float)(p.H - 1));
+            int j0 = (int)u, i0 = (int)v;
+            if (j0 > p.W - 2) j0 = p.W - 2;
+            if (i0 > p.H - 2) i0 = p.H - 2;
+            const float fx = u - (float)j0, fy = v - (float)i0;
+            const int jl = j0 - j_lo, il = i0 - i_lo;
+            float h00, h01, h10, h11;
+            if (jl >= 0 && il >= 0 && jl + 1 < tw && il + 1 < th) {
+                const float *q = lds + il * pitch + jl;
+                h00 = q[0]; h01 = q[1]; h10 = q[pitch]; h11 = q[pitch + 1];
+            } else {  // outside the staged window (cannot happen with the slack above; kept for safety)
+                const float *q = p.height + (size_t)i0 * p.W + j0;
+                h00 = q[0]; h01 = q[1]; h10 = q[p.W]; h11 = q[p.W + 1];
+            }
+            const float dx0 = h01 - h00, dx1 = h11 - h10;
+            const float hx0 = h00 + fx * dx0;
+            const float hx1 = h10 + fx * dx1;
+            hgt = hx0 + fy * (hx1 - hx0);
+        }
+        row[ray] = pz - hgt - c.scan_height_offset;  // observations.py:45
+    }
+    if (WRITE_HEAD && tid == 0) {
+        const float cbx = state[(size_t)(ROVER_CMD_B + 0) * N + e];
+        const float cby = state[(size_t)(ROVER_CMD_B + 1) * N + e];
+        float *o = out + (size_t)e * row_stride;
+        o[0] = state[(size_t)(ROVER_ACTION + 0) * N + e];
+        o[1] = state[(size_t)(ROVER_ACTION + 1) * N + e];
+        o[2] = sqrtf(cbx * cbx + cby * cby) * c.obs_scale_distance;
+        o[3] = atan2f(cby, cbx) * c.obs_scale_heading;
+    }
+}
+
+// ================================================================================================ unit kernels
+__global__ void rover_ackermann_kernel(rover_config c, int n, const float *raw, float *processed, float *steer, float *wheel)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r[2] = {raw[2 * i], raw[2 * i + 1]}, pr[2], st[4], wh[6];
+    ackermann_one(c, r, pr, st, wh);
+    processed[2 * i] = pr[0]; processed[2 * i + 1] = pr[1];
+    for (int k = 0; k < 4; ++k) steer[4 * i + k] = st[k];
+    for (int k = 0; k < 6; ++k) wheel[6 * i + k] = wh[k];
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void rover_physics_kernel(RvParams p, float *__restrict__ state, const float *steer_t,
+                                                           const float *wheel_t, int substeps, float *force)
+{
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= p.n) return;
+    const int N = p.n;
+    float S[ROVER_STATE_WORDS];
+#pragma unroll
+    for (int i = 0; i < ROVER_STATE_WORDS; ++i) S[i] = state[(size_t)i * N + e];
+    float st[4], wt[6], F[ROVER_NUM_BODIES * 3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) st[k] = steer_t[4 * e + k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) wt[k] = wheel_t[6 * e + k];
+#pragma unroll
+    for (int i = 0; i < ROVER_NUM_BODIES * 3; ++i) F[i] = 0.0f;
+    for (int s = 0; s < substeps - 1; ++s) physics_substep<false>(p, S, st, wt, nullptr);
+    if (substeps > 0) physics_substep<true>(p, S, st, wt, F);
+#pragma unroll
+    for (int i = 0; i < ROVER_STATE_WORDS; ++i) state[(size_t)i * N + e] = S[i];
+    if (force) {
+#pragma unroll
+        for (int i = 0; i < ROVER_NUM_BODIES * 3; ++i) force[(size_t)i * N + e] = F[i];
+    }
+}
+
+thread_local char g_err[512] = "";
+int fail(int code, const char *fmt, const char *detail = "")
+{
+    snprintf(g_err, sizeof(g_err), fmt, detail);
+    return code;
+}
+#define HIP_TRY(expr)                                                                                                  \
+    do {                                                                                                               \
+        hipError_t _e = (expr);                                                                                        \
+        if (_e != hipSuccess) return fail(ROVER_ERR_HIP, #expr ": %s", hipGetErrorString(_e));                        \
+    } while (0)
+
+}  // namespace
+
+// ==================================================================================================== C ABI
+struct rover_sim {
+    RvParams p;
+    int device;
+    bool have_terrain;
+    float *state;
+    float *log_partial;
+    size_t ws_bytes;
+    int n_waves;
+    size_t lds_bytes;
+};
+
+extern "C" {
+
+int rover_default_config(rover_config *c)
+{
+    if (!c) return fail(ROVER_ERR_INVALID, "cfg is NULL");
+    memset(c, 0, sizeof(*c));
+    c->scale_lin = 1.0f; c->scale_ang = 1.0f;              // actions_cfg.py:20
+    c->offset_lin = -0.0135f; c->offset_ang = -0.0135f;    // aau_rover/env_cfg.py:30 (broadcast to both, B-4)
+    c->wheel_radius = 0.1f; c->d_fr = 0.77f; c->d_mw = 0.894f; c->wheelbase = 0.849f;  // env_cfg.py:23-26
+    c->sim_dt = 1.0f / 30.0f; c->decimation = 6;           // rover_env_cfg.py:269-270
+    c->max_episode_length = 750; c->max_episode_length_s = 150.0f;  // :271
+    c->success_threshold = 0.18f; c->far_threshold = 11.0f;          // :136,162,173,177
+    c->target_distance = 9.0f;                             // terrain_importer.py:132
+    c->heading_lo = -RV_PI_F; c->heading_hi = RV_PI_F; c->resample_time = 150.0f;  // rover_env_cfg.py:195-198
+    const float w[ROVER_NUM_REW] = {5.0f, 5.0f, -0.1f, -1.5f, -0.5f, -2.0f, -2.0f};  // :126-163
+    memcpy(c->rew_weight, w, sizeof(w));
+    c->obs_scale_distance = 0.11f;                         // :104
+    c->obs_scale_heading = (float)(1.0 / 3.141592653589793);  // :110
+    c->scan_resolution = 0.1f; c->scan_size_x = 3.0f; c->scan_size_y = 3.0f;  // :82
+    c->scan_nx = 31; c->scan_ny = 31;
+    c->scan_height_offset = 0.26878f;                      // observations.py:45
+    c->reset_z_offset = 0.5f;                              // randomizations.py:12
+    c->reset_mode = 0;
+    c->seed_lo = 0u; c->seed_hi = 0u;
+    c->friction_mu = 0.75f;
+    c->solver_iterations = 8;
+    c->max_target_tries = 32;
+    return ROVER_OK;
+}
+
+int rover_create(const rover_config *cfg, int32_t num_envs, int32_t env_id_offset, int32_t device, rover_sim **out)
+{
+    if (!cfg || !out) return fail(ROVER_ERR_INVALID, "cfg/out is NULL");
+    if (num_envs <= 0 || env_id_offset < 0) return fail(ROVER_ERR_INVALID, "num_envs must be > 0 and env_id_offset >= 0");
+    if (cfg->scan_nx <= 0 || cfg->scan_ny <= 0 || cfg->scan_resolution <= 0.0f || cfg->decimation < 0 ||
+        cfg->solver_iterations < 0 || cfg->max_target_tries < 1 || cfg->sim_dt <= 0.0f || cfg->max_episode_length <= 0)
+        return fail(ROVER_ERR_INVALID, "invalid rover_config");
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return fail(ROVER_ERR_INVALID, "device ordinal out of range");
+    rover_sim *s = new (std::nothrow) rover_sim();
+    if (!s) return fail(ROVER_ERR_INVALID, "out of host memory");
+    memset(s, 0, sizeof(*s));
+    s->p.cfg = *cfg;
+    s->p.n = num_envs;
+    s->p.env_id_offset = env_id_offset;
+    s->p.rays = cfg->scan_nx * cfg->scan_ny;
+    s->p.obs_w = 4 + s->p.rays;
+    s->device = device;
+    s->n_waves = (num_envs + 63) / 64;
+    s->ws_bytes = (size_t)s->n_waves * ROVER_LOG_WORDS * sizeof(float);
+    *out = s;
+    return ROVER_OK;
+}
+
+int rover_destroy(rover_sim *sim)
+{
+    delete sim;
+    return ROVER_OK;
+}
+
+int rover_set_terrain(rover_sim *sim, const float *height, const float *obstacle, const uint8_t *safe_mask, int32_t H,
+                      int32_t W, float resolution, float min_x, float min_y, const float *spawns, int32_t n_spawns)
+{
+    if (!sim) return fail(ROVER_ERR_INVALID, "sim is NULL");
+    if (!height || !obstacle || !safe_mask || !spawns) return fail(ROVER_ERR_INVALID, "terrain pointer is NULL");
+    if (H < 2 || W < 2 || resolution <= 0.0f || n_spawns < 1) return fail(ROVER_ERR_INVALID, "bad terrain shape");
+    RvParams &p = sim->p;
+    p.height = height; p.obstacle = obstacle; p.safe_mask = safe_mask; p.spawns = spawns;
+    p.H = H; p.W = W; p.n_spawns = n_spawns; p.res = resolution; p.min_x = min_x; p.min_y = min_y;
+    // LDS tile: diagonal of the ray pattern in cells + slack
+    const float diag = sqrtf(p.cfg.scan_size_x * p.cfg.scan_size_x + p.cfg.scan_size_y * p.cfg.scan_size_y);
+    p.tile_dim = (int)ceilf(diag / resolution) + 6;
+    sim->lds_bytes = (size_t)p.tile_dim * (p.tile_dim + 1) * sizeof(float);
+    if (sim->lds_bytes < 272 * sizeof(float)) sim->lds_bytes = 272 * sizeof(float);
+    if (sim->lds_bytes > 64 * 1024) return fail(ROVER_ERR_UNSUPPORTED, "ray pattern too large for the LDS tile (64 KiB)");
+    sim->have_terrain = true;
+    return ROVER_OK;
+}
+
+size_t rover_workspace_bytes(const rover_sim *sim) { return sim ? sim->ws_bytes : 0; }
+
+int rover_bind(rover_sim *sim, float *state, void *workspace, size_t workspace_bytes)
+{
+    if (!sim || !state || !workspace) return fail(ROVER_ERR_INVALID, "NULL argument");
+    if (workspace_bytes < sim->ws_bytes) return fail(ROVER_ERR_INVALID, "workspace too small");
+    sim->state = state;
+    sim->log_partial = static_cast<float *>(workspace);
+    return ROVER_OK;
+}
+
+static int ready(rover_sim *sim)
+{
+    if (!sim) return fail(ROVER_ERR_INVALID, "sim is NULL");
+    if (!sim->have_terrain) return fail(ROVER_ERR_STATE, "rover_set_terrain has not been called");
+    if (!sim->state) return fail(ROVER_ERR_STATE, "rover_bind has not been called");
+    return ROVER_OK;
+}
+
+int rover_reset(rover_sim *sim, float *obs, void *stream)
+{
+    if (int rc = ready(sim)) return rc;
+    if (!obs) return fail(ROVER_ERR_INVALID, "obs is NULL");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const RvParams &p = sim->p;
+    hipLaunchKernelGGL(rover_reset_kernel, dim3(sim->n_waves), dim3(64), 0, st, p, sim->state);
+    hipLaunchKernelGGL(rover_scan_obs_kernel<true>, dim3(p.n), dim3(256), sim->lds_bytes, st, p, sim->state, obs, p.obs_w,
+                       4, (const float *)nullptr, 0, (float *)nullptr);
+    HIP_TRY(hipGetLastError());
+    return ROVER_OK;
+}
+
+int rover_step(rover_sim *sim, const float *action, float *obs, float *reward, uint8_t *terminated, uint8_t *truncated,
+               float *force, float *log, void *stream)
+{
+    if (int rc = ready(sim)) return rc;
+    if (!action || !obs || !reward || !terminated || !truncated || !log) return fail(ROVER_ERR_INVALID, "NULL buffer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const RvParams &p = sim->p;
+    hipLaunchKernelGGL(rover_step_kernel, dim3(sim->n_waves), dim3(64), 0, st, p, sim->state, action, reward, terminated,
+                       truncated, force, sim->log_partial);
+    hipLaunchKernelGGL(rover_scan_obs_kernel<true>, dim3(p.n + 1), dim3(256), sim->lds_bytes, st, p, sim->state, obs,
+                       p.obs_w, 4, sim->log_partial, sim->n_waves, log);
+    HIP_TRY(hipGetLastError());
+    return ROVER_OK;
+}
+
+int rover_profile_step(rover_sim *sim, const float *action, float *obs, float *reward, uint8_t *terminated,
+                       uint8_t *truncated, float *force, float *log, void *stream, float *ms_step_kernel,
+                       float *ms_scan_kernel)
+{
+    // Same two launches as rover_step, bracketed by HIP events on `stream`; synchronises (profiling only).
+    if (int rc = ready(sim)) return rc;
+    if (!action || !obs || !reward || !terminated || !truncated || !log || !ms_step_kernel || !ms_scan_kernel)
+        return fail(ROVER_ERR_INVALID, "NULL buffer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const RvParams &p = sim->p;
+    hipEvent_t ev[3];
+    for (int i = 0; i < 3; ++i) HIP_TRY(hipEventCreate(&ev[i]));
+    HIP_TRY(hipEventRecord(ev[0], st));
+    hipLaunchKernelGGL(rover_step_kernel, dim3(sim->n_waves), dim3(64), 0, st, p, sim->state, action, reward, terminated,
+                       truncated, force, sim->log_partial);
+    HIP_TRY(hipEventRecord(ev[1], st));
+    hipLaunchKernelGGL(rover_scan_obs_kernel<true>, dim3(p.n + 1), dim3(256), sim->lds_bytes, st, p, sim->state, obs,
+                       p.obs_w, 4, sim->log_partial, sim->n_waves, log);
+    HIP_TRY(hipEventRecord(ev[2], st));
+    HIP_TRY(hipEventSynchronize(ev[2]));
+    HIP_TRY(hipEventElapsedTime(ms_step_kernel, ev[0], ev[1]));
+    HIP_TRY(hipEventElapsedTime(ms_scan_kernel, ev[1], ev[2]));
+    for (int i = 0; i < 3; ++i) HIP_TRY(hipEventDestroy(ev[i]));
+    HIP_TRY(hipGetLastError());
+    return ROVER_OK;
+}
+
+int rover_ackermann(rover_sim *sim, int32_t n, const float *raw, float *processed, float *steer, float *wheel, void *stream)
+{
+    if (!sim || !raw || !processed || !steer || !wheel || n <= 0) return fail(ROVER_ERR_INVALID, "bad argument");
+    hipLaunchKernelGGL(rover_ackermann_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       sim->p.cfg, n, raw, processed, steer, wheel);
+    HIP_TRY(hipGetLastError());
+    return ROVER_OK;
+}
+
+int rover_height_scan(rover_sim *sim, float *scan, void *stream)
+{
+    if (int rc = ready(sim)) return rc;
+    if (!scan) return fail(ROVER_ERR_INVALID, "scan is NULL");
+    const RvParams &p = sim->p;
+    hipLaunchKernelGGL(rover_scan_obs_kernel<false>, dim3(p.n), dim3(256), sim->lds_bytes, static_cast<hipStream_t>(stream), p,
+                       sim->state, scan, p.rays, 0, (const float *)nullptr, 0, (float *)nullptr);
+    HIP_TRY(hipGetLastError());
+    return ROVER_OK;
+}
+
+int rover_physics(rover_sim *sim, const float *steer_target, const float *wheel_target, int32_t substeps, float *force,
+                  void *stream)
+{
+    if (int rc = ready(sim)) return rc;
+    if (!steer_target || !wheel_target || substeps < 0) return fail(ROVER_ERR_INVALID, "bad argument");
+    hipLaunchKernelGGL(rover_physics_kernel, dim3(sim->n_waves), dim3(64), 0, static_cast<hipStream_t>(stream), sim->p,
+                       sim->state, steer_target, wheel_target, substeps, force);
+    HIP_TRY(hipGetLastError());
+    return ROVER_OK;
+}
+
+int rover_model_constants(float *out, int32_t cap)
+{
+    const float com[3] = RV_COM_B_INIT, inertia[3] = RV_INERTIA_B_INIT, wheel[6][3] = RV_WHEEL_B_INIT;
+    const float pivot[3][3] = RV_BOGIE_PIVOT_INIT, axis[3][3] = RV_BOGIE_AXIS_INIT, binertia[3] = RV_BOGIE_INERTIA_INIT;
+    float t[64];
+    int n = 0;
+    t[n++] = RV_M_TOTAL;
+    for (int i = 0; i < 3; ++i) t[n++] = com[i];
+    for (int i = 0; i < 3; ++i) t[n++] = inertia[i];
+    for (int k = 0; k < 6; ++k) for (int i = 0; i < 3; ++i) t[n++] = wheel[k][i];
+    for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) t[n++] = pivot[k][i];
+    for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) t[n++] = axis[k][i];
+    for (int k = 0; k < 3; ++k) t[n++] = binertia[k];
+    t[n++] = RV_WHEEL_CONTACT_RADIUS;
+    t[n++] = RV_STEER_INERTIA; t[n++] = RV_STEER_KP; t[n++] = RV_STEER_KD; t[n++] = RV_STEER_EFFORT; t[n++] = RV_STEER_VLIM;
+    t[n++] = RV_WHEEL_INERTIA; t[n++] = RV_WHEEL_KP; t[n++] = RV_WHEEL_KD; t[n++] = RV_WHEEL_EFFORT; t[n++] = RV_WHEEL_VLIM;
+    t[n++] = RV_BOGIE_QLIM; t[n++] = RV_BOGIE_DAMPING; t[n++] = RV_BAUMGARTE; t[n++] = RV_MAX_DEPENETRATION_VEL;
+    t[n++] = RV_MAX_LINEAR_VEL; t[n++] = RV_GRAVITY; t[n++] = RV_OBSTACLE_EPS; t[n++] = RV_WARM_START; t[n++] = RV_STEER_QLIM;
+    if (out) for (int i = 0; i < n && i < cap; ++i) out[i] = t[i];
+    return n;
+}
+
+int rover_state_words(void) { return ROVER_STATE_WORDS; }
+const char *rover_last_error(void) { return g_err; }
+const char *rover_version(void) { return "isaac_rover_orbit_amd 0.1.0 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,46 @@
+// rover_model.hpp -- constants of the reduced AAU-rover model used by the HIP kernels (gfx950).
+//
+// Values come from the reference asset rover_envs/assets/robots/aau_rover_simple/rover_instance.usd (joint frames,
+// masses; SURVEY.md App. A/E -> tools/derive_rover_model.py -> tests/golden/rover_model.json) and from the actuator /
+// rigid-body configuration rover_envs/assets/robots/aau_rover_simple.py:18-65.  tests/test_model_constants.py checks
+// this table against the JSON fixture and against the CPU oracle's own copy.
+#pragma once
+
+#define RV_M_TOTAL 25.0f
+#define RV_COM_B_INIT {0.006704f, 0.0f, -0.054646f}
+#define RV_INERTIA_B_INIT {3.354645f, 3.344834f, 6.149923f}
+// wheel order: FL, FR, CL, CR, RL, RR
+#define RV_WHEEL_B_INIT                                                                                                \
+    {{0.44f, 0.3925f, -0.16699f}, {0.44f, -0.3925f, -0.16699f}, {0.007f, 0.3885f, -0.16699f},                          \
+     {0.007f, -0.3885f, -0.16699f}, {-0.44f, 0.3925f, -0.16699f}, {-0.44f, -0.3925f, -0.16699f}}
+#define RV_WHEEL_BOGIE_INIT {0, 1, 0, 1, 2, 2}
+#define RV_WHEEL_STEER_INIT {0, 1, -1, -1, 2, 3}   // steer order: FL, FR, RL, RR
+#define RV_WHEEL_BODY_INIT {9, 10, 7, 8, 11, 12}   // row in the 13-body contact sensor (rover_env_cfg.py:72-75)
+// bogie order: FL_Boogie, FR_Boogie, R_Boogie
+#define RV_BOGIE_PIVOT_INIT {{0.1535f, 0.2225f, 0.03f}, {0.1535f, -0.2225f, 0.03f}, {-0.325f, 0.0f, 0.03f}}
+#define RV_BOGIE_AXIS_INIT {{0.0f, 1.0f, 0.0f}, {0.0f, -1.0f, 0.0f}, {1.0f, 0.0f, 0.0f}}
+#define RV_BOGIE_INERTIA_INIT {0.47474f, 0.47474f, 1.141279f}
+#define RV_WHEEL_CONTACT_RADIUS 0.10179f  // 0.26878 (observations.py:45) - 0.16699
+// actuators: aau_rover_simple.py:42-64
+#define RV_STEER_INERTIA 0.005f
+#define RV_STEER_KP 8000.0f
+#define RV_STEER_KD 1000.0f
+#define RV_STEER_EFFORT 12.0f
+#define RV_STEER_VLIM 6.0f
+#define RV_STEER_QLIM 1.5707963267948966f
+#define RV_WHEEL_INERTIA 0.005f
+#define RV_WHEEL_KP 100.0f
+#define RV_WHEEL_KD 4000.0f
+#define RV_WHEEL_EFFORT 12.0f
+#define RV_WHEEL_VLIM 6.0f
+#define RV_BOGIE_QLIM 0.17453292519943295f
+#define RV_BOGIE_DAMPING 2.0f
+#define RV_BAUMGARTE 0.2f
+#define RV_MAX_DEPENETRATION_VEL 1.0f  // aau_rover_simple.py:27
+#define RV_MAX_LINEAR_VEL 1.5f         // aau_rover_simple.py:25
+#define RV_GRAVITY 9.81f
+#define RV_OBSTACLE_EPS 1.0e-3f
+#define RV_WARM_START 0.85f
+
+#define RV_PI_F 3.14159265358979323846f
+#define RV_TWO_PI_F 6.28318530717958647692f

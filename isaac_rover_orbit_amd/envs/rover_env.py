@@ -1,0 +1,404 @@
+"""``RoverEnv`` -- the gymnasium / ORBIT ``RLTaskEnv``-shaped boundary of the MI355X-native rover hot path.
+
+Reproduces the object protocol the reference's consumers use:
+
+* ``rover_envs/envs/navigation/entrypoints/rover_env.py:12-102``  ``RoverEnv.__init__ / step / _reset_idx``
+* ``rover_envs/utils/skrl_utils.py:38-41,114-142``                 skrl "isaac-orbit" wrapper + trainer loop
+* ``examples/02_train/train.py:123-134``                           ``observation_manager.group_obs_dim`` etc.
+* the mdp term signatures (``env.command_manager.get_command``, ``env.action_manager.action``,
+  ``env.scene.sensors[...]``, ``env.episode_length_buf`` ...)
+
+``step()`` is two HIP kernel launches through the C ABI (``include/rover_hip.h``); nothing is computed in Python or
+torch on the hot path and there is no host synchronisation.  All tensors live on the env's GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..cfg import OBS_ORDER, REWARD_ORDER, TERMINATION_ORDER, RoverEnvCfg
+from ..terrain import Terrain, make_flat_terrain, make_procedural_terrain
+
+try:  # gymnasium is what the reference uses (robots/aau_rover/__init__.py:3); optional here
+    import gymnasium as gym
+    from gymnasium import spaces as _spaces
+    _GymEnv = gym.Env
+except Exception:  # pragma: no cover - exercised only where gymnasium is absent
+    gym = None
+    _GymEnv = object
+
+    class _Box:
+        """Minimal stand-in for ``gymnasium.spaces.Box`` (shape / low / high / dtype only)."""
+
+        def __init__(self, low, high, shape, dtype=np.float32):
+            self.low = np.full(shape, low, dtype=dtype)
+            self.high = np.full(shape, high, dtype=dtype)
+            self.shape = tuple(shape)
+            self.dtype = np.dtype(dtype)
+
+        def __repr__(self):
+            return f"Box({self.low.min()}, {self.high.max()}, {self.shape}, {self.dtype})"
+
+    class _Dict(dict):
+        pass
+
+    class _spaces:  # noqa: N801
+        Box = _Box
+        Dict = _Dict
+
+
+def _ptr(t: torch.Tensor | None):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class _ActionManager:
+    """``env.action_manager`` facade (ORBIT ActionManager): zero-copy views into the SoA state tensor."""
+
+    def __init__(self, env):
+        self._env = env
+        self.action_term_dim = [2]                      # train.py:132
+        self.total_action_dim = 2
+        self.active_terms = ["actions"]
+
+    @property
+    def action(self) -> torch.Tensor:
+        return self._env.state[_lib.ACTION:_lib.ACTION + 2].t()
+
+    @property
+    def prev_action(self) -> torch.Tensor:
+        return self._env.state[_lib.PREV_ACTION:_lib.PREV_ACTION + 2].t()
+
+
+class _ObservationManager:
+    def __init__(self, rays: int):
+        self.group_obs_dim = {"policy": (4 + rays,)}                       # train.py:131
+        self.group_obs_term_dim = {"policy": [(2,), (1,), (1,), (rays,)]}  # get_models.py:39
+        self.active_terms = {"policy": list(OBS_ORDER)}
+
+
+class _CommandManager:
+    """``env.command_manager`` facade: ``get_command("target_pose")`` = ``pos_command_b`` (terrain_importer.py:65-68)."""
+
+    def __init__(self, env):
+        self._env = env
+        self.active_terms = ["target_pose"]
+
+    def get_command(self, name: str) -> torch.Tensor:
+        if name != "target_pose":
+            raise KeyError(name)
+        return self._env.state[_lib.CMD_B:_lib.CMD_B + 3].t()
+
+    @property
+    def pos_command_w(self):
+        return self._env.state[_lib.TARGET_W:_lib.TARGET_W + 3].t()
+
+    @property
+    def heading_command_w(self):
+        return self._env.state[_lib.HEADING_CMD_W]
+
+    @property
+    def heading_command_b(self):
+        return self._env.state[_lib.HEADING_CMD_B]
+
+    @property
+    def metrics(self):
+        return {"error_pos": self._env.state[_lib.METRIC_POS], "error_heading": self._env.state[_lib.METRIC_HEAD]}
+
+
+class _SensorData:
+    pass
+
+
+class _ContactSensor:
+    """``scene.sensors["contact_sensor"]``: ``data.force_matrix_w`` (N, 13, 1, 3) view of the SoA force buffer."""
+    body_names = ["FL_Boogie", "FR_Boogie", "R_Boogie", "FL_Steer", "FR_Steer", "RL_Steer", "RR_Steer", "CL_Drive",
+                  "CR_Drive", "FL_Drive", "FR_Drive", "RL_Drive", "RR_Drive"]
+
+    def __init__(self, env):
+        self._env = env
+
+    @property
+    def data(self):
+        env = self._env
+        if env._force is None:
+            raise RuntimeError("contact forces are not recorded (cfg.record_contact_forces=False)")
+        d = _SensorData()
+        n = env.num_envs
+        d.force_matrix_w = env._force.view(_lib.NUM_BODIES, 3, n).permute(2, 0, 1).unsqueeze(2)
+        return d
+
+
+class _RayCaster:
+    """``scene.sensors["height_scanner"]``: ``data.pos_w`` and a lazily rebuilt ``data.ray_hits_w`` (slow path)."""
+
+    def __init__(self, env):
+        self._env = env
+
+    @property
+    def data(self):
+        env = self._env
+        d = _SensorData()
+        pos = env.state[_lib.POS:_lib.POS + 3].t()
+        d.pos_w = pos
+        obs = env.obs_buf["policy"]
+        hit_z = pos[:, 2:3] - obs[:, 4:] - env.cfg.height_scanner.height_offset
+        q = env.state[_lib.QUAT:_lib.QUAT + 4].t()
+        yaw = torch.atan2(2 * (q[:, 0] * q[:, 3] + q[:, 1] * q[:, 2]), 1 - 2 * (q[:, 2] ** 2 + q[:, 3] ** 2))
+        nx, ny = env.cfg.height_scanner.grid
+        hs = env.cfg.height_scanner
+        xs = torch.arange(nx, device=pos.device, dtype=torch.float64) * hs.resolution - 0.5 * hs.size[0]
+        ys = torch.arange(ny, device=pos.device, dtype=torch.float64) * hs.resolution - 0.5 * hs.size[1]
+        gx, gy = torch.meshgrid(xs.float(), ys.float(), indexing="xy")
+        ox, oy = gx.reshape(1, -1), gy.reshape(1, -1)
+        c, s = torch.cos(yaw).unsqueeze(1), torch.sin(yaw).unsqueeze(1)
+        d.ray_hits_w = torch.stack([pos[:, 0:1] + c * ox - s * oy, pos[:, 1:2] + s * ox + c * oy, hit_z], dim=-1)
+        return d
+
+
+class _TerrainFacade:
+    """``scene.terrain``: ``env_origins`` + ``get_spawn_locations()`` (terrain_importer.py:177-185)."""
+
+    def __init__(self, env):
+        self._env = env
+
+    @property
+    def env_origins(self):
+        return self._env.state[_lib.ENV_ORIGIN:_lib.ENV_ORIGIN + 3].t()
+
+    def get_spawn_locations(self):
+        return self._env._spawns_dev
+
+
+class _Scene:
+    def __init__(self, env):
+        self.terrain = _TerrainFacade(env)
+        self.sensors = {"contact_sensor": _ContactSensor(env), "height_scanner": _RayCaster(env)}
+        self.num_envs = env.num_envs
+
+    def __getitem__(self, name):
+        if name in self.sensors:
+            return self.sensors[name]
+        raise KeyError(name)
+
+
+class RLTaskEnv(_GymEnv):
+    """Name the skrl shim checks with ``isinstance(env.unwrapped, RLTaskEnv)`` (skrl_utils.py:38)."""
+    metadata = {"render_modes": [None]}
+
+
+LOG_KEYS = ([f"Episode Reward/{k}" for k in REWARD_ORDER] + [f"Episode Termination/{k}" for k in TERMINATION_ORDER]
+            + ["Metrics/target_pose/error_pos", "Metrics/target_pose/error_heading"])
+
+
+class RoverEnv(RLTaskEnv):
+    """MI355X-native ``AAURoverEnv-v0``.  ``RoverEnv(cfg)`` / ``gym.make("AAURoverEnv-v0", cfg=cfg)``."""
+
+    def __init__(self, cfg: RoverEnvCfg | None = None, terrain: Terrain | None = None, render_mode=None, **kwargs):
+        self.cfg = cfg if cfg is not None else RoverEnvCfg()
+        self.render_mode = render_mode
+        self.cfg.validate()
+        if not torch.cuda.is_available():
+            raise _lib.RoverHipError("RoverEnv needs a ROCm GPU: the hot path is HIP-only (no CPU fallback)")
+        self.device = torch.device(self.cfg.sim.device)
+        if self.device.type != "cuda":
+            raise _lib.RoverHipError(f"cfg.sim.device must be a cuda (ROCm) device, got {self.device}")
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.num_envs = int(self.cfg.scene.num_envs)
+        self._lib = _lib.load()
+        self._native_cfg = self.cfg.to_native()
+        nx, ny = self.cfg.height_scanner.grid
+        self.num_rays = nx * ny
+        self.obs_dim = 4 + self.num_rays
+        self.max_episode_length = self.cfg.max_episode_length
+        self.max_episode_length_s = self.cfg.episode_length_s
+        self.physics_dt = self.cfg.sim.dt
+        self.step_dt = self.cfg.sim.dt * self.cfg.decimation
+        self.common_step_counter = 0
+
+        # ---- shared terrain data (replicated per GPU)
+        tc = self.cfg.terrain
+        if terrain is None:
+            if tc.kind == "custom":
+                terrain = tc.terrain
+            elif tc.kind == "flat":
+                terrain = make_flat_terrain(tc.shape)
+            elif tc.kind == "procedural":
+                terrain = make_procedural_terrain(tc.shape, seed=tc.seed, sigma_z=tc.sigma_z, n_rocks=tc.n_rocks)
+            else:
+                raise ValueError(f"unknown terrain kind {tc.kind}")
+        self.terrain_data = terrain
+        n_global = self.cfg.global_num_envs or self.num_envs
+        if terrain.spawn_locations is None:
+            terrain.make_spawns(2 * n_global, seed=tc.spawn_seed)   # terrain_utils.py:123-124: n_spawns = 2 * num_envs
+        with torch.cuda.device(self.device):
+            dev = self.device
+            self._height_dev = torch.from_numpy(terrain.height).to(dev)
+            self._obstacle_dev = torch.from_numpy(terrain.obstacle).to(dev)
+            self._mask_dev = torch.from_numpy(np.ascontiguousarray(terrain.safe_rock_mask, dtype=np.uint8)).to(dev)
+            self._spawns_dev = torch.from_numpy(np.ascontiguousarray(terrain.spawn_locations, dtype=np.float32)).to(dev)
+
+            # ---- native handle + caller-owned buffers
+            h = C.c_void_p()
+            _lib.check(self._lib.rover_create(C.byref(self._native_cfg), self.num_envs, int(self.cfg.env_id_offset),
+                                              self._dev_index, C.byref(h)), "rover_create")
+            self._h = h
+            H, W = terrain.shape
+            _lib.check(self._lib.rover_set_terrain(h, _ptr(self._height_dev), _ptr(self._obstacle_dev), _ptr(self._mask_dev),
+                                                   H, W, float(terrain.resolution), float(terrain.min_x),
+                                                   float(terrain.min_y), _ptr(self._spawns_dev),
+                                                   int(self._spawns_dev.shape[0])), "rover_set_terrain")
+            n = self.num_envs
+            self.state = torch.zeros(_lib.STATE_WORDS, n, dtype=torch.float32, device=dev)
+            self.state[_lib.QUAT] = 1.0
+            ws = int(self._lib.rover_workspace_bytes(h))
+            self._workspace = torch.zeros(max(ws, 4) // 4, dtype=torch.float32, device=dev)
+            _lib.check(self._lib.rover_bind(h, _ptr(self.state), _ptr(self._workspace), ws), "rover_bind")
+            # two rotating output sets: the tensors returned by step k stay valid during step k + 1 (skrl keeps
+            # `states` while it asks for `next_states`, skrl_utils.py:121-135)
+            self._nbuf = 2
+            self._obs = [torch.zeros(n, self.obs_dim, dtype=torch.float32, device=dev) for _ in range(self._nbuf)]
+            self._rew = [torch.zeros(n, dtype=torch.float32, device=dev) for _ in range(self._nbuf)]
+            self._term = [torch.zeros(n, dtype=torch.uint8, device=dev) for _ in range(self._nbuf)]
+            self._trunc = [torch.zeros(n, dtype=torch.uint8, device=dev) for _ in range(self._nbuf)]
+            self._force = (torch.zeros(_lib.NUM_BODIES * 3, n, dtype=torch.float32, device=dev)
+                           if self.cfg.record_contact_forces else None)
+            self._log = torch.zeros(_lib.LOG_WORDS, dtype=torch.float32, device=dev)
+        self._cur = 0
+        self.episode_length_buf = self.state[_lib.EP_LEN].view(torch.int32)
+        self.obs_buf = {"policy": self._obs[0]}
+        self.reward_buf = self._rew[0]
+        self.reset_terminated = self._term[0].view(torch.bool)
+        self.reset_time_outs = self._trunc[0].view(torch.bool)
+        # extras["log"]: 0-d views into the device log vector, refreshed by the kernels (no host sync)
+        self._log_dict = {k: self._log[i] for i, k in enumerate(LOG_KEYS)}
+        self.extras = {"log": self._log_dict, "episode": self._log_dict}   # rover_env.py:39
+
+        # ---- manager / scene facades + spaces
+        self.action_manager = _ActionManager(self)
+        self.observation_manager = _ObservationManager(self.num_rays)
+        self.command_manager = _CommandManager(self)
+        self.scene = _Scene(self)
+        # ORBIT exposes batched spaces (01_zero_agent.py:44-52 builds zeros(env.action_space.shape))
+        self.single_observation_space = _spaces.Dict({"policy": _spaces.Box(-np.inf, np.inf, (self.obs_dim,), np.float32)})
+        self.single_action_space = _spaces.Box(-np.inf, np.inf, (2,), np.float32)
+        self.observation_space = _spaces.Dict({"policy": _spaces.Box(-np.inf, np.inf, (n, self.obs_dim), np.float32)})
+        self.action_space = _spaces.Box(-np.inf, np.inf, (n, 2), np.float32)
+        self._step_args = None
+        self._closed = False
+
+    # ------------------------------------------------------------------------------------------------------------
+    @property
+    def unwrapped(self):
+        return self
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def seed(self, seed: int = -1) -> int:
+        self.cfg.seed = int(seed)
+        return seed
+
+    def reset(self, seed: int | None = None, options=None):
+        """ORBIT ``RLTaskEnv.reset``: reset every env, return the first observation."""
+        obs = self._obs[self._cur]
+        _lib.check(self._lib.rover_reset(self._h, _ptr(obs), self._stream()), "rover_reset")
+        self.obs_buf = {"policy": obs}
+        return self.obs_buf, self.extras
+
+    def step(self, action: torch.Tensor):
+        """``RoverEnv.step`` (rover_env.py:42-102): two asynchronous kernel launches, no host sync."""
+        if action.dtype != torch.float32 or not action.is_contiguous() or action.device != self.device:
+            action = action.to(device=self.device, dtype=torch.float32).contiguous()
+        if action.shape != (self.num_envs, 2):
+            raise ValueError(f"action must have shape ({self.num_envs}, 2), got {tuple(action.shape)}")
+        self._cur = (self._cur + 1) % self._nbuf
+        k = self._cur
+        rc = self._lib.rover_step(self._h, C.c_void_p(action.data_ptr()), self._obs_ptr[k], self._rew_ptr[k],
+                                  self._term_ptr[k], self._trunc_ptr[k], self._force_ptr, self._log_ptr,
+                                  self._stream())
+        if rc != 0:
+            _lib.check(rc, "rover_step")
+        self.common_step_counter += 1
+        self.obs_buf = self._obs_dicts[k]
+        self.reward_buf = self._rew[k]
+        self.reset_terminated = self._term_b[k]
+        self.reset_time_outs = self._trunc_b[k]
+        return self.obs_buf, self.reward_buf, self.reset_terminated, self.reset_time_outs, self.extras
+
+    def profile_step(self, action: torch.Tensor):
+        """``step`` with HIP-event timing of the two kernels; returns ``(ms_step_kernel, ms_scan_kernel)``.  Syncs."""
+        self._cur = (self._cur + 1) % self._nbuf
+        k = self._cur
+        a, b = C.c_float(0.0), C.c_float(0.0)
+        _lib.check(self._lib.rover_profile_step(self._h, C.c_void_p(action.data_ptr()), self._obs_ptr[k], self._rew_ptr[k],
+                                                self._term_ptr[k], self._trunc_ptr[k], self._force_ptr, self._log_ptr,
+                                                self._stream(), C.byref(a), C.byref(b)), "rover_profile_step")
+        self.obs_buf = self._obs_dicts[k]
+        return a.value, b.value
+
+    def __getattr__(self, name):
+        # lazily built pointer caches (kept out of __init__ so that tensors can be swapped in tests)
+        if name in ("_obs_ptr", "_rew_ptr", "_term_ptr", "_trunc_ptr", "_force_ptr", "_log_ptr", "_obs_dicts", "_term_b",
+                    "_trunc_b"):
+            self._obs_ptr = [_ptr(t) for t in self._obs]
+            self._rew_ptr = [_ptr(t) for t in self._rew]
+            self._term_ptr = [_ptr(t) for t in self._term]
+            self._trunc_ptr = [_ptr(t) for t in self._trunc]
+            self._force_ptr = _ptr(self._force)
+            self._log_ptr = _ptr(self._log)
+            self._obs_dicts = [{"policy": t} for t in self._obs]
+            self._term_b = [t.view(torch.bool) for t in self._term]
+            self._trunc_b = [t.view(torch.bool) for t in self._trunc]
+            return self.__dict__[name]
+        raise AttributeError(name)
+
+    # ---- unit entry points used by the parity tests ------------------------------------------------------------
+    def ackermann(self, raw: torch.Tensor):
+        raw = raw.to(self.device, torch.float32).contiguous()
+        n = raw.shape[0]
+        processed = torch.empty(n, 2, device=self.device)
+        steer = torch.empty(n, 4, device=self.device)
+        wheel = torch.empty(n, 6, device=self.device)
+        _lib.check(self._lib.rover_ackermann(self._h, n, _ptr(raw), _ptr(processed), _ptr(steer), _ptr(wheel),
+                                             self._stream()), "rover_ackermann")
+        return processed, steer, wheel
+
+    def height_scan(self) -> torch.Tensor:
+        scan = torch.empty(self.num_envs, self.num_rays, device=self.device)
+        _lib.check(self._lib.rover_height_scan(self._h, _ptr(scan), self._stream()), "rover_height_scan")
+        return scan
+
+    def physics(self, steer_target: torch.Tensor, wheel_target: torch.Tensor, substeps: int = 1):
+        st = steer_target.to(self.device, torch.float32).contiguous()
+        wt = wheel_target.to(self.device, torch.float32).contiguous()
+        force = torch.zeros(_lib.NUM_BODIES * 3, self.num_envs, device=self.device)
+        _lib.check(self._lib.rover_physics(self._h, _ptr(st), _ptr(wt), int(substeps), _ptr(force), self._stream()),
+                   "rover_physics")
+        return force.view(_lib.NUM_BODIES, 3, self.num_envs).permute(2, 0, 1)
+
+    # ---- state access (env state is never checkpointed in the reference; here it is just a tensor) -------------
+    def get_state(self) -> torch.Tensor:
+        """(num_envs, 72) copy of the per-env state words (AoS, same word order as include/rover_hip.h)."""
+        return self.state.t().contiguous()
+
+    def set_state(self, state_aos: torch.Tensor):
+        self.state.copy_(state_aos.to(self.device, torch.float32).t())
+
+    def render(self):
+        return None
+
+    def close(self):
+        if not self._closed and getattr(self, "_h", None):
+            torch.cuda.synchronize(self.device)
+            self._lib.rover_destroy(self._h)
+            self._h = None
+            self._closed = True
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,337 @@
+"""GPU parity tests: the HIP path (through the C ABI, via RoverEnv) against the CPU oracle and the golden vectors.
+
+Tolerances (fp32, -ffp-contract=off on both sides; the only differing primitives are sinf/cosf/atan2f of the device
+math library vs glibc):
+  * exact-arithmetic layer / single calls ........ atol 2e-6, rtol 2e-6
+  * one env.step() from identical state .......... atol 2e-5, rtol 2e-5
+  * 64-step closed-loop rollouts .................. atol 1e-3, rtol 1e-3   (north_star: <= 1e-3 rel)
+  * flags / counters / indices .................... bit exact (a small number of threshold flips is reported, not hidden)
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close, flat, oracle_config_from, oracle_terrain, small_procedural
+
+pytestmark = pytest.mark.gpu
+
+
+def make_env(n, ter, **over):
+    from isaac_rover_orbit_amd.cfg import RoverEnvCfg
+    from isaac_rover_orbit_amd.envs import RoverEnv
+    cfg = RoverEnvCfg()
+    cfg.scene.num_envs = n
+    cfg.terrain.kind = "custom"
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    if ter.spawn_locations is None or ter.spawn_locations.shape[0] != 2 * (cfg.global_num_envs or n):
+        ter.make_spawns(2 * (cfg.global_num_envs or n))
+    return RoverEnv(cfg, terrain=ter)
+
+
+def oracle_side(ro, env):
+    ocfg = oracle_config_from(ro, env._native_cfg)
+    oter = oracle_terrain(ro, env.terrain_data)
+    return ocfg, oter
+
+
+def state_np(env):
+    return env.get_state().cpu().numpy().astype(np.float32).copy()
+
+
+# ------------------------------------------------------------------------------------------------ exact layer
+def test_ackermann_matches_golden_and_oracle(oracle, golden_dir):
+    g = np.load(f"{golden_dir}/ackermann.npz")
+    env = make_env(64, flat())
+    p, s, w = env.ackermann(torch.from_numpy(g["raw"]))
+    assert_close(p.cpu().numpy(), g["processed"], 0, 0, "processed (bit exact)")
+    assert_close(s.cpu().numpy(), g["steer"], 2e-6, 2e-6, "steer")
+    assert_close(w.cpu().numpy(), g["wheel"], 0, 0, "wheel (bit exact)")
+    po, so, wo = oracle.ackermann(oracle.default_config(), g["raw"])
+    assert_close(s.cpu().numpy(), so, 2e-6, 2e-6, "steer vs oracle")
+    env.close()
+
+
+def test_height_scan_matches_oracle(oracle):
+    ter = small_procedural()
+    env = make_env(256, ter)
+    env.reset()
+    ocfg, oter = oracle_side(oracle, env)
+    S = state_np(env)
+    scan = env.height_scan().cpu().numpy()
+    ref = oracle.height_scan(ocfg, oter, S)
+    assert_close(scan, ref, 2e-6, 2e-6, "height scan")
+    # observation row = [0, 0, d*0.11, angle/pi, scan]
+    obs = env.obs_buf["policy"].cpu().numpy()
+    assert_close(obs[:, 4:], ref, 2e-6, 2e-6, "obs scan part")
+    env.close()
+
+
+def test_height_scan_misses_are_minus_inf(oracle):
+    """Rays that leave the map report +inf hits -> obs = -inf (ORBIT RayCaster semantics)."""
+    ter = flat()
+    env = make_env(4, ter)
+    env.reset()
+    S = state_np(env)
+    S[:, 0:3] = [[0.5, 0.5, 0.3], [51.0, 25.0, 0.3], [25.0, 0.2, 0.3], [25.0, 25.0, 0.3]]
+    env.set_state(torch.from_numpy(S))
+    ocfg, oter = oracle_side(oracle, env)
+    scan = env.height_scan().cpu().numpy()
+    ref = oracle.height_scan(ocfg, oter, S)
+    assert np.isinf(ref[:3]).any() and not np.isinf(ref[3]).any()
+    assert_close(scan, ref, 2e-6, 2e-6, "scan with misses")
+    env.close()
+
+
+def test_reset_matches_oracle(oracle):
+    ter = small_procedural()
+    env = make_env(512, ter, seed=1234567890123)
+    obs, info = env.reset()
+    ocfg, oter = oracle_side(oracle, env)
+    So = oracle.new_state(512)
+    obs_o = oracle.reset_all(ocfg, oter, So)
+    S = state_np(env)
+    # integer words bit exact
+    for w in (oracle.EP_LEN, oracle.RESET_COUNT):
+        assert (S[:, w].view(np.int32) == So[:, w].view(np.int32)).all()
+    assert_close(S[:, oracle.POS:oracle.POS + 3], So[:, oracle.POS:oracle.POS + 3], 0, 0, "spawn positions (bit exact)")
+    fl = [i for i in range(72) if i not in (oracle.EP_LEN, oracle.RESET_COUNT)]
+    assert_close(S[:, fl], So[:, fl], 5e-6, 5e-6, "state after reset")
+    assert_close(obs["policy"].cpu().numpy(), obs_o, 5e-6, 5e-6, "obs after reset")
+    assert set(info["episode"].keys()) == set(info["log"].keys()) and len(info["log"]) == 13
+    env.close()
+
+
+# ------------------------------------------------------------------------------------------------ physics
+def test_physics_substeps_match_oracle(oracle):
+    ter = small_procedural()
+    n = 256
+    env = make_env(n, ter)
+    env.reset()
+    ocfg, oter = oracle_side(oracle, env)
+    rng = np.random.RandomState(5)
+    steer = rng.uniform(-0.9, 0.9, (n, 4)).astype(np.float32)
+    wheel = rng.uniform(-8, 8, (n, 6)).astype(np.float32)
+    So = state_np(env)
+    # 1 substep from identical state, then 12 more (drop + touch-down + driving)
+    for sub, tol in ((1, 2e-5), (12, 2e-4)):
+        f = env.physics(torch.from_numpy(steer), torch.from_numpy(wheel), sub).cpu().numpy()
+        fo = oracle.physics_step(ocfg, oter, So, steer, wheel, sub)
+        S = state_np(env)
+        assert_close(S[:, :39], So[:, :39], tol, tol, f"state after {sub} substeps")
+        assert_close(S[:, oracle.LAMBDA_N:oracle.LAMBDA_N + 6], So[:, oracle.LAMBDA_N:oracle.LAMBDA_N + 6], 50 * tol, 50 * tol,
+                     "cached normal impulses")
+        assert_close(f, fo, 0.05, 1e-2, "obstacle contact forces")
+        env.set_state(torch.from_numpy(So))   # re-synchronise before the next segment
+    env.close()
+
+
+# ------------------------------------------------------------------------------------------------ full step
+def rollout_compare(oracle, env, steps, actions, tol_step, tol_final, resync):
+    ocfg, oter = oracle_side(oracle, env)
+    n = env.num_envs
+    env.reset()
+    So = state_np(env)
+    flips = 0
+    log_o = np.zeros(16, np.float32)
+    for k in range(steps):
+        a = actions[k]
+        obs, rew, term, trunc, info = env.step(torch.from_numpy(a).to(env.device))
+        obs_o, rew_o, term_o, trunc_o, force_o, log_o = oracle.step(ocfg, oter, So, a, log=log_o)
+        obs, rew = obs["policy"].cpu().numpy(), rew.cpu().numpy()
+        term, trunc = term.cpu().numpy().astype(np.uint8), trunc.cpu().numpy().astype(np.uint8)
+        bad = (term != term_o) | (trunc != trunc_o)
+        flips += int(bad.sum())
+        ok = ~bad
+        tol = tol_step if resync else tol_final
+        assert_close(obs[ok], obs_o[ok], tol, tol, f"obs step {k}")
+        assert_close(rew[ok], rew_o[ok], tol, tol, f"reward step {k}")
+        if not bad.any():
+            log = env._log.cpu().numpy()
+            assert log[13] == log_o[13], f"reset count step {k}"
+            assert_close(log[:13], log_o[:13], 1e-4, 1e-4, f"extras['log'] step {k}")
+        S = state_np(env)
+        assert (S[ok][:, oracle.EP_LEN].view(np.int32) == So[ok][:, oracle.EP_LEN].view(np.int32)).all()
+        if resync:
+            So = S.copy()
+    return flips
+
+
+def test_step_config1_flat_single_env(oracle):
+    """BASELINE config 1: N=1, flat terrain, 64-step random-action rollout, actions from manual_seed(0)."""
+    ter = flat(2048)
+    ter.spawn_locations = np.array([[51.2, 51.2, 0.0]], dtype=np.float32)
+    from isaac_rover_orbit_amd.cfg import RoverEnvCfg
+    from isaac_rover_orbit_amd.envs import RoverEnv
+    cfg = RoverEnvCfg()
+    cfg.scene.num_envs = 1
+    cfg.terrain.kind = "custom"
+    env = RoverEnv(cfg, terrain=ter)
+    g = torch.Generator().manual_seed(0)
+    actions = (torch.rand(64, 1, 2, generator=g) * 2 - 1).numpy().astype(np.float32)
+    flips = rollout_compare(oracle, env, 64, actions, 2e-5, 1e-3, resync=False)
+    assert flips == 0
+    S = state_np(env)
+    assert np.isfinite(S).all()
+    env.close()
+
+
+@pytest.mark.parametrize("n", [64, 1000, 4096])
+def test_step_procedural_single_steps(oracle, n):
+    """Every step compared from an identical (re-synchronised) state, resets and log included; ragged n too."""
+    ter = small_procedural()
+    env = make_env(n, ter, seed=99)
+    rng = np.random.RandomState(n)
+    steps = 12
+    actions = rng.uniform(-1, 1, (steps, n, 2)).astype(np.float32)
+    flips = rollout_compare(oracle, env, steps, actions, 5e-5, 1e-3, resync=True)
+    assert flips <= max(1, n // 2000), f"{flips} termination flag flips"
+    env.close()
+
+
+def test_step_procedural_closed_loop_64(oracle):
+    """64-step closed-loop rollout (no re-synchronisation): obs / reward within 1e-3 (north_star tolerance)."""
+    ter = small_procedural()
+    n = 512
+    env = make_env(n, ter, seed=3)
+    rng = np.random.RandomState(11)
+    actions = rng.uniform(-1, 1, (64, n, 2)).astype(np.float32)
+    actions[:, :, 0] = np.abs(actions[:, :, 0])
+    flips = rollout_compare(oracle, env, 64, actions, 5e-5, 1e-3, resync=False)
+    assert flips <= 2, f"{flips} termination flag flips"
+    env.close()
+
+
+def test_sharding_invariance_gpu(oracle):
+    """Two shards with env_id_offset reproduce the corresponding rows of one big env (RNG keyed by global id)."""
+    ter = small_procedural()
+    ter.make_spawns(2 * 256)
+    big = make_env(256, ter, seed=5, global_num_envs=256)
+    lo = make_env(128, ter, seed=5, global_num_envs=256, env_id_offset=0)
+    hi = make_env(128, ter, seed=5, global_num_envs=256, env_id_offset=128)
+    for e in (big, lo, hi):
+        e.reset()
+    rng = np.random.RandomState(2)
+    for k in range(8):
+        a = torch.from_numpy(rng.uniform(-1, 1, (256, 2)).astype(np.float32)).cuda()
+        ob, rb, tb, ub, _ = big.step(a)
+        ol, rl, tl, ul, _ = lo.step(a[:128].contiguous())
+        oh, rh, th, uh, _ = hi.step(a[128:].contiguous())
+        assert torch.equal(ob["policy"][:128], ol["policy"]) and torch.equal(ob["policy"][128:], oh["policy"])
+        assert torch.equal(rb[:128], rl) and torch.equal(rb[128:], rh)
+        assert torch.equal(tb[:128], tl) and torch.equal(tb[128:], th)
+    for e in (big, lo, hi):
+        e.close()
+
+
+def test_determinism_and_buffers(oracle):
+    ter = small_procedural()
+    outs = []
+    for _ in range(2):
+        env = make_env(300, ter, seed=8)
+        env.reset()
+        rng = np.random.RandomState(0)
+        prev = None
+        for k in range(6):
+            o, r, t, u, info = env.step(torch.from_numpy(rng.uniform(-1, 1, (300, 2)).astype(np.float32)).cuda())
+            if prev is not None:
+                # the tensors returned by the previous step are still intact (double buffering)
+                assert prev[0].data_ptr() != o["policy"].data_ptr()
+                assert torch.equal(prev[0], prev[1])
+            prev = (o["policy"], o["policy"].clone())
+        outs.append((o["policy"].clone(), r.clone(), env.get_state()))
+        env.close()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
+def test_boundary_surface():
+    """Attribute surface the reference's consumers touch."""
+    ter = small_procedural()
+    env = make_env(128, ter)
+    obs, info = env.reset()
+    assert env.unwrapped is env and env.num_envs == 128
+    assert env.observation_manager.group_obs_dim["policy"] == (965,)
+    assert env.observation_manager.group_obs_term_dim["policy"] == [(2,), (1,), (1,), (961,)]
+    assert env.action_manager.action_term_dim == [2]
+    assert env.action_space.shape == (128, 2) and env.observation_space["policy"].shape == (128, 965)
+    a = torch.zeros(env.action_space.shape, device=env.unwrapped.device)
+    obs, rew, term, trunc, info = env.step(a)
+    assert obs["policy"].shape == (128, 965) and rew.shape == (128,) and term.dtype == torch.bool and trunc.dtype == torch.bool
+    assert env.command_manager.get_command("target_pose").shape == (128, 3)
+    assert env.action_manager.action.shape == (128, 2) and env.action_manager.prev_action.shape == (128, 2)
+    f = env.scene.sensors["contact_sensor"].data.force_matrix_w
+    assert f.shape == (128, 13, 1, 3) and f.view(128, -1, 3).shape == (128, 13, 3)
+    d = env.scene.sensors["height_scanner"].data
+    assert d.pos_w.shape == (128, 3) and d.ray_hits_w.shape == (128, 961, 3)
+    assert env.scene.terrain.env_origins.shape == (128, 3)
+    assert env.scene.terrain.get_spawn_locations().shape == (256, 3)
+    assert env.episode_length_buf.dtype == torch.int32 and int(env.max_episode_length) == 750
+    assert "episode" in info and info["episode"] is info["log"]
+    assert all(v.dim() == 0 for v in info["episode"].values())
+    with pytest.raises(ValueError):
+        env.step(torch.zeros(5, 2, device=env.device))
+    env.close()
+
+
+def test_timeout_truncation_and_success(oracle):
+    """Force the time-out and the success branches (rare in random rollouts) and compare with the oracle."""
+    ter = small_procedural()
+    n = 64
+    env = make_env(n, ter, seed=21)
+    env.reset()
+    ocfg, oter = oracle_side(oracle, env)
+    S = state_np(env)
+    Si = S.view(np.int32)
+    Si[:16, oracle.EP_LEN] = 749                    # -> time_out on the next step
+    S[16:32, oracle.CMD_B:oracle.CMD_B + 2] = 0.05  # stale command inside the success radius
+    S[32:40, oracle.CMD_B] = 11.5                   # far from target
+    env.set_state(torch.from_numpy(S))
+    a = np.zeros((n, 2), np.float32)
+    obs, rew, term, trunc, info = env.step(torch.from_numpy(a).cuda())
+    obs_o, rew_o, term_o, trunc_o, force_o, log_o = oracle.step(ocfg, oter, S, a)
+    assert trunc.cpu().numpy()[:16].all() and term.cpu().numpy()[16:40].all()
+    assert (term.cpu().numpy().astype(np.uint8) == term_o).all() and (trunc.cpu().numpy().astype(np.uint8) == trunc_o).all()
+    assert_close(rew.cpu().numpy(), rew_o, 1e-5, 1e-5, "reward with forced branches")
+    assert_close(obs["policy"].cpu().numpy(), obs_o, 5e-5, 5e-5, "obs with forced branches")
+    log = env._log.cpu().numpy()
+    assert log[13] == log_o[13] and log[13] >= 40
+    assert_close(log[:13], log_o[:13], 1e-4, 1e-4, "extras['log']")
+    # reset envs observe a zeroed last action and a fresh episode counter
+    assert (obs["policy"].cpu().numpy()[:40, :2] == 0).all()
+    assert (env.episode_length_buf.cpu().numpy()[:40] == 0).all()
+    env.close()
+
+
+def test_full_size_properties():
+    """BASELINE config 2 size (N=4096, 2048^2 terrain): size-independent invariants over a 40-step rollout."""
+    from isaac_rover_orbit_amd.cfg import RoverEnvCfg
+    from isaac_rover_orbit_amd.envs import RoverEnv
+    cfg = RoverEnvCfg()
+    cfg.scene.num_envs = 4096
+    env = RoverEnv(cfg)
+    obs, _ = env.reset()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    total_resets = 0
+    for k in range(40):
+        a = torch.rand(4096, 2, device="cuda", generator=g) * 2 - 1
+        obs, rew, term, trunc, info = env.step(a)
+        o = obs["policy"]
+        assert torch.isfinite(o).all() and torch.isfinite(rew).all()
+        st = env.state
+        qn = (st[3:7] ** 2).sum(0)
+        assert torch.allclose(qn, torch.ones_like(qn), atol=1e-4)                  # unit quaternions
+        assert (st[13:16].abs() <= 0.1745330).all()                                 # bogies inside +-10 deg
+        assert (st[33:39].abs() <= 6.0 + 1e-5).all() and (st[29:33].abs() <= 6.0 + 1e-5).all()   # joint rate limits
+        assert ((st[7:10] ** 2).sum(0).sqrt() <= 1.5 + 1e-4).all()                  # max linear velocity
+        done = term | trunc
+        assert (o[done][:, :2] == 0).all()                                          # reset envs: last_action zeroed
+        assert (o[~done][:, :2] == a[~done]).all()
+        assert (env.episode_length_buf[done] == 0).all()
+        assert int(info["log"]["Episode Termination/time_limit"].item()) >= 0
+        # distance observation is consistent with the command in the state
+        d = (st[52] ** 2 + st[53] ** 2).sqrt() * 0.11
+        assert torch.allclose(o[:, 2], d, atol=1e-5)
+        total_resets += int(done.sum())
+        assert float(env._log[13]) == float(done.sum())
+    assert total_resets > 0
+    env.close()
