@@ -50,6 +50,18 @@ class RoverConfig(C.Structure):
 _lib = None
 
 
+def _hip_runtimes() -> set:
+    out = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    out.add(line.split()[-1])
+    except OSError:
+        pass
+    return out
+
+
 def load():
     """Load ``librover_hip.so`` (built in-tree by ``__graft_entry__.build()`` / ``isaac_rover_orbit_amd.build``)."""
     global _lib
@@ -59,7 +71,14 @@ def load():
         raise RoverHipError(
             f"{LIB_PATH} not found: build it with `python -m isaac_rover_orbit_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the rover hot path.")
+    # torch-ROCm bundles its own libamdhip64.so.7; device pointers and streams are only meaningful inside ONE HIP runtime,
+    # so torch must be loaded first: the dynamic linker then binds librover_hip.so to the runtime torch already mapped.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
+    runtimes = _hip_runtimes()
+    if len(runtimes) > 1:
+        raise RoverHipError(f"two HIP runtimes are mapped into this process ({sorted(runtimes)}): import torch before "
+                            "loading librover_hip.so")
     vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
     lib.rover_default_config.argtypes = [C.POINTER(RoverConfig)]
     lib.rover_create.argtypes = [C.POINTER(RoverConfig), i32, i32, i32, C.POINTER(vp)]

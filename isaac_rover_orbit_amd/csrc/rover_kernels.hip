@@ -81,6 +81,45 @@ __device__ __forceinline__ void mat_tvec(const float R[3][3], const float *v, fl
 }
 __device__ __forceinline__ float wdot3(const float *a, const float *w) { return a[0] * a[0] * w[0] + a[1] * a[1] * w[1] + a[2] * a[2] * w[2]; }
 
+
+/* ---- portable fp32 trigonometry ------------------------------------------------------------------------
+ * sin/cos/atan2 are evaluated by the SAME explicit fp32 operation sequence here and in the HIP kernels (Cody-Waite
+ * reduction + Cephes single-precision minimax polynomials, ~1 ulp), so that the CPU oracle and the GPU agree bit for
+ * bit instead of differing by the libm-vs-device-library rounding of sinf/cosf/atan2f.                       */
+__device__ __forceinline__ void rv_sincosf(float x, float *s, float *c)
+{
+    const float k = floorf(x * 0.63661977236758134f + 0.5f); /* nearest multiple of pi/2 */
+    float r = x - k * 1.5703125f;
+    r = r - k * 4.837512969970703125e-4f;
+    r = r - k * 7.54978995489188e-8f;
+    const int q = ((int)k) & 3;
+    const float z = r * r;
+    const float sp = r + r * z * (-1.6666654611e-1f + z * (8.3321608736e-3f + z * (-1.9515295891e-4f)));
+    const float cp = 1.0f - 0.5f * z + z * z * (4.166664568298827e-2f + z * (-1.388731625493765e-3f + z * 2.443315711809948e-5f));
+    const float ss = (q & 1) ? cp : sp;
+    const float cc = (q & 1) ? sp : cp;
+    *s = (q & 2) ? -ss : ss;
+    *c = ((q + 1) & 2) ? -cc : cc;
+}
+__device__ __forceinline__ float rv_sinf(float x) { float s, c; rv_sincosf(x, &s, &c); return s; }
+__device__ __forceinline__ float rv_cosf(float x) { float s, c; rv_sincosf(x, &s, &c); return c; }
+__device__ __forceinline__ float rv_atan2f(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a;
+    if (ax == 0.0f) {
+        a = (ay == 0.0f) ? 0.0f : 1.5707963267948966f;
+    } else {
+        float t = ay / ax, y0 = 0.0f;
+        if (t > 2.414213562373095f) { y0 = 1.5707963267948966f; t = -(1.0f / t); }
+        else if (t > 0.4142135623730950f) { y0 = 0.7853981633974483f; t = (t - 1.0f) / (t + 1.0f); }
+        const float z = t * t;
+        a = y0 + ((((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * t + t);
+    }
+    if (x < 0.0f) a = RV_PI_F - a;
+    return (y < 0.0f) ? -a : a;
+}
+
 // Philox4x32-10, counter = (global env id, reset count, draw block, stream), key = seed
 __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                                            uint32_t out[4])
@@ -128,7 +167,7 @@ __device__ __forceinline__ void ackermann_one(const rover_config &c, const float
     const float v_RR = point ? pt : (az ? lin : (r_RR * ang)) * direction;
     const float v_ML = point ? -pt : (az ? lin : (r_ML * ang)) * direction;
     const float v_MR = point ? pt : (az ? lin : (r_MR * ang)) * direction;
-    const float th = atan2f(wl, r_FL) * turn;
+    const float th = rv_atan2f(wl, r_FL) * turn;
     const float q = RV_PI_F / 4.0f;
     wheel[0] = v_ML / c.wheel_radius; wheel[1] = v_FL / c.wheel_radius; wheel[2] = v_RL / c.wheel_radius;
     wheel[3] = v_RR / c.wheel_radius; wheel[4] = v_MR / c.wheel_radius; wheel[5] = v_FR / c.wheel_radius;
@@ -198,15 +237,15 @@ __device__ __forceinline__ float heading_of(const float *q)
     const float w = q[0], x = q[1], y = q[2], z = q[3];
     const float fx = 1.0f - 2.0f * (y * y + z * z);
     const float fy = 2.0f * (w * z + x * y);
-    return atan2f(fy, fx);
+    return rv_atan2f(fy, fx);
 }
 // TerrainBasedPositionCommand._update_command, terrain_importer.py:97-101 (ORBIT yaw_quat + quat_rotate_inverse)
 __device__ __forceinline__ void update_command_one(const float *pos, const float *quat, const float *target_w,
                                                    float heading_cmd_w, float *cmd_b, float *heading_b)
 {
     const float qw = quat[0], qx = quat[1], qy = quat[2], qz = quat[3];
-    const float yaw = atan2f(2.0f * (qw * qz + qx * qy), 1.0f - 2.0f * (qy * qy + qz * qz));
-    float yw = cosf(yaw / 2.0f), yz = sinf(yaw / 2.0f);
+    const float yaw = rv_atan2f(2.0f * (qw * qz + qx * qy), 1.0f - 2.0f * (qy * qy + qz * qz));
+    float yw = rv_cosf(yaw / 2.0f), yz = rv_sinf(yaw / 2.0f);
     const float nrm = sqrtf(yw * yw + yz * yz);
     yw = yw / nrm;
     yz = yz / nrm;
@@ -242,7 +281,7 @@ __device__ __forceinline__ void mdp_terms_one(const rover_config &c, const float
 {
     const float L = (float)c.max_episode_length;
     const float d = sqrtf(cmd_b[0] * cmd_b[0] + cmd_b[1] * cmd_b[1]);
-    const float angle = atan2f(cmd_b[1], cmd_b[0]);
+    const float angle = rv_atan2f(cmd_b[1], cmd_b[0]);
     rew[0] = (1.0f / (1.0f + (0.11f * d * d))) / L;
     rew[1] = (d < c.success_threshold) ? (float)(c.max_episode_length - ep_len) / L : 0.0f;
     {
@@ -342,7 +381,7 @@ __device__ __forceinline__ void physics_substep(const RvParams &p, float *S, con
         const float P[3] = {BOGIE_PIVOT[j][0], BOGIE_PIVOT[j][1], BOGIE_PIVOT[j][2]};
         const float ax[3] = {BOGIE_AXIS[j][0], BOGIE_AXIS[j][1], BOGIE_AXIS[j][2]};
         const float d0[3] = {WHEEL_B[k][0] - P[0], WHEEL_B[k][1] - P[1], WHEEL_B[k][2] - P[2]};
-        const float cb = cosf(bq[j]), sb = sinf(bq[j]);
+        const float cb = rv_cosf(bq[j]), sb = rv_sinf(bq[j]);
         float axd[3];
         cross3(ax, d0, axd);
         const float ad = dot3(ax, d0);
@@ -367,7 +406,7 @@ __device__ __forceinline__ void physics_substep(const RvParams &p, float *S, con
         for (int i = 0; i < 3; ++i) cp[i] = cen_w[i] - RV_WHEEL_CONTACT_RADIUS * ct.n[i];
         const int si = WHEEL_STEER[k];
         float fwd_b[3] = {1.0f, 0.0f, 0.0f}, fwd[3];
-        if (si >= 0) { fwd_b[0] = cosf(S[ROVER_STEER_Q + (si >= 0 ? si : 0)]); fwd_b[1] = sinf(S[ROVER_STEER_Q + (si >= 0 ? si : 0)]); }
+        if (si >= 0) { fwd_b[0] = rv_cosf(S[ROVER_STEER_Q + (si >= 0 ? si : 0)]); fwd_b[1] = rv_sinf(S[ROVER_STEER_Q + (si >= 0 ? si : 0)]); }
         mat_vec(R, fwd_b, fwd);
         const float fn = dot3(fwd, ct.n);
         float tl = 0.0f;
@@ -530,8 +569,8 @@ __device__ __forceinline__ void resample_command(const RvParams &p, float *S, ui
         for (int i = 0; i < 4; ++i) {
             if (!done) {
                 const float theta = u01(r[i]) * 2.0f * RV_PI_F;
-                tx = cosf(theta) * c.target_distance + S[ROVER_ENV_ORIGIN + 0];
-                ty = sinf(theta) * c.target_distance + S[ROVER_ENV_ORIGIN + 1];
+                tx = rv_cosf(theta) * c.target_distance + S[ROVER_ENV_ORIGIN + 0];
+                ty = rv_sinf(theta) * c.target_distance + S[ROVER_ENV_ORIGIN + 1];
                 int cx, cy;
                 quirk_cell(p, tx, ty, cx, cy);
                 ++tries;
@@ -560,8 +599,8 @@ __device__ __forceinline__ void reset_one(const RvParams &p, float *S, uint32_t 
     const float pz = p.spawns[3 * row + 2] + c.reset_z_offset;
     const float angle = u01(r[1]) * 2.0f * RV_PI_F;
     S[ROVER_POS + 0] = px; S[ROVER_POS + 1] = py; S[ROVER_POS + 2] = pz;
-    S[ROVER_QUAT + 0] = cosf(angle / 2.0f); S[ROVER_QUAT + 1] = 0.0f; S[ROVER_QUAT + 2] = 0.0f;
-    S[ROVER_QUAT + 3] = sinf(angle / 2.0f);
+    S[ROVER_QUAT + 0] = rv_cosf(angle / 2.0f); S[ROVER_QUAT + 1] = 0.0f; S[ROVER_QUAT + 2] = 0.0f;
+    S[ROVER_QUAT + 3] = rv_sinf(angle / 2.0f);
     S[ROVER_ENV_ORIGIN + 0] = px; S[ROVER_ENV_ORIGIN + 1] = py; S[ROVER_ENV_ORIGIN + 2] = pz;
     if (c.reset_mode == 1) {
 #pragma unroll
@@ -860,7 +899,7 @@ __global__ __launch_bounds__(256) void rover_scan_obs_kernel(RvParams p, const f
         o[0] = state[(size_t)(ROVER_ACTION + 0) * N + e];
         o[1] = state[(size_t)(ROVER_ACTION + 1) * N + e];
         o[2] = sqrtf(cbx * cbx + cby * cby) * c.obs_scale_distance;
-        o[3] = atan2f(cby, cbx) * c.obs_scale_heading;
+        o[3] = rv_atan2f(cby, cbx) * c.obs_scale_heading;
     }
 }
 
