@@ -146,6 +146,7 @@ int rover_physics(rover_sim *sim, const float *steer_target, const float *wheel_
 /* Model constant table (same order as the oracle's rvo_model_constants); returns the count. Host only. */
 int rover_model_constants(float *out, int32_t cap);
 int rover_state_words(void);
+size_t rover_config_bytes(void); /* sizeof(rover_config): lets a binding verify its struct mirror */
 const char *rover_last_error(void);
 const char *rover_version(void);
 

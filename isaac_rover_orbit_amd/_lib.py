@@ -21,7 +21,7 @@ CMD_B, HEADING_CMD_B, EP_SUM, METRIC_POS, METRIC_HEAD, LAMBDA_N, RESET_COUNT = 5
 EXPORTS = [
     "rover_default_config", "rover_create", "rover_destroy", "rover_set_terrain", "rover_workspace_bytes", "rover_bind",
     "rover_reset", "rover_step", "rover_profile_step", "rover_ackermann", "rover_height_scan", "rover_physics", "rover_model_constants",
-    "rover_state_words", "rover_last_error", "rover_version",
+    "rover_state_words", "rover_config_bytes", "rover_last_error", "rover_version",
 ]
 
 
@@ -100,6 +100,9 @@ def load():
         fn = getattr(lib, name)
         if fn.restype is C.c_int:
             fn.restype = C.c_int
+    lib.rover_config_bytes.restype = C.c_size_t
+    if lib.rover_config_bytes() != C.sizeof(RoverConfig):
+        raise RoverHipError("struct rover_config of librover_hip.so does not match the Python mirror")
     if lib.rover_state_words() != STATE_WORDS:
         raise RoverHipError("librover_hip.so state layout does not match the Python binding")
     _lib = lib

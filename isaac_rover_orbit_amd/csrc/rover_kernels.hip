@@ -1156,7 +1156,7 @@ int rover_model_constants(float *out, int32_t cap)
 {
     const float com[3] = RV_COM_B_INIT, inertia[3] = RV_INERTIA_B_INIT, wheel[6][3] = RV_WHEEL_B_INIT;
     const float pivot[3][3] = RV_BOGIE_PIVOT_INIT, axis[3][3] = RV_BOGIE_AXIS_INIT, binertia[3] = RV_BOGIE_INERTIA_INIT;
-    float t[64];
+    float t[96];
     int n = 0;
     t[n++] = RV_M_TOTAL;
     for (int i = 0; i < 3; ++i) t[n++] = com[i];
@@ -1175,6 +1175,7 @@ int rover_model_constants(float *out, int32_t cap)
 }
 
 int rover_state_words(void) { return ROVER_STATE_WORDS; }
+size_t rover_config_bytes(void) { return sizeof(rover_config); }
 const char *rover_last_error(void) { return g_err; }
 const char *rover_version(void) { return "isaac_rover_orbit_amd 0.1.0 (gfx950)"; }
 

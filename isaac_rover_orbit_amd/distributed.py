@@ -74,10 +74,10 @@ class RolloutGatherer:
         if self._stream is not None:
             self._stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._stream):
-                dist.all_gather_into_tensor(out, shard.contiguous(), group=self.group)
+                dist.all_gather_into_tensor(out.view(-1), shard.contiguous().view(-1), group=self.group)
             self._pending = out
         else:
-            dist.all_gather_into_tensor(out, shard.contiguous(), group=self.group)
+            dist.all_gather_into_tensor(out.view(-1), shard.contiguous().view(-1), group=self.group)
         return out
 
     def wait(self):

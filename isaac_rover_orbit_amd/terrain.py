@@ -145,11 +145,11 @@ def fbm_heightfield(shape=(2048, 2048), seed=1234, sigma_z=0.15, base_cell=256, 
     return out.astype(np.float32)
 
 
-def gaussian_rocks(shape, n_rocks=400, seed=1234, h_range=(0.2, 0.6), aspect_range=(1.0, 1.6), resolution=RESOLUTION,
+def gaussian_rocks(shape, n_rocks=400, seed=1234, h_range=(0.25, 0.6), aspect_range=(1.0, 1.4), resolution=RESOLUTION,
                    border_m=5.0):
     """Obstacle layer: compactly supported Gaussian bumps of height h and footprint radius r = h * aspect
-    (0.2 .. 0.96 m), sigma = r / 2.  The aspect range keeps every rock steeper than the reference's rock detector
-    threshold (Sobel magnitude 0.3 <=> slope 0.75, terrain_utils.py:109,283), so the obstacle layer and the rock mask
+    (0.25 .. 0.84 m), sigma = r / 2.  The ranges keep every rock steeper than the reference's rock detector threshold
+    (Sobel magnitude 0.3 <=> slope 0.75, terrain_utils.py:109,283) and wider than its 7x7 opening, so the obstacle layer and the rock mask
     describe the same set of stones, as the reference's rocks_merged.usd / gradient mask pair does."""
     rng = np.random.RandomState(seed + 1)
     H, W = shape
@@ -226,8 +226,8 @@ def make_flat_terrain(shape=(2048, 2048), z=0.0) -> Terrain:
     return Terrain(ground=g, obstacle=np.zeros(shape, np.float32), rock_mask=zero, safe_rock_mask=zero.copy())
 
 
-def make_procedural_terrain(shape=(2048, 2048), seed=1234, sigma_z=0.15, n_rocks=400, h_range=(0.2, 0.6),
-                            aspect_range=(1.0, 1.6)) -> Terrain:
+def make_procedural_terrain(shape=(2048, 2048), seed=1234, sigma_z=0.15, n_rocks=400, h_range=(0.25, 0.6),
+                            aspect_range=(1.0, 1.4)) -> Terrain:
     """SURVEY 8d config 2 (and config 4 with sigma_z = 0.4): fBm ground + Gaussian rocks."""
     scale = min(shape) / 2048.0
     ground = fbm_heightfield(shape, seed=seed, sigma_z=sigma_z, base_cell=max(int(256 * scale), 8))

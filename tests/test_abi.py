@@ -1,0 +1,95 @@
+"""The C-ABI library loads on a CPU-only host and exports every symbol include/rover_hip.h declares; model constants
+agree between the HIP library, the oracle and the fixture derived from the reference asset.  No compute calls."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "rover_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rover_[a-z_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from isaac_rover_orbit_amd import _lib, build
+    build.build_extension()
+    lib = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/rover_hip.h but not exported"
+    assert sorted(_lib.EXPORTS) == names, "python binding and header disagree on the entry points"
+    assert lib.rover_config_bytes() == C.sizeof(_lib.RoverConfig)
+    assert lib.rover_state_words() == 72
+    assert b"gfx950" in lib.rover_version()
+
+
+def test_code_object_is_gfx950():
+    from isaac_rover_orbit_amd import _lib
+    data = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in data and b"rover_step_kernel" in data and b"rover_scan_obs_kernel" in data
+
+
+def test_default_config_matches_reference_cfg_and_oracle(oracle):
+    from isaac_rover_orbit_amd import _lib
+    c, o = _lib.default_config(), oracle.default_config()
+    for name, _ in _lib.RoverConfig._fields_:
+        a, b = getattr(c, name), getattr(o, name)
+        if name == "rew_weight":
+            assert list(a) == list(b) == pytest.approx([5.0, 5.0, -0.1, -1.5, -0.5, -2.0, -2.0])
+        else:
+            assert a == b, name
+    assert c.decimation == 6 and c.max_episode_length == 750 and c.scan_nx == 31 and c.scan_ny == 31
+    assert c.offset_lin == c.offset_ang == pytest.approx(-0.0135)
+
+
+def test_errors_are_codes_not_crashes():
+    """Error behaviour of the boundary: int codes + rover_last_error(), also on a host without a GPU."""
+    from isaac_rover_orbit_amd import _lib
+    lib = _lib.load()
+    assert lib.rover_default_config(None) == 1
+    assert b"NULL" in lib.rover_last_error()
+    cfg = _lib.default_config()
+    h = C.c_void_p()
+    assert lib.rover_create(C.byref(cfg), 0, 0, 0, C.byref(h)) == 1           # num_envs must be > 0
+    bad = _lib.default_config()
+    bad.scan_nx = 0
+    assert lib.rover_create(C.byref(bad), 16, 0, 0, C.byref(h)) == 1
+    assert lib.rover_step(None, None, None, None, None, None, None, None, None) == 1
+    assert lib.rover_workspace_bytes(None) == 0
+    import torch
+    if not torch.cuda.is_available():
+        rc = lib.rover_create(C.byref(cfg), 16, 0, 0, C.byref(h))
+        assert rc == 3 and len(lib.rover_last_error()) > 0                    # ROVER_ERR_HIP, no device
+        with pytest.raises(_lib.RoverHipError):
+            from isaac_rover_orbit_amd.envs import RoverEnv
+            RoverEnv()                                                         # product path fails loudly, no CPU fallback
+
+
+def test_model_constants_agree(oracle):
+    from isaac_rover_orbit_amd import _lib
+    lib = _lib.load()
+    n = lib.rover_model_constants(None, 0)
+    hip = np.zeros(n, np.float32)
+    lib.rover_model_constants(hip.ctypes.data_as(C.c_void_p), n)
+    orc = oracle.model_constants()
+    assert n == len(orc) and np.array_equal(hip, orc)
+    j = json.load(open(os.path.join(ROOT, "tests", "golden", "rover_model.json")))
+    assert hip[0] == j["total_mass"] == 25.0
+    assert np.allclose(hip[1:4], j["com"], atol=1e-6) and np.allclose(hip[4:7], j["inertia_diag"], atol=1e-6)
+    wheels = np.array([j["wheel_centres"][k] for k in ["FL", "FR", "CL", "CR", "RL", "RR"]]).ravel()
+    assert np.allclose(hip[7:25], wheels, atol=1e-6)
+    bog = ["FL_Boogie", "FR_Boogie", "R_Boogie"]
+    assert np.allclose(hip[25:34], np.array([j["bogies"][b]["pivot"] for b in bog]).ravel(), atol=1e-6)
+    assert np.allclose(hip[34:43], np.array([j["bogies"][b]["axis"] for b in bog]).ravel(), atol=1e-6)
+    assert np.allclose(hip[43:46], [j["bogies"][b]["inertia"] for b in bog], atol=1e-6)
+    assert abs(hip[46] - j["wheel_contact_radius"]) < 1e-6
+    # actuator values of aau_rover_simple.py:42-64
+    assert list(hip[48:52]) == [8000.0, 1000.0, 12.0, 6.0] and list(hip[53:57]) == [100.0, 4000.0, 12.0, 6.0]

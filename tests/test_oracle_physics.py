@@ -1,0 +1,212 @@
+"""Plausibility of the reduced rover model (no physics oracle exists for PhysX: SURVEY section 4, item 3).
+Runs on the CPU oracle; the GPU tests show the HIP kernels reproduce the oracle bit for bit."""
+import numpy as np
+import pytest
+
+from helpers import flat, oracle_terrain, small_procedural
+
+H = 1.0 / 30.0
+
+
+def settle(ro, cfg, t, S, n=45):
+    z4, z6 = np.zeros((S.shape[0], 4), np.float32), np.zeros((S.shape[0], 6), np.float32)
+    ro.physics_step(cfg, t, S, z4, z6, n)
+    return S
+
+
+def fresh(ro, n=1, xy=(25.6, 25.6), z=0.5):
+    S = ro.new_state(n)
+    S[:, ro.POS:ro.POS + 3] = [xy[0], xy[1], z]
+    return S
+
+
+def test_static_rest_height_and_load_sharing(oracle):
+    ro = oracle
+    cfg, t = ro.default_config(), oracle_terrain(ro, flat(), 2)
+    S = settle(ro, cfg, t, fresh(ro))
+    # body origin rests 0.26878 m above the contact plane (observations.py:45) => flat-ground height scan == 0
+    assert abs(S[0, ro.POS + 2] - 0.26878) < 2e-4
+    lam = S[0, ro.LAMBDA_N:ro.LAMBDA_N + 6] / H
+    assert abs(lam.sum() - 25.0 * 9.81) < 0.5                                 # wheels carry the weight
+    assert abs(lam[0] - lam[1]) < 1.0 and abs(lam[2] - lam[3]) < 1.0 and abs(lam[4] - lam[5]) < 1.0   # left/right symmetric
+    # front bogie: pivot at x = 0.1535 between the front (0.44) and centre (0.007) wheels => centre ~ 2x front
+    assert 1.7 < lam[2] / lam[0] < 2.3
+    assert np.abs(S[0, ro.BOGIE_Q:ro.BOGIE_Q + 3]).max() < 1e-3 and np.abs(S[0, ro.LINVEL:ro.ANGVEL + 3]).max() < 1e-3
+    scan = ro.height_scan(cfg, t, S)
+    assert np.abs(scan).max() < 3e-4
+
+
+def test_straight_line_speed_is_omega_r(oracle):
+    ro = oracle
+    cfg, t = ro.default_config(), oracle_terrain(ro, flat(), 2)
+    S = settle(ro, cfg, t, fresh(ro))
+    w = np.full((1, 6), 4.0, np.float32)
+    ro.physics_step(cfg, t, S, np.zeros((1, 4), np.float32), w, 60)
+    x0 = S[0, 0]
+    ro.physics_step(cfg, t, S, np.zeros((1, 4), np.float32), w, 90)
+    v = (S[0, 0] - x0) / (90 * H)
+    omega = S[0, ro.WHEEL_QD:ro.WHEEL_QD + 6].mean()
+    assert abs(omega - 4.0) < 0.2                                               # stiff velocity drive (kd 4000)
+    assert abs(v - omega * 0.10179) < 0.01 and abs(S[0, 1] - 25.6) < 0.02       # no slip, no drift
+    # joint velocity limit 6 rad/s (aau_rover_simple.py:52): a 10 rad/s target saturates
+    ro.physics_step(cfg, t, S, np.zeros((1, 4), np.float32), np.full((1, 6), 10.0, np.float32), 60)
+    assert S[0, ro.WHEEL_QD:ro.WHEEL_QD + 6].max() <= 6.0 + 1e-6
+    assert np.linalg.norm(S[0, ro.LINVEL:ro.LINVEL + 2]) < 6.0 * 0.10179 + 0.02
+
+
+def test_point_turn_spins_in_place(oracle):
+    ro = oracle
+    cfg, t = ro.default_config(), oracle_terrain(ro, flat(), 2)
+    S = settle(ro, cfg, t, fresh(ro))
+    q = np.pi / 4
+    steer = np.array([[-q, q, q, -q]], np.float32)                   # model order FL, FR, RL, RR (X pattern)
+    wheel = np.array([[-3, 3, -3, 3, -3, 3]], np.float32)            # left backwards, right forwards => CCW
+    ro.physics_step(cfg, t, S, steer, wheel, 150)
+    assert S[0, ro.ANGVEL + 2] > 0.2                                  # yaw rate positive (counter-clockwise)
+    assert np.linalg.norm(S[0, 0:2] - 25.6) < 0.15                    # stays in place
+    assert np.allclose(S[0, ro.STEER_Q:ro.STEER_Q + 4], steer[0], atol=2e-2)
+
+
+def test_steering_joint_is_first_order_lag(oracle):
+    """kp 8000 / kd 1000 => time constant ~ kd / kp = 0.125 s, rate limit 6 rad/s (aau_rover_simple.py:43-49)."""
+    ro = oracle
+    cfg, t = ro.default_config(), oracle_terrain(ro, flat(), 2)
+    S = settle(ro, cfg, t, fresh(ro))
+    steer = np.full((1, 4), 0.5, np.float32)
+    ro.physics_step(cfg, t, S, steer, np.zeros((1, 6), np.float32), 4)     # 0.133 s ~ one time constant
+    q = S[0, ro.STEER_Q]
+    assert 0.25 < q < 0.42
+    ro.physics_step(cfg, t, S, steer, np.zeros((1, 6), np.float32), 40)
+    assert abs(S[0, ro.STEER_Q] - 0.5) < 2e-3
+    assert np.abs(S[0, ro.STEER_QD:ro.STEER_QD + 4]).max() <= 6.0
+
+
+def test_energy_does_not_grow_on_flat_ground(oracle):
+    ro = oracle
+    cfg, t = ro.default_config(), oracle_terrain(ro, flat(), 2)
+    S = settle(ro, cfg, t, fresh(ro))
+    S[0, ro.LINVEL:ro.LINVEL + 2] = [0.5, 0.2]
+    S[0, ro.ANGVEL + 2] = 0.4
+    S[0, ro.WHEEL_QD:ro.WHEEL_QD + 6] = 0.0
+    z4, z6 = np.zeros((1, 4), np.float32), np.zeros((1, 6), np.float32)
+    ke_prev = np.inf
+    for _ in range(30):
+        ro.physics_step(cfg, t, S, z4, z6, 3)
+        v, w = S[0, ro.LINVEL:ro.LINVEL + 3], S[0, ro.ANGVEL:ro.ANGVEL + 3]
+        ke = 0.5 * 25 * (v @ v) + 0.5 * 6.15 * w[2] ** 2
+        assert ke <= ke_prev + 1e-4
+        ke_prev = ke
+    assert ke_prev < 1e-3                                              # braked wheels stop the rover
+
+
+def test_slope_parking_and_friction_limit(oracle):
+    """With braked wheels the rover holds on a slope below atan(mu) and slides on a steeper one."""
+    ro = oracle
+    from isaac_rover_orbit_amd import terrain as T
+    for slope, holds in ((0.3, True), (1.2, False)):
+        Hh = W = 600
+        x = np.arange(W, dtype=np.float32) * 0.05
+        g = np.tile(slope * x, (Hh, 1)).astype(np.float32)
+        zero = np.zeros((Hh, W), np.uint8)
+        ter = T.Terrain(ground=g, obstacle=np.zeros_like(g), rock_mask=zero, safe_rock_mask=zero)
+        ter.spawn_locations = np.array([[15.0, 15.0, 15.0 * slope]], np.float32)
+        cfg, t = ro.default_config(), oracle_terrain(ro, ter)
+        S = fresh(ro, 1, (15.0, 15.0), 15.0 * slope + 0.45)
+        settle(ro, cfg, t, S, 30)
+        x0 = S[0, 0]
+        settle(ro, cfg, t, S, 60)
+        moved = abs(S[0, 0] - x0)
+        assert (moved < 0.02) if holds else (moved > 0.3), (slope, moved)
+        assert np.isfinite(S).all()
+
+
+def test_bogies_conform_and_respect_limits(oracle):
+    ro = oracle
+    ter = small_procedural()
+    cfg, t = ro.default_config(), oracle_terrain(ro, ter, 512)
+    S = ro.new_state(256)
+    ro.reset_all(cfg, t, S)
+    rng = np.random.RandomState(0)
+    lim = 0.17453292519943295
+    for _ in range(40):
+        a = rng.uniform(-1, 1, (256, 2)).astype(np.float32)
+        ro.step(cfg, t, S, a)
+        assert np.isfinite(S).all()
+        assert np.abs(S[:, ro.BOGIE_Q:ro.BOGIE_Q + 3]).max() <= lim + 1e-6
+        q = S[:, ro.QUAT:ro.QUAT + 4]
+        assert np.allclose((q ** 2).sum(1), 1.0, atol=1e-5)
+        assert np.linalg.norm(S[:, ro.LINVEL:ro.LINVEL + 3], axis=1).max() <= 1.5 + 1e-5
+        tilt = 1 - 2 * (q[:, 1] ** 2 + q[:, 2] ** 2)                     # cos of the tilt angle
+        assert tilt.min() > 0.8
+    assert np.abs(S[:, ro.BOGIE_Q:ro.BOGIE_Q + 3]).max() > 0.01           # the suspension is actually used
+
+
+def test_collision_only_from_obstacle_layer(oracle):
+    """Contact forces are reported only for wheels standing on the obstacle layer (rover_env_cfg.py:72-75)."""
+    ro = oracle
+    from isaac_rover_orbit_amd import terrain as T
+    Hh = W = 600
+    g = np.zeros((Hh, W), np.float32)
+    ob = np.zeros((Hh, W), np.float32)
+    ob[290:312, 305:318] = 0.05                                           # a 5 cm slab under the front-left wheel only
+    zero = np.zeros((Hh, W), np.uint8)
+    ter = T.Terrain(ground=g, obstacle=ob, rock_mask=zero, safe_rock_mask=zero)
+    ter.spawn_locations = np.array([[15.0, 15.0, 0.0]], np.float32)
+    cfg, t = ro.default_config(), oracle_terrain(ro, ter)
+    S = fresh(ro, 1, (15.17, 14.65), 0.45)                                # FL wheel at (15.61, 15.04) -> on the slab
+    f = None
+    for _ in range(40):
+        f = ro.physics_step(cfg, t, S, np.zeros((1, 4), np.float32), np.zeros((1, 6), np.float32), 1)
+    rows = np.nonzero(np.abs(f[0]).sum(1) > 0)[0]
+    assert list(rows) == [9]                                              # FL_Drive only
+    assert f[0, 9, 2] > 5.0                                               # carries load => "collision" (> 1 N)
+    od, oa, rew, term = ro.mdp_terms(cfg, np.zeros((1, 3), np.float32) + 5, np.zeros((1, 2), np.float32),
+                                     np.zeros((1, 2), np.float32), np.zeros(1, np.int32), f)
+    assert term[0, 3] == 1 and rew[0, 5] == 1.0
+
+
+def test_oracle_is_deterministic_and_shard_invariant(oracle):
+    ro = oracle
+    ter = small_procedural()
+    cfg, t = ro.default_config(seed_lo=77), oracle_terrain(ro, ter, 256)
+    rng = np.random.RandomState(4)
+    acts = rng.uniform(-1, 1, (10, 128, 2)).astype(np.float32)
+
+    def run(lo, hi):
+        S = ro.new_state(hi - lo)
+        ro.reset_all(cfg, t, S, env_id_offset=lo)
+        outs = []
+        for a in acts:
+            outs.append(ro.step(cfg, t, S, a[lo:hi], env_id_offset=lo)[0])
+        return S, np.stack(outs)
+
+    S_all, o_all = run(0, 128)
+    S_all2, o_all2 = run(0, 128)
+    assert np.array_equal(S_all, S_all2) and np.array_equal(o_all, o_all2)
+    S_lo, o_lo = run(0, 50)
+    S_hi, o_hi = run(50, 128)
+    assert np.array_equal(np.concatenate([S_lo, S_hi]), S_all)
+    assert np.array_equal(np.concatenate([o_lo, o_hi], 1), o_all)
+
+
+def test_step_ordering_quirks(oracle):
+    """B-13 (stale command in reward/termination), B-14 (counter before terminations), reset-time action zeroing."""
+    ro = oracle
+    cfg, t = ro.default_config(), oracle_terrain(ro, flat(), 8)
+    S = ro.new_state(4)
+    ro.reset_all(cfg, t, S)
+    Si = S.view(np.int32)
+    # env 0: the STALE command says "success" although the true target is 9 m away -> terminates anyway
+    S[0, ro.CMD_B:ro.CMD_B + 2] = 0.01
+    # env 1: counter at 749 -> incremented to 750 before the time_out test -> truncated, not terminated
+    Si[1, ro.EP_LEN] = 749
+    a = np.full((4, 2), 0.3, np.float32)
+    obs, rew, term, trunc, force, log = ro.step(cfg, t, S, a)
+    assert term[0] == 1 and trunc[0] == 0 and trunc[1] == 1 and term[1] == 0 and term[2] == 0 and trunc[2] == 0
+    # reached_target reward on env 0 uses the incremented counter: 5 * (750 - 1)/750 * 0.2 (+ the other terms)
+    assert rew[0] > 0.9
+    assert (obs[:2, :2] == 0).all() and (obs[2:, :2] == a[2:]).all()        # reset envs see a zeroed last action
+    assert (Si[:2, ro.EP_LEN] == 0).all() and (Si[2:, ro.EP_LEN] == 1).all()
+    assert log[13] == 2 and log[7] == 1 and log[8] == 1                      # one time_limit, one is_success
+    # fresh command for the observation: distance obs ~ 9 m * 0.11 after the reset
+    assert abs(obs[0, 2] - 0.99) < 2e-3
