@@ -75,6 +75,8 @@ typedef struct rover_config {
     float friction_mu;
     int32_t solver_iterations;
     int32_t max_target_tries;
+    int32_t step_mapping;    /* mapping of the step kernel: 0 = auto (by num_envs), 1 = one env per lane,
+                                2 = eight lanes per env (wave-cooperative); results are bit-identical */
 } rover_config;
 
 typedef struct rover_sim rover_sim;

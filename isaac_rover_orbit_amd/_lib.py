@@ -44,6 +44,7 @@ class RoverConfig(C.Structure):
         ("scan_height_offset", C.c_float), ("scan_nx", C.c_int32), ("scan_ny", C.c_int32),
         ("reset_z_offset", C.c_float), ("reset_mode", C.c_int32), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
         ("friction_mu", C.c_float), ("solver_iterations", C.c_int32), ("max_target_tries", C.c_int32),
+        ("step_mapping", C.c_int32),
     ]
 
 

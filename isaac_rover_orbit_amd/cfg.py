@@ -153,7 +153,8 @@ class RoverEnvCfg:
     reset_velocities: str = "reference"      # "reference" (root pose only, B-17) | "zero"
     seed: int = 0
     friction: float = 0.75
-    solver_iterations: int = 8
+    solver_iterations: int = 16             # Jacobi sweeps of the contact solver (ORBIT cfg: 32 position iterations)
+    step_mapping: str = "auto"              # "auto" | "lane" (one env per lane) | "group" (eight lanes per env)
     record_contact_forces: bool = True       # materialise contact_sensor.data.force_matrix_w every step
     # multi-GPU sharding: this process simulates global env ids [env_id_offset, env_id_offset + num_envs)
     env_id_offset: int = 0
@@ -215,6 +216,7 @@ class RoverEnvCfg:
         c.friction_mu = self.friction
         c.solver_iterations = self.solver_iterations
         c.max_target_tries = self.commands.max_target_tries
+        c.step_mapping = {"auto": 0, "lane": 1, "group": 2}[self.step_mapping]
         return c
 
 

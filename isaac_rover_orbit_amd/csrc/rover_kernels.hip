@@ -40,7 +40,8 @@ struct RvParams {
     float res, min_x, min_y;
     int n, env_id_offset;
     int rays, obs_w;
-    int tile_dim;  // LDS tile edge (cells) for the scan kernel
+    int tile_dim;    // LDS tile rows (cells) for the scan kernel
+    int tile_pitch;  // floats per LDS tile row (multiple of 4)
 };
 
 // ------------------------------------------------------------------------------------------------ small helpers
@@ -305,6 +306,12 @@ __device__ __forceinline__ void mdp_terms_one(const rover_config &c, const float
 }
 
 // ------------------------------------------------------------------------------------------------ (a3, a5) dynamics
+// Reduced rover model; mirrors oracle/rover_oracle.c physics_substep operation for operation.
+// The per-wheel pieces below are shared by the two mappings of the step kernel:
+//   "lane"  : one env per lane, the six wheels looped inside the lane            (throughput mapping, large N)
+//   "group" : eight lanes per env -- slots [FL, CL, FR, CR, RL, RR, -, -] --, cross-wheel sums by xor butterflies
+//             (latency mapping, small N: 8x more waves, ~6x shorter dependent instruction stream per env)
+// Both evaluate cross-wheel sums in the tree ((s0+s1)+(s2+s3)) + ((s4+s5)+(0+0)), so they agree bit for bit.
 struct Contact {
     float n[3], t[3], s[3];
     float jn_a[3], jt_a[3], js_a[3];  // angular Jacobians R^T (r x dir), in the BODY frame (diagonal inertia)
@@ -315,8 +322,218 @@ struct Contact {
     float obst;
 };
 
-// One physics substep (dt = sim_dt) of the reduced rover model; S = the env's state words in registers.
-// Mirrors oracle/rover_oracle.c physics_substep operation for operation.
+#define RV_SPLIT_C 6.0f  // contacts sharing the chassis (mass splitting)
+#define RV_SPLIT_B 2.0f  // contacts sharing one bogie
+#define RV_TREE6(a, b, c, d, e, f) ((((a) + (b)) + ((c) + (d))) + (((e) + (f)) + (0.0f + 0.0f)))
+
+// implicit-PD steering joint (kp 8000, kd 1000, effort 12, rate 6; aau_rover_simple.py:43-49)
+__device__ __forceinline__ void steer_joint(float h, float target, float &q, float &qd)
+{
+    const float q0 = q, qd0 = qd;
+    const float e = target - q0;
+    float v = (RV_STEER_INERTIA * qd0 + h * RV_STEER_KP * e) / (RV_STEER_INERTIA + h * RV_STEER_KD + h * h * RV_STEER_KP);
+    const float tau = (v - qd0) * RV_STEER_INERTIA / h;
+    if (tau > RV_STEER_EFFORT) v = qd0 + RV_STEER_EFFORT * h / RV_STEER_INERTIA;
+    if (tau < -RV_STEER_EFFORT) v = qd0 - RV_STEER_EFFORT * h / RV_STEER_INERTIA;
+    v = clampf(v, -RV_STEER_VLIM, RV_STEER_VLIM);
+    float x = q0 + h * v;
+    if (x > RV_STEER_QLIM) { x = RV_STEER_QLIM; v = 0.0f; }
+    if (x < -RV_STEER_QLIM) { x = -RV_STEER_QLIM; v = 0.0f; }
+    q = x;
+    qd = v;
+}
+
+// implicit-PD wheel motor about q* = 0 with velocity target (kp 100, kd 4000, effort 12, rate 6; :50-56)
+__device__ __forceinline__ void wheel_motor(float h, float target, float lt, float &q, float &qd)
+{
+    const float q0 = q, qd0 = qd;
+    const float tgt = clampf(target, -RV_WHEEL_VLIM, RV_WHEEL_VLIM);
+    const float tau_ext = -RV_WHEEL_CONTACT_RADIUS * lt / h;
+    float v = (RV_WHEEL_INERTIA * qd0 + h * (RV_WHEEL_KP * (0.0f - q0) + RV_WHEEL_KD * tgt + tau_ext)) /
+              (RV_WHEEL_INERTIA + h * RV_WHEEL_KD + h * h * RV_WHEEL_KP);
+    const float tau = RV_WHEEL_KP * (0.0f - q0 - h * v) + RV_WHEEL_KD * (tgt - v);
+    if (tau > RV_WHEEL_EFFORT) v = qd0 + h * (RV_WHEEL_EFFORT + tau_ext) / RV_WHEEL_INERTIA;
+    if (tau < -RV_WHEEL_EFFORT) v = qd0 + h * (-RV_WHEEL_EFFORT + tau_ext) / RV_WHEEL_INERTIA;
+    v = clampf(v, -RV_WHEEL_VLIM, RV_WHEEL_VLIM);
+    float x = q0 + h * v;
+    if (x > RV_TWO_PI_F) x -= RV_TWO_PI_F;
+    if (x < -RV_TWO_PI_F) x += RV_TWO_PI_F;
+    q = x;
+    qd = v;
+}
+
+// contact geometry, Jacobians, split effective masses and bias of ONE wheel
+template <bool WANT_OBST>
+__device__ __forceinline__ void wheel_geometry(const RvParams &p, const float R[3][3], const float *pos, const float *com_w,
+                                               const float *wb, const float *P, const float *ax, float b_winv, float bq,
+                                               bool at_hi, bool at_lo, bool steerable, float steer_q, float inv_m,
+                                               const float *inv_I, float h, Contact &ct)
+{
+    const float d0[3] = {wb[0] - P[0], wb[1] - P[1], wb[2] - P[2]};
+    float sb, cb;
+    rv_sincosf(bq, &sb, &cb);
+    float axd[3];
+    cross3(ax, d0, axd);
+    const float ad = dot3(ax, d0);
+    float cen_b[3], cen_w[3], piv_w[3], ax_w[3], tmp[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) cen_b[i] = P[i] + (d0[i] * cb + axd[i] * sb + ax[i] * (ad * (1.0f - cb)));
+    mat_vec(R, cen_b, tmp);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) cen_w[i] = pos[i] + tmp[i];
+    mat_vec(R, P, tmp);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) piv_w[i] = pos[i] + tmp[i];
+    mat_vec(R, ax, ax_w);
+    float hgt, gx, gy;
+    ct.obst = 0.0f;
+    terrain_sample<WANT_OBST>(p, cen_w[0], cen_w[1], hgt, gx, gy, ct.obst);
+    const float inv = 1.0f / sqrtf(gx * gx + gy * gy + 1.0f);
+    ct.n[0] = -gx * inv; ct.n[1] = -gy * inv; ct.n[2] = inv;
+    const float gap = (cen_w[2] - hgt) * ct.n[2] - RV_WHEEL_CONTACT_RADIUS;
+    float cp[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) cp[i] = cen_w[i] - RV_WHEEL_CONTACT_RADIUS * ct.n[i];
+    float fwd_b[3] = {1.0f, 0.0f, 0.0f}, fwd[3];
+    if (steerable) rv_sincosf(steer_q, &fwd_b[1], &fwd_b[0]);
+    mat_vec(R, fwd_b, fwd);
+    const float fn = dot3(fwd, ct.n);
+    float tl = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { ct.t[i] = fwd[i] - fn * ct.n[i]; tl += ct.t[i] * ct.t[i]; }
+    const float tinv = 1.0f / sqrtf(tl > 1.0e-12f ? tl : 1.0e-12f);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ct.t[i] *= tinv;
+    cross3(ct.n, ct.t, ct.s);
+    float r[3], rp[3], x[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { r[i] = cp[i] - com_w[i]; rp[i] = cp[i] - piv_w[i]; }
+    cross3(r, ct.n, x); mat_tvec(R, x, ct.jn_a);
+    cross3(r, ct.t, x); mat_tvec(R, x, ct.jt_a);
+    cross3(r, ct.s, x); mat_tvec(R, x, ct.js_a);
+    cross3(rp, ct.n, x); ct.jn_b = dot3(ax_w, x);
+    cross3(rp, ct.t, x); ct.jt_b = dot3(ax_w, x);
+    cross3(rp, ct.s, x); ct.js_b = dot3(ax_w, x);
+    // unilateral lock of a bogie that sits on its +-10 deg stop
+    if ((at_hi && ct.jn_b > 0.0f) || (at_lo && ct.jn_b < 0.0f)) ct.jn_b = 0.0f;
+    if (at_hi || at_lo) { ct.jt_b = 0.0f; ct.js_b = 0.0f; }
+    if (gap > 0.0f) {
+        ct.bias = -gap / h;  // speculative contact while separated
+    } else {
+        const float push = RV_BAUMGARTE * (-gap) / h;
+        ct.bias = push < RV_MAX_DEPENETRATION_VEL ? push : RV_MAX_DEPENETRATION_VEL;
+    }
+    // mass splitting: every contact sees 1/6 of the chassis and 1/2 of its bogie
+    ct.mn = 1.0f / (RV_SPLIT_C * inv_m + RV_SPLIT_C * wdot3(ct.jn_a, inv_I) + RV_SPLIT_B * (ct.jn_b * ct.jn_b * b_winv));
+    ct.mt = 1.0f / (RV_SPLIT_C * inv_m + RV_SPLIT_C * wdot3(ct.jt_a, inv_I) + RV_SPLIT_B * (ct.jt_b * ct.jt_b * b_winv));
+    ct.ms = 1.0f / (RV_SPLIT_C * inv_m + RV_SPLIT_C * wdot3(ct.js_a, inv_I) + RV_SPLIT_B * (ct.js_b * ct.js_b * b_winv));
+}
+
+// warm-start contribution of one wheel
+__device__ __forceinline__ void wheel_warm(const Contact &ct, float inv_m, const float *inv_I, float b_winv, float *dv,
+                                           float *dw, float &db)
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { dv[i] = ct.n[i] * (ct.ln * inv_m); dw[i] = ct.jn_a[i] * (inv_I[i] * ct.ln); }
+    db = ct.jn_b * b_winv * ct.ln;
+}
+
+// the three rows of one wheel against a snapshot (v, w, bogie rate) of the shared velocities; returns its velocity
+// contributions with the TRUE masses (dv, dw, db); the local copies advance with the split masses
+__device__ __forceinline__ void wheel_rows(Contact &ct, const float *v, const float *w, float bdj, float inv_m,
+                                           const float *inv_I, float b_winv, float mu, float lt_motor, float wheel_w,
+                                           float *dv, float *dw, float &db)
+{
+    float vl[3] = {v[0], v[1], v[2]}, wl[3] = {w[0], w[1], w[2]}, bl = bdj;
+    {
+        const float vrel = dot3(ct.n, vl) + dot3(ct.jn_a, wl) + ct.jn_b * bl;
+        float ln = ct.ln - (vrel - ct.bias) * ct.mn;
+        if (ln < 0.0f) ln = 0.0f;
+        const float d = ln - ct.ln;
+        ct.ln = ln;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float a = ct.n[i] * (d * inv_m), b = ct.jn_a[i] * (inv_I[i] * d);
+            dv[i] = a; dw[i] = b;
+            vl[i] += RV_SPLIT_C * a; wl[i] += RV_SPLIT_C * b;
+        }
+        const float e = ct.jn_b * b_winv * d;
+        db = e;
+        bl += RV_SPLIT_B * e;
+    }
+    const float lim = mu * ct.ln;
+    {   // longitudinal: the rim speed R_W * omega is prescribed by the (stiff) wheel motor
+        const float vrel = dot3(ct.t, vl) + dot3(ct.jt_a, wl) + ct.jt_b * bl - RV_WHEEL_CONTACT_RADIUS * wheel_w;
+        const float lmax = lim < lt_motor ? lim : lt_motor;
+        const float lt = clampf(ct.lt - vrel * ct.mt, -lmax, lmax);
+        const float d = lt - ct.lt;
+        ct.lt = lt;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float a = ct.t[i] * (d * inv_m), b = ct.jt_a[i] * (inv_I[i] * d);
+            dv[i] += a; dw[i] += b;
+            vl[i] += RV_SPLIT_C * a; wl[i] += RV_SPLIT_C * b;
+        }
+        const float e = ct.jt_b * b_winv * d;
+        db += e;
+        bl += RV_SPLIT_B * e;
+    }
+    {   // lateral
+        const float vrel = dot3(ct.s, vl) + dot3(ct.js_a, wl) + ct.js_b * bl;
+        const float ls = clampf(ct.ls - vrel * ct.ms, -lim, lim);
+        const float d = ls - ct.ls;
+        ct.ls = ls;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            dv[i] += ct.s[i] * (d * inv_m);
+            dw[i] += ct.js_a[i] * (inv_I[i] * d);
+        }
+        db += ct.js_b * b_winv * d;
+    }
+}
+
+// chassis integration shared by both mappings: velocity cap, symplectic Euler, quaternion update
+__device__ __forceinline__ void chassis_integrate(float h, const float R[3][3], float *v, float *wb, float *com_w,
+                                                  float *pos, float *quat, float *linvel, float *angvel)
+{
+    constexpr float COM_B[3] = RV_COM_B_INIT;
+    const float sp = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    if (sp > RV_MAX_LINEAR_VEL) {
+        const float sc = RV_MAX_LINEAR_VEL / sp;
+        v[0] *= sc; v[1] *= sc; v[2] *= sc;
+    }
+    float w[3];
+    mat_vec(R, wb, w);  // angular velocity back to the world frame
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { com_w[i] += h * v[i]; linvel[i] = v[i]; angvel[i] = w[i]; }
+    {
+        const float qw = quat[0], qx = quat[1], qy = quat[2], qz = quat[3];
+        const float hh = 0.5f * h;
+        const float nw = qw + hh * (-w[0] * qx - w[1] * qy - w[2] * qz);
+        const float nx = qx + hh * (w[0] * qw + w[1] * qz - w[2] * qy);
+        const float ny = qy + hh * (w[1] * qw + w[2] * qx - w[0] * qz);
+        const float nz = qz + hh * (w[2] * qw + w[0] * qy - w[1] * qx);
+        const float inv = 1.0f / sqrtf(nw * nw + nx * nx + ny * ny + nz * nz);
+        quat[0] = nw * inv; quat[1] = nx * inv; quat[2] = ny * inv; quat[3] = nz * inv;
+    }
+    float R2[3][3], com_off[3];
+    quat_to_mat(quat, R2);
+    mat_vec(R2, COM_B, com_off);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pos[i] = com_w[i] - com_off[i];
+}
+
+__device__ __forceinline__ void bogie_integrate(float h, float bq0, float bdv, float &q_out, float &qd_out)
+{
+    float q = bq0 + h * bdv;
+    float qd = bdv;
+    if (q > RV_BOGIE_QLIM) { q = RV_BOGIE_QLIM; if (qd > 0.0f) qd = 0.0f; }
+    if (q < -RV_BOGIE_QLIM) { q = -RV_BOGIE_QLIM; if (qd < 0.0f) qd = 0.0f; }
+    q_out = q;
+    qd_out = qd;
+}
+
+// ---- "lane" mapping: one physics substep of one env, S = the env's state words in registers
 template <bool RECORD_FORCE>
 __device__ __forceinline__ void physics_substep(const RvParams &p, float *S, const float *steer_t, const float *wheel_t,
                                                 float *F /* 39, only if RECORD_FORCE */)
@@ -324,32 +541,19 @@ __device__ __forceinline__ void physics_substep(const RvParams &p, float *S, con
     constexpr float COM_B[3] = RV_COM_B_INIT;
     constexpr float INERTIA_B[3] = RV_INERTIA_B_INIT;
     constexpr float WHEEL_B[6][3] = RV_WHEEL_B_INIT;
-    constexpr int WHEEL_BOGIE[6] = RV_WHEEL_BOGIE_INIT;
     constexpr int WHEEL_STEER[6] = RV_WHEEL_STEER_INIT;
     constexpr int WHEEL_BODY[6] = RV_WHEEL_BODY_INIT;
+    constexpr int SLOT_WHEEL[6] = RV_SLOT_WHEEL_INIT;
     constexpr float BOGIE_PIVOT[3][3] = RV_BOGIE_PIVOT_INIT;
     constexpr float BOGIE_AXIS[3][3] = RV_BOGIE_AXIS_INIT;
     constexpr float BOGIE_INERTIA[3] = RV_BOGIE_INERTIA_INIT;
 
     const float h = p.cfg.sim_dt;
     const float mu = p.cfg.friction_mu;
-    // ---- 1. steering joints: implicit PD
+    // ---- 1. steering joints
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const float q0 = S[ROVER_STEER_Q + s], qd0 = S[ROVER_STEER_QD + s];
-        const float e = steer_t[s] - q0;
-        float qd = (RV_STEER_INERTIA * qd0 + h * RV_STEER_KP * e) / (RV_STEER_INERTIA + h * RV_STEER_KD + h * h * RV_STEER_KP);
-        const float tau = (qd - qd0) * RV_STEER_INERTIA / h;
-        if (tau > RV_STEER_EFFORT) qd = qd0 + RV_STEER_EFFORT * h / RV_STEER_INERTIA;
-        if (tau < -RV_STEER_EFFORT) qd = qd0 - RV_STEER_EFFORT * h / RV_STEER_INERTIA;
-        qd = clampf(qd, -RV_STEER_VLIM, RV_STEER_VLIM);
-        float q = q0 + h * qd;
-        if (q > RV_STEER_QLIM) { q = RV_STEER_QLIM; qd = 0.0f; }
-        if (q < -RV_STEER_QLIM) { q = -RV_STEER_QLIM; qd = 0.0f; }
-        S[ROVER_STEER_Q + s] = q;
-        S[ROVER_STEER_QD + s] = qd;
-    }
-    // ---- 2. chassis frame, world inverse inertia, gravity
+    for (int s = 0; s < 4; ++s) steer_joint(h, steer_t[s], S[ROVER_STEER_Q + s], S[ROVER_STEER_QD + s]);
+    // ---- 2. chassis frame, gravity
     float R[3][3];
     quat_to_mat(S + ROVER_QUAT, R);
     float com_off[3], com_w[3];
@@ -371,187 +575,146 @@ __device__ __forceinline__ void physics_substep(const RvParams &p, float *S, con
         at_lo[j] = bq[j] <= -RV_BOGIE_QLIM + 1.0e-5f;
     }
     const float inv_m = 1.0f / RV_M_TOTAL;
-    // ---- 3. contact geometry
+    // ---- 3. contact geometry (slot order), warm start
     Contact C[6];
-    float wheel_w[6];
+    float dv[6][3], dw[6][3], db[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        Contact &ct = C[k];
-        const int j = WHEEL_BOGIE[k];
+    for (int s = 0; s < 6; ++s) {
+        const int k = SLOT_WHEEL[s], j = s >> 1, si = WHEEL_STEER[k];
+        const float wb[3] = {WHEEL_B[k][0], WHEEL_B[k][1], WHEEL_B[k][2]};
         const float P[3] = {BOGIE_PIVOT[j][0], BOGIE_PIVOT[j][1], BOGIE_PIVOT[j][2]};
         const float ax[3] = {BOGIE_AXIS[j][0], BOGIE_AXIS[j][1], BOGIE_AXIS[j][2]};
-        const float d0[3] = {WHEEL_B[k][0] - P[0], WHEEL_B[k][1] - P[1], WHEEL_B[k][2] - P[2]};
-        const float cb = rv_cosf(bq[j]), sb = rv_sinf(bq[j]);
-        float axd[3];
-        cross3(ax, d0, axd);
-        const float ad = dot3(ax, d0);
-        float cen_b[3], cen_w[3], piv_w[3], ax_w[3], tmp[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) cen_b[i] = P[i] + (d0[i] * cb + axd[i] * sb + ax[i] * (ad * (1.0f - cb)));
-        mat_vec(R, cen_b, tmp);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) cen_w[i] = S[ROVER_POS + i] + tmp[i];
-        mat_vec(R, P, tmp);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) piv_w[i] = S[ROVER_POS + i] + tmp[i];
-        mat_vec(R, ax, ax_w);
-        float hgt, gx, gy;
-        ct.obst = 0.0f;
-        terrain_sample<RECORD_FORCE>(p, cen_w[0], cen_w[1], hgt, gx, gy, ct.obst);
-        const float inv = 1.0f / sqrtf(gx * gx + gy * gy + 1.0f);
-        ct.n[0] = -gx * inv; ct.n[1] = -gy * inv; ct.n[2] = inv;
-        const float gap = (cen_w[2] - hgt) * ct.n[2] - RV_WHEEL_CONTACT_RADIUS;
-        float cp[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) cp[i] = cen_w[i] - RV_WHEEL_CONTACT_RADIUS * ct.n[i];
-        const int si = WHEEL_STEER[k];
-        float fwd_b[3] = {1.0f, 0.0f, 0.0f}, fwd[3];
-        if (si >= 0) { fwd_b[0] = rv_cosf(S[ROVER_STEER_Q + (si >= 0 ? si : 0)]); fwd_b[1] = rv_sinf(S[ROVER_STEER_Q + (si >= 0 ? si : 0)]); }
-        mat_vec(R, fwd_b, fwd);
-        const float fn = dot3(fwd, ct.n);
-        float tl = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { ct.t[i] = fwd[i] - fn * ct.n[i]; tl += ct.t[i] * ct.t[i]; }
-        const float tinv = 1.0f / sqrtf(tl > 1.0e-12f ? tl : 1.0e-12f);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) ct.t[i] *= tinv;
-        cross3(ct.n, ct.t, ct.s);
-        float r[3], rp[3], x[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { r[i] = cp[i] - com_w[i]; rp[i] = cp[i] - piv_w[i]; }
-        cross3(r, ct.n, x); mat_tvec(R, x, ct.jn_a);
-        cross3(r, ct.t, x); mat_tvec(R, x, ct.jt_a);
-        cross3(r, ct.s, x); mat_tvec(R, x, ct.js_a);
-        cross3(rp, ct.n, x); ct.jn_b = dot3(ax_w, x);
-        cross3(rp, ct.t, x); ct.jt_b = dot3(ax_w, x);
-        cross3(rp, ct.s, x); ct.js_b = dot3(ax_w, x);
-        if ((at_hi[j] && ct.jn_b > 0.0f) || (at_lo[j] && ct.jn_b < 0.0f)) ct.jn_b = 0.0f;
-        if (at_hi[j] || at_lo[j]) { ct.jt_b = 0.0f; ct.js_b = 0.0f; }
-        ct.mn = 1.0f / (inv_m + wdot3(ct.jn_a, inv_I) + ct.jn_b * ct.jn_b * b_winv[j]);
-        ct.mt = 1.0f / (inv_m + wdot3(ct.jt_a, inv_I) + ct.jt_b * ct.jt_b * b_winv[j]);
-        ct.ms = 1.0f / (inv_m + wdot3(ct.js_a, inv_I) + ct.js_b * ct.js_b * b_winv[j]);
-        if (gap > 0.0f) {
-            ct.bias = -gap / h;
-        } else {
-            const float push = RV_BAUMGARTE * (-gap) / h;
-            ct.bias = push < RV_MAX_DEPENETRATION_VEL ? push : RV_MAX_DEPENETRATION_VEL;
-        }
-        ct.ln = RV_WARM_START * S[ROVER_LAMBDA_N + k];
-        ct.lt = 0.0f;
-        ct.ls = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { v[i] += ct.n[i] * (ct.ln * inv_m); w[i] += ct.jn_a[i] * (inv_I[i] * ct.ln); }
-        bd[j] += ct.jn_b * b_winv[j] * ct.ln;
-        wheel_w[k] = S[ROVER_WHEEL_QD + k];
+        wheel_geometry<RECORD_FORCE>(p, R, S + ROVER_POS, com_w, wb, P, ax, b_winv[j], bq[j], at_hi[j], at_lo[j], si >= 0,
+                                     S[ROVER_STEER_Q + (si >= 0 ? si : 0)], inv_m, inv_I, h, C[s]);
+        C[s].ln = RV_WARM_START * S[ROVER_LAMBDA_N + k];
+        C[s].lt = 0.0f;
+        C[s].ls = 0.0f;
+        wheel_warm(C[s], inv_m, inv_I, b_winv[j], dv[s], dw[s], db[s]);
     }
-    // ---- 4. projected Gauss-Seidel over {normal, longitudinal, lateral} x 6 wheels
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        v[i] += RV_TREE6(dv[0][i], dv[1][i], dv[2][i], dv[3][i], dv[4][i], dv[5][i]);
+        w[i] += RV_TREE6(dw[0][i], dw[1][i], dw[2][i], dw[3][i], dw[4][i], dw[5][i]);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) bd[j] += db[2 * j] + db[2 * j + 1];
+    // ---- 4. wheel-parallel projected Jacobi with mass splitting
     const float lt_motor = RV_WHEEL_EFFORT * h / RV_WHEEL_CONTACT_RADIUS;
     for (int it = 0; it < p.cfg.solver_iterations; ++it) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            Contact &ct = C[k];
-            const int j = WHEEL_BOGIE[k];
-            {
-                const float vrel = dot3(ct.n, v) + dot3(ct.jn_a, w) + ct.jn_b * bd[j];
-                float ln = ct.ln - (vrel - ct.bias) * ct.mn;
-                if (ln < 0.0f) ln = 0.0f;
-                const float d = ln - ct.ln;
-                ct.ln = ln;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) { v[i] += ct.n[i] * (d * inv_m); w[i] += ct.jn_a[i] * (inv_I[i] * d); }
-                bd[j] += ct.jn_b * b_winv[j] * d;
-            }
-            const float lim = mu * ct.ln;
-            {
-                const float vrel = dot3(ct.t, v) + dot3(ct.jt_a, w) + ct.jt_b * bd[j] - RV_WHEEL_CONTACT_RADIUS * wheel_w[k];
-                const float lmax = lim < lt_motor ? lim : lt_motor;
-                const float lt = clampf(ct.lt - vrel * ct.mt, -lmax, lmax);
-                const float d = lt - ct.lt;
-                ct.lt = lt;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) { v[i] += ct.t[i] * (d * inv_m); w[i] += ct.jt_a[i] * (inv_I[i] * d); }
-                bd[j] += ct.jt_b * b_winv[j] * d;
-            }
-            {
-                const float vrel = dot3(ct.s, v) + dot3(ct.js_a, w) + ct.js_b * bd[j];
-                const float ls = clampf(ct.ls - vrel * ct.ms, -lim, lim);
-                const float d = ls - ct.ls;
-                ct.ls = ls;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) { v[i] += ct.s[i] * (d * inv_m); w[i] += ct.js_a[i] * (inv_I[i] * d); }
-                bd[j] += ct.js_b * b_winv[j] * d;
-            }
+        for (int s = 0; s < 6; ++s) {
+            const int k = SLOT_WHEEL[s], j = s >> 1;
+            wheel_rows(C[s], v, w, bd[j], inv_m, inv_I, b_winv[j], mu, lt_motor, S[ROVER_WHEEL_QD + k], dv[s], dw[s], db[s]);
         }
-    }
-    // ---- 5. wheel motors: implicit PD about q* = 0 with velocity target
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const float q0 = S[ROVER_WHEEL_Q + k], qd0 = S[ROVER_WHEEL_QD + k];
-        const float tgt = clampf(wheel_t[k], -RV_WHEEL_VLIM, RV_WHEEL_VLIM);
-        const float tau_ext = -RV_WHEEL_CONTACT_RADIUS * C[k].lt / h;
-        float qd = (RV_WHEEL_INERTIA * qd0 + h * (RV_WHEEL_KP * (0.0f - q0) + RV_WHEEL_KD * tgt + tau_ext)) /
-                   (RV_WHEEL_INERTIA + h * RV_WHEEL_KD + h * h * RV_WHEEL_KP);
-        const float tau = RV_WHEEL_KP * (0.0f - q0 - h * qd) + RV_WHEEL_KD * (tgt - qd);
-        if (tau > RV_WHEEL_EFFORT) qd = qd0 + h * (RV_WHEEL_EFFORT + tau_ext) / RV_WHEEL_INERTIA;
-        if (tau < -RV_WHEEL_EFFORT) qd = qd0 + h * (-RV_WHEEL_EFFORT + tau_ext) / RV_WHEEL_INERTIA;
-        qd = clampf(qd, -RV_WHEEL_VLIM, RV_WHEEL_VLIM);
-        float q = q0 + h * qd;
-        if (q > RV_TWO_PI_F) q -= RV_TWO_PI_F;
-        if (q < -RV_TWO_PI_F) q += RV_TWO_PI_F;
-        S[ROVER_WHEEL_Q + k] = q;
-        S[ROVER_WHEEL_QD + k] = qd;
-        S[ROVER_LAMBDA_N + k] = C[k].ln;
+        for (int i = 0; i < 3; ++i) {
+            v[i] += RV_TREE6(dv[0][i], dv[1][i], dv[2][i], dv[3][i], dv[4][i], dv[5][i]);
+            w[i] += RV_TREE6(dw[0][i], dw[1][i], dw[2][i], dw[3][i], dw[4][i], dw[5][i]);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) bd[j] += db[2 * j] + db[2 * j + 1];
     }
-    // ---- 6. obstacle contact report (forces on the Drive bodies that touch the obstacle layer)
+    // ---- 5. wheel motors, 6. obstacle contact report
     if (RECORD_FORCE) {
 #pragma unroll
         for (int i = 0; i < ROVER_NUM_BODIES * 3; ++i) F[i] = 0.0f;
+    }
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            if (C[k].obst > RV_OBSTACLE_EPS) {
+    for (int s = 0; s < 6; ++s) {
+        const int k = SLOT_WHEEL[s];
+        wheel_motor(h, wheel_t[k], C[s].lt, S[ROVER_WHEEL_Q + k], S[ROVER_WHEEL_QD + k]);
+        S[ROVER_LAMBDA_N + k] = C[s].ln;
+        if (RECORD_FORCE) {
+            if (C[s].obst > RV_OBSTACLE_EPS) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
-                    F[WHEEL_BODY[k] * 3 + i] = (C[k].n[i] * C[k].ln + C[k].t[i] * C[k].lt + C[k].s[i] * C[k].ls) / h;
+                    F[WHEEL_BODY[k] * 3 + i] = (C[s].n[i] * C[s].ln + C[s].t[i] * C[s].lt + C[s].s[i] * C[s].ls) / h;
             }
         }
     }
     // ---- 7. integrate
-    const float sp = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-    if (sp > RV_MAX_LINEAR_VEL) {
-        const float sc = RV_MAX_LINEAR_VEL / sp;
-        v[0] *= sc; v[1] *= sc; v[2] *= sc;
-    }
-    {
-        float ww[3];
-        mat_vec(R, w, ww);  // back to the world frame
-        w[0] = ww[0]; w[1] = ww[1]; w[2] = ww[2];
-    }
+    chassis_integrate(h, R, v, w, com_w, S + ROVER_POS, S + ROVER_QUAT, S + ROVER_LINVEL, S + ROVER_ANGVEL);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { com_w[i] += h * v[i]; S[ROVER_LINVEL + i] = v[i]; S[ROVER_ANGVEL + i] = w[i]; }
-    {
-        float *q = S + ROVER_QUAT;
-        const float qw = q[0], qx = q[1], qy = q[2], qz = q[3];
-        const float hh = 0.5f * h;
-        const float nw = qw + hh * (-w[0] * qx - w[1] * qy - w[2] * qz);
-        const float nx = qx + hh * (w[0] * qw + w[1] * qz - w[2] * qy);
-        const float ny = qy + hh * (w[1] * qw + w[2] * qx - w[0] * qz);
-        const float nz = qz + hh * (w[2] * qw + w[0] * qy - w[1] * qx);
-        const float inv = 1.0f / sqrtf(nw * nw + nx * nx + ny * ny + nz * nz);
-        q[0] = nw * inv; q[1] = nx * inv; q[2] = ny * inv; q[3] = nz * inv;
-    }
-    quat_to_mat(S + ROVER_QUAT, R);
+    for (int j = 0; j < 3; ++j) bogie_integrate(h, bq[j], bd[j], S[ROVER_BOGIE_Q + j], S[ROVER_BOGIE_QD + j]);
+}
+
+// ---- "group" mapping: eight lanes per env.  Per-lane copy of the chassis + ONE wheel.
+struct GroupLane {
+    // chassis (identical in the 8 lanes of a group)
+    float pos[3], quat[4], linvel[3], angvel[3];
+    // this lane's bogie / steer joint / wheel
+    float bq, bqd, sq, sqd, wq, wqd, lam;
+    float steer_t, wheel_t;
+    // constants of this lane's slot
+    float wb[3], P[3], ax[3], b_inertia;
+    bool steerable, wheel_active;
+};
+
+__device__ __forceinline__ float group_sum8(float x)  // ((s0+s1)+(s2+s3)) + ((s4+s5)+(s6+s7)), same value in all 8 lanes
+{
+    x += __shfl_xor(x, 1, 64);
+    x += __shfl_xor(x, 2, 64);
+    x += __shfl_xor(x, 4, 64);
+    return x;
+}
+
+template <bool RECORD_FORCE>
+__device__ __forceinline__ void physics_substep_group(const RvParams &p, GroupLane &g, float *Fw /* 3: this wheel's force */)
+{
+    constexpr float COM_B[3] = RV_COM_B_INIT;
+    constexpr float INERTIA_B[3] = RV_INERTIA_B_INIT;
+    const float h = p.cfg.sim_dt;
+    const float mu = p.cfg.friction_mu;
+    if (g.steerable) steer_joint(h, g.steer_t, g.sq, g.sqd);
+    float R[3][3];
+    quat_to_mat(g.quat, R);
+    float com_off[3], com_w[3];
     mat_vec(R, COM_B, com_off);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) S[ROVER_POS + i] = com_w[i] - com_off[i];
+    for (int i = 0; i < 3; ++i) com_w[i] = g.pos[i] + com_off[i];
+    const float inv_I[3] = {1.0f / INERTIA_B[0], 1.0f / INERTIA_B[1], 1.0f / INERTIA_B[2]};
+    float v[3] = {g.linvel[0], g.linvel[1], g.linvel[2] - RV_GRAVITY * h};
+    float w[3];
+    mat_tvec(R, g.angvel, w);
+    const float bq = g.bq;
+    float bd = g.bqd / (1.0f + h * RV_BOGIE_DAMPING / g.b_inertia);
+    const float b_winv = 1.0f / g.b_inertia;
+    const bool at_hi = bq >= RV_BOGIE_QLIM - 1.0e-5f, at_lo = bq <= -RV_BOGIE_QLIM + 1.0e-5f;
+    const float inv_m = 1.0f / RV_M_TOTAL;
+    Contact ct;
+    wheel_geometry<RECORD_FORCE>(p, R, g.pos, com_w, g.wb, g.P, g.ax, b_winv, bq, at_hi, at_lo, g.steerable, g.sq, inv_m, inv_I,
+                                 h, ct);
+    ct.ln = RV_WARM_START * g.lam;
+    ct.lt = 0.0f;
+    ct.ls = 0.0f;
+    float dv[3], dw[3], db;
+    wheel_warm(ct, inv_m, inv_I, b_winv, dv, dw, db);
+    const bool act = g.wheel_active;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        float q = bq[j] + h * bd[j];
-        float qd = bd[j];
-        if (q > RV_BOGIE_QLIM) { q = RV_BOGIE_QLIM; if (qd > 0.0f) qd = 0.0f; }
-        if (q < -RV_BOGIE_QLIM) { q = -RV_BOGIE_QLIM; if (qd < 0.0f) qd = 0.0f; }
-        S[ROVER_BOGIE_Q + j] = q;
-        S[ROVER_BOGIE_QD + j] = qd;
+    for (int i = 0; i < 3; ++i) {
+        v[i] += group_sum8(act ? dv[i] : 0.0f);
+        w[i] += group_sum8(act ? dw[i] : 0.0f);
     }
+    bd += db + __shfl_xor(db, 1, 64);
+    const float lt_motor = RV_WHEEL_EFFORT * h / RV_WHEEL_CONTACT_RADIUS;
+    for (int it = 0; it < p.cfg.solver_iterations; ++it) {
+        wheel_rows(ct, v, w, bd, inv_m, inv_I, b_winv, mu, lt_motor, g.wqd, dv, dw, db);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            v[i] += group_sum8(act ? dv[i] : 0.0f);
+            w[i] += group_sum8(act ? dw[i] : 0.0f);
+        }
+        bd += db + __shfl_xor(db, 1, 64);
+    }
+    wheel_motor(h, g.wheel_t, ct.lt, g.wq, g.wqd);
+    g.lam = ct.ln;
+    if (RECORD_FORCE) {
+        const bool on = ct.obst > RV_OBSTACLE_EPS;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) Fw[i] = on ? (ct.n[i] * ct.ln + ct.t[i] * ct.lt + ct.s[i] * ct.ls) / h : 0.0f;
+    }
+    chassis_integrate(h, R, v, w, com_w, g.pos, g.quat, g.linvel, g.angvel);
+    bogie_integrate(h, bq, bd, g.bq, g.bqd);
 }
 
 // ------------------------------------------------------------------------------------------------ (a7, a8) reset
@@ -761,6 +924,275 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
 }
 
+// ---- per-lane constants / state of the "group" mapping
+__device__ const float d_WHEEL_B[6][3] = RV_WHEEL_B_INIT;
+__device__ const int d_WHEEL_STEER[6] = RV_WHEEL_STEER_INIT;
+__device__ const int d_WHEEL_BODY[6] = RV_WHEEL_BODY_INIT;
+__device__ const int d_SLOT_WHEEL[6] = RV_SLOT_WHEEL_INIT;
+__device__ const float d_BOGIE_PIVOT[3][3] = RV_BOGIE_PIVOT_INIT;
+__device__ const float d_BOGIE_AXIS[3][3] = RV_BOGIE_AXIS_INIT;
+__device__ const float d_BOGIE_INERTIA[3] = RV_BOGIE_INERTIA_INIT;
+
+struct GroupIds {
+    int slot, k, j, si, body;
+    bool wheel_active;
+};
+__device__ __forceinline__ GroupIds group_ids(int lane)
+{
+    GroupIds id;
+    id.slot = lane & 7;
+    id.wheel_active = id.slot < 6;
+    const int sc = id.wheel_active ? id.slot : 5;  // idle slots 6, 7 shadow slot 5 and contribute exact zeros
+    id.k = d_SLOT_WHEEL[sc];
+    id.j = sc >> 1;
+    id.si = d_WHEEL_STEER[id.k];
+    id.body = d_WHEEL_BODY[id.k];
+    return id;
+}
+__device__ __forceinline__ void group_load(const float *__restrict__ state, int N, int e, const GroupIds &id, GroupLane &g)
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g.pos[i] = state[(size_t)(ROVER_POS + i) * N + e];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g.quat[i] = state[(size_t)(ROVER_QUAT + i) * N + e];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g.linvel[i] = state[(size_t)(ROVER_LINVEL + i) * N + e];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g.angvel[i] = state[(size_t)(ROVER_ANGVEL + i) * N + e];
+    g.bq = state[(size_t)(ROVER_BOGIE_Q + id.j) * N + e];
+    g.bqd = state[(size_t)(ROVER_BOGIE_QD + id.j) * N + e];
+    const int si = id.si >= 0 ? id.si : 0;
+    g.sq = state[(size_t)(ROVER_STEER_Q + si) * N + e];
+    g.sqd = state[(size_t)(ROVER_STEER_QD + si) * N + e];
+    g.wq = state[(size_t)(ROVER_WHEEL_Q + id.k) * N + e];
+    g.wqd = state[(size_t)(ROVER_WHEEL_QD + id.k) * N + e];
+    g.lam = state[(size_t)(ROVER_LAMBDA_N + id.k) * N + e];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        g.wb[i] = d_WHEEL_B[id.k][i];
+        g.P[i] = d_BOGIE_PIVOT[id.j][i];
+        g.ax[i] = d_BOGIE_AXIS[id.j][i];
+    }
+    g.b_inertia = d_BOGIE_INERTIA[id.j];
+    g.steerable = id.si >= 0;
+    g.wheel_active = id.wheel_active;
+}
+// physical state back to HBM: chassis by slot 0, bogie j by slot 2j, steer / wheel words by their wheel's slot
+__device__ __forceinline__ void group_store(float *__restrict__ state, int N, int e, const GroupIds &id, const GroupLane &g)
+{
+    if (id.slot == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) state[(size_t)(ROVER_POS + i) * N + e] = g.pos[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) state[(size_t)(ROVER_QUAT + i) * N + e] = g.quat[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) state[(size_t)(ROVER_LINVEL + i) * N + e] = g.linvel[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) state[(size_t)(ROVER_ANGVEL + i) * N + e] = g.angvel[i];
+    }
+    if (id.wheel_active) {
+        if ((id.slot & 1) == 0) {
+            state[(size_t)(ROVER_BOGIE_Q + id.j) * N + e] = g.bq;
+            state[(size_t)(ROVER_BOGIE_QD + id.j) * N + e] = g.bqd;
+        }
+        if (id.si >= 0) {
+            state[(size_t)(ROVER_STEER_Q + id.si) * N + e] = g.sq;
+            state[(size_t)(ROVER_STEER_QD + id.si) * N + e] = g.sqd;
+        }
+        state[(size_t)(ROVER_WHEEL_Q + id.k) * N + e] = g.wq;
+        state[(size_t)(ROVER_WHEEL_QD + id.k) * N + e] = g.wqd;
+        state[(size_t)(ROVER_LAMBDA_N + id.k) * N + e] = g.lam;
+    }
+}
+
+// ================================================================================================ K1g: step, group mapping
+// Eight lanes per env (64-thread workgroup = 8 envs).  Physics: one wheel per lane (slots 0..5), chassis replicated;
+// MDP tail (terminations, rewards, reset, command): replicated in the 8 lanes, stored by slot 0.
+__global__ __launch_bounds__(64) void rover_step_kernel_group(RvParams p, float *__restrict__ state,
+                                                              const float *__restrict__ action, float *__restrict__ reward,
+                                                              uint8_t *__restrict__ terminated, uint8_t *__restrict__ truncated,
+                                                              float *__restrict__ force, float *__restrict__ log_partial)
+{
+    const int lane = threadIdx.x;
+    const int e_raw = blockIdx.x * 8 + (lane >> 3);
+    const bool active = e_raw < p.n;
+    const int e = active ? e_raw : p.n - 1;
+    const int N = p.n;
+    const rover_config &c = p.cfg;
+    const GroupIds id = group_ids(lane);
+
+    GroupLane g;
+    group_load(state, N, e, id, g);
+    // rover_env.py:62 ActionManager.process_action
+    float act[2], prev[2];
+    prev[0] = state[(size_t)(ROVER_ACTION + 0) * N + e];
+    prev[1] = state[(size_t)(ROVER_ACTION + 1) * N + e];
+    const float2 a = reinterpret_cast<const float2 *>(action)[e];
+    act[0] = a.x;
+    act[1] = a.y;
+    {
+        float processed[2], steer[4], wheel[6];
+        ackermann_one(c, act, processed, steer, wheel);
+        const float steer_m[4] = {steer[0], steer[3], steer[1], steer[2]};                      // FL, FR, RL, RR
+        const float wheel_m[6] = {wheel[1], wheel[5], wheel[0], wheel[4], wheel[2], wheel[3]};  // FL,FR,CL,CR,RL,RR
+        float st = steer_m[0], wt = wheel_m[0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) st = (id.si == i) ? steer_m[i] : st;
+#pragma unroll
+        for (int i = 1; i < 6; ++i) wt = (id.k == i) ? wheel_m[i] : wt;
+        g.steer_t = st;
+        g.wheel_t = wt;
+    }
+    // rover_env.py:64-72 decimation loop
+    float Fw[3] = {0.0f, 0.0f, 0.0f};
+    for (int s = 0; s < c.decimation - 1; ++s) physics_substep_group<false>(p, g, nullptr);
+    if (c.decimation > 0) physics_substep_group<true>(p, g, Fw);
+    if (!id.wheel_active) { Fw[0] = 0.0f; Fw[1] = 0.0f; Fw[2] = 0.0f; }
+    if (active) group_store(state, N, e, id, g);
+
+    // contact report: gather the six Drive-body forces of the env (sensor body order) into every lane
+    float F[ROVER_NUM_BODIES * 3];
+#pragma unroll
+    for (int i = 0; i < ROVER_NUM_BODIES * 3; ++i) F[i] = 0.0f;
+    {
+        constexpr int BODY_SLOT[6] = {1, 3, 0, 2, 4, 5};  // bodies 7..12 = CL, CR, FL, FR, RL, RR -> solver slot
+        const int base = lane & ~7;
+#pragma unroll
+        for (int b = 0; b < 6; ++b)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) F[(7 + b) * 3 + i] = __shfl(Fw[i], base + BODY_SLOT[b], 64);
+    }
+    if (force && active && id.wheel_active) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) force[(size_t)(id.body * 3 + i) * N + e] = Fw[i];
+    }
+
+    // ---- MDP tail on the manager words (replicated in the group)
+    float S[ROVER_STATE_WORDS];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) S[ROVER_POS + i] = g.pos[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) S[ROVER_QUAT + i] = g.quat[i];
+#pragma unroll
+    for (int i = ROVER_TARGET_W; i < ROVER_ACTION; ++i) S[i] = state[(size_t)i * N + e];
+#pragma unroll
+    for (int i = ROVER_TIME_LEFT; i < ROVER_LAMBDA_N; ++i) S[i] = state[(size_t)i * N + e];
+    S[ROVER_RESET_COUNT] = state[(size_t)ROVER_RESET_COUNT * N + e];
+    S[ROVER_ACTION] = act[0]; S[ROVER_ACTION + 1] = act[1];
+    S[ROVER_PREV_ACTION] = prev[0]; S[ROVER_PREV_ACTION + 1] = prev[1];
+    // words reset_one may clear in reset_mode 1 (stored by their owner lanes only when that happens)
+#pragma unroll
+    for (int i = ROVER_LINVEL; i < ROVER_TARGET_W; ++i) S[i] = 0.0f;
+#pragma unroll
+    for (int i = ROVER_LAMBDA_N; i < ROVER_LAMBDA_N + 6; ++i) S[i] = 0.0f;
+
+    const int ep_len = __float_as_int(S[ROVER_EP_LEN]) + 1;
+    S[ROVER_EP_LEN] = __int_as_float(ep_len);
+    float rew[ROVER_NUM_REW];
+    bool term[ROVER_NUM_TERM];
+    mdp_terms_one(c, S + ROVER_CMD_B, S + ROVER_ACTION, S + ROVER_PREV_ACTION, ep_len, F, rew, term);
+    const bool time_out = term[0];
+    const bool term_any = term[1] | term[2] | term[3];
+    const float step_dt = c.sim_dt * (float)c.decimation;
+    float total = 0.0f;
+#pragma unroll
+    for (int i = 0; i < ROVER_NUM_REW; ++i) {
+        if (c.rew_weight[i] != 0.0f) {
+            const float val = rew[i] * c.rew_weight[i] * step_dt;
+            total += val;
+            S[ROVER_EP_SUM + i] += val;
+        }
+    }
+    const bool do_reset = term_any | time_out;
+    const bool writer = active && id.slot == 0;
+    float lg[14];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) lg[i] = 0.0f;
+    if (do_reset && writer) {
+#pragma unroll
+        for (int i = 0; i < ROVER_NUM_REW; ++i) lg[i] = S[ROVER_EP_SUM + i];
+#pragma unroll
+        for (int i = 0; i < ROVER_NUM_TERM; ++i) lg[7 + i] = term[i] ? 1.0f : 0.0f;
+        lg[11] = S[ROVER_METRIC_POS];
+        lg[12] = S[ROVER_METRIC_HEAD];
+        lg[13] = 1.0f;
+    }
+    const uint32_t gid = (uint32_t)(p.env_id_offset + e);
+    if (do_reset) {
+        reset_one(p, S, gid);
+        if (active) {
+            // the reset rewrites the root pose (slot 0 stores it below), the contact cache of every wheel and, in
+            // reset_mode 1, all velocities / joint words
+            if (id.wheel_active) state[(size_t)(ROVER_LAMBDA_N + id.k) * N + e] = 0.0f;
+            if (c.reset_mode == 1) {
+                if (id.wheel_active) {
+                    state[(size_t)(ROVER_WHEEL_Q + id.k) * N + e] = 0.0f;
+                    state[(size_t)(ROVER_WHEEL_QD + id.k) * N + e] = 0.0f;
+                    if (id.si >= 0) {
+                        state[(size_t)(ROVER_STEER_Q + id.si) * N + e] = 0.0f;
+                        state[(size_t)(ROVER_STEER_QD + id.si) * N + e] = 0.0f;
+                    }
+                    if ((id.slot & 1) == 0) {
+                        state[(size_t)(ROVER_BOGIE_Q + id.j) * N + e] = 0.0f;
+                        state[(size_t)(ROVER_BOGIE_QD + id.j) * N + e] = 0.0f;
+                    }
+                }
+                if (id.slot == 0) {
+#pragma unroll
+                    for (int i = ROVER_LINVEL; i < ROVER_BOGIE_Q; ++i) state[(size_t)i * N + e] = 0.0f;
+                }
+            }
+        }
+    }
+    command_compute(p, S, gid, step_dt);
+
+#pragma unroll
+    for (int i = 0; i < 14; ++i) lg[i] = wave_sum(lg[i]);
+    if (lane < 14) {
+        float vsel = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 14; ++i) vsel = (lane == i) ? lg[i] : vsel;
+        log_partial[(size_t)blockIdx.x * ROVER_LOG_WORDS + lane] = vsel;
+    }
+    if (writer) {
+        if (do_reset) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) state[(size_t)(ROVER_POS + i) * N + e] = S[ROVER_POS + i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) state[(size_t)(ROVER_QUAT + i) * N + e] = S[ROVER_QUAT + i];
+        }
+#pragma unroll
+        for (int i = ROVER_TARGET_W; i < ROVER_LAMBDA_N; ++i) state[(size_t)i * N + e] = S[i];
+        state[(size_t)ROVER_RESET_COUNT * N + e] = S[ROVER_RESET_COUNT];
+        reward[e] = total;
+        terminated[e] = term_any ? 1 : 0;
+        truncated[e] = time_out ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(64) void rover_physics_kernel_group(RvParams p, float *__restrict__ state, const float *steer_t,
+                                                                 const float *wheel_t, int substeps, float *force)
+{
+    const int lane = threadIdx.x;
+    const int e_raw = blockIdx.x * 8 + (lane >> 3);
+    const bool active = e_raw < p.n;
+    const int e = active ? e_raw : p.n - 1;
+    const int N = p.n;
+    const GroupIds id = group_ids(lane);
+    GroupLane g;
+    group_load(state, N, e, id, g);
+    g.steer_t = steer_t[4 * e + (id.si >= 0 ? id.si : 0)];
+    g.wheel_t = wheel_t[6 * e + id.k];
+    float Fw[3] = {0.0f, 0.0f, 0.0f};
+    for (int s = 0; s < substeps - 1; ++s) physics_substep_group<false>(p, g, nullptr);
+    if (substeps > 0) physics_substep_group<true>(p, g, Fw);
+    if (active) group_store(state, N, e, id, g);
+    if (force && active && id.wheel_active) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) force[(size_t)(id.body * 3 + i) * N + e] = Fw[i];
+    }
+}
+
 // reset of every env (env.reset()): reset_one + _update_command, no physics
 __global__ __launch_bounds__(64) void rover_reset_kernel(RvParams p, float *__restrict__ state)
 {
@@ -821,6 +1253,12 @@ __global__ __launch_bounds__(256) void rover_scan_obs_kernel(RvParams p, const f
     }
     const int e = blockIdx.x;
     const rover_config &c = p.cfg;
+    // LDS carve: [0, 64) ray x offsets, [64, 128) ray y offsets, [128, ...) terrain tile (16-B aligned)
+    float *ox_tab = lds, *oy_tab = lds + 64, *tile = lds + 128;
+    // ORBIT grid_pattern: arange(-size/2, size/2 + 1e-9, res) evaluated in double, x fastest (App. C)
+    if (tid < c.scan_nx) ox_tab[tid] = (float)(-0.5 * (double)c.scan_size_x + (double)c.scan_resolution * (double)tid);
+    if (tid >= 64 && tid < 64 + c.scan_ny)
+        oy_tab[tid - 64] = (float)(-0.5 * (double)c.scan_size_y + (double)c.scan_resolution * (double)(tid - 64));
     const float px = state[(size_t)(ROVER_POS + 0) * N + e];
     const float py = state[(size_t)(ROVER_POS + 1) * N + e];
     const float pz = state[(size_t)(ROVER_POS + 2) * N + e];
@@ -835,7 +1273,8 @@ __global__ __launch_bounds__(256) void rover_scan_obs_kernel(RvParams p, const f
     const float cy = a * inv, sy = b * inv;
     const float inv_res = 1.0f / p.res;
 
-    // window of the heightfield covered by the rotated pattern (+ 2 cells of slack), clamped to the map
+    // window of the heightfield covered by the rotated pattern (+ slack), clamped to the map; the left edge is
+    // aligned down to a multiple of 4 cells so that every row can be staged with 16-byte loads
     const float hx = 0.5f * c.scan_size_x, hy = 0.5f * c.scan_size_y;
     const float ex = fabsf(cy) * hx + fabsf(sy) * hy, ey = fabsf(sy) * hx + fabsf(cy) * hy;
     int j_lo = (int)floorf((px - ex - p.min_x) * inv_res) - 1;
@@ -844,24 +1283,43 @@ __global__ __launch_bounds__(256) void rover_scan_obs_kernel(RvParams p, const f
     int i_hi = (int)floorf((py + ey - p.min_y) * inv_res) + 2;
     j_lo = max(0, min(j_lo, p.W - 1)); j_hi = max(0, min(j_hi, p.W - 1));
     i_lo = max(0, min(i_lo, p.H - 1)); i_hi = max(0, min(i_hi, p.H - 1));
-    const int td = p.tile_dim;
-    const int tw = min(j_hi - j_lo + 1, td), th = min(i_hi - i_lo + 1, td);
-    const int pitch = td + 1;
-    // stage the window: consecutive lanes read consecutive cells of a row (coalesced 4-B loads)
-    for (int idx = tid; idx < th * tw; idx += 256) {
-        const int r = idx / tw, cc = idx - r * tw;
-        lds[r * pitch + cc] = p.height[(size_t)(i_lo + r) * p.W + (j_lo + cc)];
+    j_lo &= ~3;
+    const int pitch = p.tile_pitch;                 // floats per LDS row, multiple of 4
+    const int th = min(i_hi - i_lo + 1, p.tile_dim);
+    int tw4 = min((j_hi - j_lo + 4) >> 2, pitch >> 2);   // float4 columns
+    const bool vec_ok = ((p.W & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.height) & 15) == 0);
+#ifndef RV_K2_ABLATE
+#define RV_K2_ABLATE 0
+#endif
+    if (RV_K2_ABLATE & 1) {
+    } else if (vec_ok) {
+        tw4 = min(tw4, (p.W - j_lo) >> 2);
+        // 8 rows x 32 float4 columns per pass: consecutive lanes read consecutive 16-B pieces of a row
+        const int tx = tid & 31, ty = tid >> 5;
+        if (tx < tw4) {
+            const float4 *src = reinterpret_cast<const float4 *>(p.height + (size_t)i_lo * p.W + j_lo) + tx;
+            float4 *dst = reinterpret_cast<float4 *>(tile) + tx;
+            const int wq = p.W >> 2, pq = pitch >> 2;
+            for (int r = ty; r < th; r += 8) dst[r * pq] = src[(size_t)r * wq];
+        }
+    } else {
+        const int tw = min(tw4 * 4, p.W - j_lo);
+        for (int r = tid >> 6; r < th; r += 4)
+            for (int cc = tid & 63; cc < tw; cc += 64) tile[r * pitch + cc] = p.height[(size_t)(i_lo + r) * p.W + (j_lo + cc)];
+        tw4 = (tw + 3) >> 2;
     }
+    const int tw = tw4 * 4;
     __syncthreads();
 
     const float x_max = p.min_x + (float)(p.W - 1) * p.res;
     const float y_max = p.min_y + (float)(p.H - 1) * p.res;
+    const float inv_nx = 1.0f / (float)c.scan_nx;
     float *row = out + (size_t)e * row_stride + col0;
-    for (int ray = tid; ray < p.rays; ray += 256) {
-        const int i = ray / c.scan_nx, j = ray - i * c.scan_nx;
-        // ORBIT grid_pattern: arange(-size/2, size/2 + 1e-9, res), x fastest (App. C)
-        const float oy = (float)(-0.5 * (double)c.scan_size_y + (double)c.scan_resolution * (double)i);
-        const float ox = (float)(-0.5 * (double)c.scan_size_x + (double)c.scan_resolution * (double)j);
+    for (int ray = tid; ray < ((RV_K2_ABLATE & 2) ? 0 : p.rays); ray += 256) {
+        const int i = (int)(((float)ray + 0.5f) * inv_nx);   // ray / scan_nx, exact for ray < 2^20
+        const int j = ray - i * c.scan_nx;
+        const float oy = oy_tab[i];
+        const float ox = ox_tab[j];
         const float x = px + (cy * ox - sy * oy);
         const float y = py + (sy * ox + cy * oy);
         float hgt;
@@ -879,7 +1337,7 @@ __global__ __launch_bounds__(256) void rover_scan_obs_kernel(RvParams p, const f
             const int jl = j0 - j_lo, il = i0 - i_lo;
             float h00, h01, h10, h11;
             if (jl >= 0 && il >= 0 && jl + 1 < tw && il + 1 < th) {
-                const float *q = lds + il * pitch + jl;
+                const float *q = tile + il * pitch + jl;
                 h00 = q[0]; h01 = q[1]; h10 = q[pitch]; h11 = q[pitch + 1];
             } else {  // outside the staged window (cannot happen with the slack above; kept for safety)
                 const float *q = p.height + (size_t)i0 * p.W + j0;
@@ -890,7 +1348,7 @@ __global__ __launch_bounds__(256) void rover_scan_obs_kernel(RvParams p, const f
             const float hx1 = h10 + fx * dx1;
             hgt = hx0 + fy * (hx1 - hx0);
         }
-        row[ray] = pz - hgt - c.scan_height_offset;  // observations.py:45
+        if (!(RV_K2_ABLATE & 4) || hgt == 12345.0f) row[ray] = pz - hgt - c.scan_height_offset;  // observations.py:45
     }
     if (WRITE_HEAD && tid == 0) {
         const float cbx = state[(size_t)(ROVER_CMD_B + 0) * N + e];
@@ -963,7 +1421,8 @@ struct rover_sim {
     float *state;
     float *log_partial;
     size_t ws_bytes;
-    int n_waves;
+    int n_waves;       // log-partial rows written by the step kernel of the selected mapping
+    bool group_mapping; // eight lanes per env
     size_t lds_bytes;
 };
 
@@ -992,7 +1451,8 @@ int rover_default_config(rover_config *c)
     c->reset_mode = 0;
     c->seed_lo = 0u; c->seed_hi = 0u;
     c->friction_mu = 0.75f;
-    c->solver_iterations = 8;
+    c->solver_iterations = 16;
+    c->step_mapping = 0;
     c->max_target_tries = 32;
     return ROVER_OK;
 }
@@ -1001,6 +1461,7 @@ int rover_create(const rover_config *cfg, int32_t num_envs, int32_t env_id_offse
 {
     if (!cfg || !out) return fail(ROVER_ERR_INVALID, "cfg/out is NULL");
     if (num_envs <= 0 || env_id_offset < 0) return fail(ROVER_ERR_INVALID, "num_envs must be > 0 and env_id_offset >= 0");
+    if (cfg->scan_nx > 64 || cfg->scan_ny > 64) return fail(ROVER_ERR_UNSUPPORTED, "scan grid larger than 64 x 64 rays");
     if (cfg->scan_nx <= 0 || cfg->scan_ny <= 0 || cfg->scan_resolution <= 0.0f || cfg->decimation < 0 ||
         cfg->solver_iterations < 0 || cfg->max_target_tries < 1 || cfg->sim_dt <= 0.0f || cfg->max_episode_length <= 0)
         return fail(ROVER_ERR_INVALID, "invalid rover_config");
@@ -1016,8 +1477,11 @@ int rover_create(const rover_config *cfg, int32_t num_envs, int32_t env_id_offse
     s->p.rays = cfg->scan_nx * cfg->scan_ny;
     s->p.obs_w = 4 + s->p.rays;
     s->device = device;
-    s->n_waves = (num_envs + 63) / 64;
-    s->ws_bytes = (size_t)s->n_waves * ROVER_LOG_WORDS * sizeof(float);
+    if (cfg->step_mapping < 0 || cfg->step_mapping > 2) { delete s; return fail(ROVER_ERR_INVALID, "step_mapping must be 0, 1 or 2"); }
+    // latency mapping (8 lanes per env) while one-env-per-lane would leave most SIMDs without a wave
+    s->group_mapping = cfg->step_mapping == 2 || (cfg->step_mapping == 0 && num_envs < 65536);
+    s->n_waves = s->group_mapping ? (num_envs + 7) / 8 : (num_envs + 63) / 64;
+    s->ws_bytes = (size_t)((num_envs + 7) / 8) * ROVER_LOG_WORDS * sizeof(float);
     *out = s;
     return ROVER_OK;
 }
@@ -1040,8 +1504,10 @@ int rover_set_terrain(rover_sim *sim, const float *height, const float *obstacle
     // LDS tile: diagonal of the ray pattern in cells + slack
     const float diag = sqrtf(p.cfg.scan_size_x * p.cfg.scan_size_x + p.cfg.scan_size_y * p.cfg.scan_size_y);
     p.tile_dim = (int)ceilf(diag / resolution) + 6;
-    sim->lds_bytes = (size_t)p.tile_dim * (p.tile_dim + 1) * sizeof(float);
-    if (sim->lds_bytes < 272 * sizeof(float)) sim->lds_bytes = 272 * sizeof(float);
+    p.tile_pitch = ((p.tile_dim + 3 + 3) & ~3) + 4;   // + 3 cells for the 4-cell alignment of the left edge, + 4 pad
+    if (p.tile_pitch > 128) return fail(ROVER_ERR_UNSUPPORTED, "ray pattern wider than 124 cells is not supported");
+    sim->lds_bytes = (128 + (size_t)p.tile_dim * p.tile_pitch) * sizeof(float);
+    if (sim->lds_bytes < 512 * sizeof(float)) sim->lds_bytes = 512 * sizeof(float);
     if (sim->lds_bytes > 64 * 1024) return fail(ROVER_ERR_UNSUPPORTED, "ray pattern too large for the LDS tile (64 KiB)");
     sim->have_terrain = true;
     return ROVER_OK;
@@ -1072,7 +1538,7 @@ int rover_reset(rover_sim *sim, float *obs, void *stream)
     if (!obs) return fail(ROVER_ERR_INVALID, "obs is NULL");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const RvParams &p = sim->p;
-    hipLaunchKernelGGL(rover_reset_kernel, dim3(sim->n_waves), dim3(64), 0, st, p, sim->state);
+    hipLaunchKernelGGL(rover_reset_kernel, dim3((p.n + 63) / 64), dim3(64), 0, st, p, sim->state);
     hipLaunchKernelGGL(rover_scan_obs_kernel<true>, dim3(p.n), dim3(256), sim->lds_bytes, st, p, sim->state, obs, p.obs_w,
                        4, (const float *)nullptr, 0, (float *)nullptr);
     HIP_TRY(hipGetLastError());
@@ -1086,8 +1552,12 @@ int rover_step(rover_sim *sim, const float *action, float *obs, float *reward, u
     if (!action || !obs || !reward || !terminated || !truncated || !log) return fail(ROVER_ERR_INVALID, "NULL buffer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const RvParams &p = sim->p;
-    hipLaunchKernelGGL(rover_step_kernel, dim3(sim->n_waves), dim3(64), 0, st, p, sim->state, action, reward, terminated,
-                       truncated, force, sim->log_partial);
+    if (sim->group_mapping)
+        hipLaunchKernelGGL(rover_step_kernel_group, dim3(sim->n_waves), dim3(64), 0, st, p, sim->state, action, reward,
+                           terminated, truncated, force, sim->log_partial);
+    else
+        hipLaunchKernelGGL(rover_step_kernel, dim3(sim->n_waves), dim3(64), 0, st, p, sim->state, action, reward, terminated,
+                           truncated, force, sim->log_partial);
     hipLaunchKernelGGL(rover_scan_obs_kernel<true>, dim3(p.n + 1), dim3(256), sim->lds_bytes, st, p, sim->state, obs,
                        p.obs_w, 4, sim->log_partial, sim->n_waves, log);
     HIP_TRY(hipGetLastError());
@@ -1107,8 +1577,12 @@ int rover_profile_step(rover_sim *sim, const float *action, float *obs, float *r
     hipEvent_t ev[3];
     for (int i = 0; i < 3; ++i) HIP_TRY(hipEventCreate(&ev[i]));
     HIP_TRY(hipEventRecord(ev[0], st));
-    hipLaunchKernelGGL(rover_step_kernel, dim3(sim->n_waves), dim3(64), 0, st, p, sim->state, action, reward, terminated,
-                       truncated, force, sim->log_partial);
+    if (sim->group_mapping)
+        hipLaunchKernelGGL(rover_step_kernel_group, dim3(sim->n_waves), dim3(64), 0, st, p, sim->state, action, reward,
+                           terminated, truncated, force, sim->log_partial);
+    else
+        hipLaunchKernelGGL(rover_step_kernel, dim3(sim->n_waves), dim3(64), 0, st, p, sim->state, action, reward, terminated,
+                           truncated, force, sim->log_partial);
     HIP_TRY(hipEventRecord(ev[1], st));
     hipLaunchKernelGGL(rover_scan_obs_kernel<true>, dim3(p.n + 1), dim3(256), sim->lds_bytes, st, p, sim->state, obs,
                        p.obs_w, 4, sim->log_partial, sim->n_waves, log);
@@ -1146,8 +1620,12 @@ int rover_physics(rover_sim *sim, const float *steer_target, const float *wheel_
 {
     if (int rc = ready(sim)) return rc;
     if (!steer_target || !wheel_target || substeps < 0) return fail(ROVER_ERR_INVALID, "bad argument");
-    hipLaunchKernelGGL(rover_physics_kernel, dim3(sim->n_waves), dim3(64), 0, static_cast<hipStream_t>(stream), sim->p,
-                       sim->state, steer_target, wheel_target, substeps, force);
+    if (sim->group_mapping)
+        hipLaunchKernelGGL(rover_physics_kernel_group, dim3((sim->p.n + 7) / 8), dim3(64), 0, static_cast<hipStream_t>(stream),
+                           sim->p, sim->state, steer_target, wheel_target, substeps, force);
+    else
+        hipLaunchKernelGGL(rover_physics_kernel, dim3((sim->p.n + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream),
+                           sim->p, sim->state, steer_target, wheel_target, substeps, force);
     HIP_TRY(hipGetLastError());
     return ROVER_OK;
 }

@@ -16,6 +16,7 @@
 #define RV_WHEEL_BOGIE_INIT {0, 1, 0, 1, 2, 2}
 #define RV_WHEEL_STEER_INIT {0, 1, -1, -1, 2, 3}   // steer order: FL, FR, RL, RR
 #define RV_WHEEL_BODY_INIT {9, 10, 7, 8, 11, 12}   // row in the 13-body contact sensor (rover_env_cfg.py:72-75)
+#define RV_SLOT_WHEEL_INIT {0, 2, 1, 3, 4, 5}      // solver slot -> wheel: FL, CL, FR, CR, RL, RR (slots 2j, 2j+1 share bogie j)
 // bogie order: FL_Boogie, FR_Boogie, R_Boogie
 #define RV_BOGIE_PIVOT_INIT {{0.1535f, 0.2225f, 0.03f}, {0.1535f, -0.2225f, 0.03f}, {-0.325f, 0.0f, 0.03f}}
 #define RV_BOGIE_AXIS_INIT {{0.0f, 1.0f, 0.0f}, {0.0f, -1.0f, 0.0f}, {1.0f, 0.0f, 0.0f}}

@@ -77,6 +77,7 @@ typedef struct {
     float friction_mu;
     int32_t solver_iterations;
     int32_t max_target_tries;
+    int32_t step_mapping;        /* GPU-side kernel mapping selector; ignored by the oracle */
 } rvo_config;
 
 typedef struct {

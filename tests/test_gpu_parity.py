@@ -103,10 +103,14 @@ def test_reset_matches_oracle(oracle):
 
 
 # ------------------------------------------------------------------------------------------------ physics
-def test_physics_substeps_match_oracle(oracle):
+MAPPINGS = ["lane", "group"]     # one env per lane | eight lanes per env: both must reproduce the oracle bit for bit
+
+
+@pytest.mark.parametrize("mapping", MAPPINGS)
+def test_physics_substeps_match_oracle(oracle, mapping):
     ter = small_procedural()
-    n = 256
-    env = make_env(n, ter)
+    n = 250
+    env = make_env(n, ter, step_mapping=mapping)
     env.reset()
     ocfg, oter = oracle_side(oracle, env)
     rng = np.random.RandomState(5)
@@ -186,11 +190,12 @@ def test_step_config1_flat_single_env(oracle):
     env.close()
 
 
+@pytest.mark.parametrize("mapping", MAPPINGS)
 @pytest.mark.parametrize("n", [64, 1000, 4096])
-def test_step_procedural_single_steps(oracle, n):
+def test_step_procedural_single_steps(oracle, n, mapping):
     """Every step compared from an identical (re-synchronised) state, resets and log included; ragged n too."""
     ter = small_procedural()
-    env = make_env(n, ter, seed=99)
+    env = make_env(n, ter, seed=99, step_mapping=mapping)
     rng = np.random.RandomState(n)
     steps = 12
     actions = rng.uniform(-1, 1, (steps, n, 2)).astype(np.float32)
@@ -199,11 +204,12 @@ def test_step_procedural_single_steps(oracle, n):
     env.close()
 
 
-def test_step_procedural_closed_loop_64(oracle):
-    """64-step closed-loop rollout (no re-synchronisation): obs / reward within 1e-3 (north_star tolerance)."""
+@pytest.mark.parametrize("mapping", MAPPINGS)
+def test_step_procedural_closed_loop_64(oracle, mapping):
+    """64-step closed-loop rollout (no re-synchronisation), resets included: bit-exact obs / reward / state."""
     ter = small_procedural()
-    n = 512
-    env = make_env(n, ter, seed=3)
+    n = 509
+    env = make_env(n, ter, seed=3, step_mapping=mapping)
     rng = np.random.RandomState(11)
     actions = rng.uniform(-1, 1, (64, n, 2)).astype(np.float32)
     actions[:, :, 0] = np.abs(actions[:, :, 0])
@@ -284,11 +290,13 @@ def test_boundary_surface():
     env.close()
 
 
-def test_timeout_truncation_and_success(oracle):
+@pytest.mark.parametrize("mapping,reset_velocities", [("lane", "reference"), ("group", "reference"), ("group", "zero"),
+                                                     ("lane", "zero")])
+def test_timeout_truncation_and_success(oracle, mapping, reset_velocities):
     """Force the time-out and the success branches (rare in random rollouts) and compare with the oracle."""
     ter = small_procedural()
     n = 64
-    env = make_env(n, ter, seed=21)
+    env = make_env(n, ter, seed=21, step_mapping=mapping, reset_velocities=reset_velocities)
     env.reset()
     ocfg, oter = oracle_side(oracle, env)
     S = state_np(env)
@@ -310,6 +318,7 @@ def test_timeout_truncation_and_success(oracle):
     # reset envs observe a zeroed last action and a fresh episode counter
     assert (obs["policy"].cpu().numpy()[:40, :2] == 0).all()
     assert (env.episode_length_buf.cpu().numpy()[:40] == 0).all()
+    assert np.array_equal(state_np(env).view(np.int32), S.view(np.int32)), "state after forced resets (bit exact)"
     env.close()
 
 
