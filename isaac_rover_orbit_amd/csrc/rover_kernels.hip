@@ -80,6 +80,7 @@ __device__ __forceinline__ void mat_tvec(const float R[3][3], const float *v, fl
     o[1] = R[0][1] * v[0] + R[1][1] * v[1] + R[2][1] * v[2];
     o[2] = R[0][2] * v[0] + R[1][2] * v[1] + R[2][2] * v[2];
 }
+__device__ __forceinline__ float wdot3x(const float *a, const float *b, const float *w) { return a[0] * b[0] * w[0] + a[1] * b[1] * w[1] + a[2] * b[2] * w[2]; }
 __device__ __forceinline__ float wdot3(const float *a, const float *w) { return a[0] * a[0] * w[0] + a[1] * a[1] * w[1] + a[2] * a[2] * w[2]; }
 
 
@@ -317,6 +318,7 @@ struct Contact {
     float jn_a[3], jt_a[3], js_a[3];  // angular Jacobians R^T (r x dir), in the BODY frame (diagonal inertia)
     float jn_b, jt_b, js_b;
     float mn, mt, ms;
+    float a_nt, a_ns, a_ts;  // split-mass coupling between the wheel's own rows
     float bias;
     float ln, lt, ls;
     float obst;
@@ -427,6 +429,9 @@ __device__ __forceinline__ void wheel_geometry(const RvParams &p, const float R[
     ct.mn = 1.0f / (RV_SPLIT_C * inv_m + RV_SPLIT_C * wdot3(ct.jn_a, inv_I) + RV_SPLIT_B * (ct.jn_b * ct.jn_b * b_winv));
     ct.mt = 1.0f / (RV_SPLIT_C * inv_m + RV_SPLIT_C * wdot3(ct.jt_a, inv_I) + RV_SPLIT_B * (ct.jt_b * ct.jt_b * b_winv));
     ct.ms = 1.0f / (RV_SPLIT_C * inv_m + RV_SPLIT_C * wdot3(ct.js_a, inv_I) + RV_SPLIT_B * (ct.js_b * ct.js_b * b_winv));
+    ct.a_nt = RV_SPLIT_C * wdot3x(ct.jn_a, ct.jt_a, inv_I) + RV_SPLIT_B * (ct.jn_b * ct.jt_b * b_winv);
+    ct.a_ns = RV_SPLIT_C * wdot3x(ct.jn_a, ct.js_a, inv_I) + RV_SPLIT_B * (ct.jn_b * ct.js_b * b_winv);
+    ct.a_ts = RV_SPLIT_C * wdot3x(ct.jt_a, ct.js_a, inv_I) + RV_SPLIT_B * (ct.jt_b * ct.js_b * b_winv);
 }
 
 // warm-start contribution of one wheel
@@ -438,58 +443,38 @@ __device__ __forceinline__ void wheel_warm(const Contact &ct, float inv_m, const
     db = ct.jn_b * b_winv * ct.ln;
 }
 
-// the three rows of one wheel against a snapshot (v, w, bogie rate) of the shared velocities; returns its velocity
-// contributions with the TRUE masses (dv, dw, db); the local copies advance with the split masses
+// the three rows of one wheel against a snapshot (v, w, bogie rate) of the shared velocities: Gauss-Seidel inside the
+// wheel through the split-mass coupling terms, velocity contributions (dv, dw, db) with the TRUE masses.
+// Explicit fused multiply-adds; oracle/rover_oracle.c evaluates the identical sequence.
 __device__ __forceinline__ void wheel_rows(Contact &ct, const float *v, const float *w, float bdj, float inv_m,
                                            const float *inv_I, float b_winv, float mu, float lt_motor, float wheel_w,
                                            float *dv, float *dw, float &db)
 {
-    float vl[3] = {v[0], v[1], v[2]}, wl[3] = {w[0], w[1], w[2]}, bl = bdj;
-    {
-        const float vrel = dot3(ct.n, vl) + dot3(ct.jn_a, wl) + ct.jn_b * bl;
-        float ln = ct.ln - (vrel - ct.bias) * ct.mn;
-        if (ln < 0.0f) ln = 0.0f;
-        const float d = ln - ct.ln;
-        ct.ln = ln;
+    const float un = fmaf(ct.jn_b, bdj, fmaf(ct.n[2], v[2], fmaf(ct.n[1], v[1], ct.n[0] * v[0])) +
+                                            fmaf(ct.jn_a[2], w[2], fmaf(ct.jn_a[1], w[1], ct.jn_a[0] * w[0])));
+    const float ut = fmaf(ct.jt_b, bdj, fmaf(ct.t[2], v[2], fmaf(ct.t[1], v[1], ct.t[0] * v[0])) +
+                                            fmaf(ct.jt_a[2], w[2], fmaf(ct.jt_a[1], w[1], ct.jt_a[0] * w[0]))) -
+                     RV_WHEEL_CONTACT_RADIUS * wheel_w;  // rim speed prescribed by the (stiff) wheel motor
+    const float us = fmaf(ct.js_b, bdj, fmaf(ct.s[2], v[2], fmaf(ct.s[1], v[1], ct.s[0] * v[0])) +
+                                            fmaf(ct.js_a[2], w[2], fmaf(ct.js_a[1], w[1], ct.js_a[0] * w[0])));
+    float ln = fmaf(ct.bias - un, ct.mn, ct.ln);
+    if (ln < 0.0f) ln = 0.0f;
+    const float dn = ln - ct.ln;
+    ct.ln = ln;
+    const float lim = mu * ln;
+    const float lmax = lim < lt_motor ? lim : lt_motor;
+    const float lt = clampf(fmaf(-fmaf(ct.a_nt, dn, ut), ct.mt, ct.lt), -lmax, lmax);
+    const float dt = lt - ct.lt;
+    ct.lt = lt;
+    const float ls = clampf(fmaf(-fmaf(ct.a_ts, dt, fmaf(ct.a_ns, dn, us)), ct.ms, ct.ls), -lim, lim);
+    const float ds = ls - ct.ls;
+    ct.ls = ls;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const float a = ct.n[i] * (d * inv_m), b = ct.jn_a[i] * (inv_I[i] * d);
-            dv[i] = a; dw[i] = b;
-            vl[i] += RV_SPLIT_C * a; wl[i] += RV_SPLIT_C * b;
-        }
-        const float e = ct.jn_b * b_winv * d;
-        db = e;
-        bl += RV_SPLIT_B * e;
+    for (int i = 0; i < 3; ++i) {
+        dv[i] = fmaf(ct.s[i], ds, fmaf(ct.t[i], dt, ct.n[i] * dn)) * inv_m;
+        dw[i] = fmaf(ct.js_a[i], ds, fmaf(ct.jt_a[i], dt, ct.jn_a[i] * dn)) * inv_I[i];
     }
-    const float lim = mu * ct.ln;
-    {   // longitudinal: the rim speed R_W * omega is prescribed by the (stiff) wheel motor
-        const float vrel = dot3(ct.t, vl) + dot3(ct.jt_a, wl) + ct.jt_b * bl - RV_WHEEL_CONTACT_RADIUS * wheel_w;
-        const float lmax = lim < lt_motor ? lim : lt_motor;
-        const float lt = clampf(ct.lt - vrel * ct.mt, -lmax, lmax);
-        const float d = lt - ct.lt;
-        ct.lt = lt;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const float a = ct.t[i] * (d * inv_m), b = ct.jt_a[i] * (inv_I[i] * d);
-            dv[i] += a; dw[i] += b;
-            vl[i] += RV_SPLIT_C * a; wl[i] += RV_SPLIT_C * b;
-        }
-        const float e = ct.jt_b * b_winv * d;
-        db += e;
-        bl += RV_SPLIT_B * e;
-    }
-    {   // lateral
-        const float vrel = dot3(ct.s, vl) + dot3(ct.js_a, wl) + ct.js_b * bl;
-        const float ls = clampf(ct.ls - vrel * ct.ms, -lim, lim);
-        const float d = ls - ct.ls;
-        ct.ls = ls;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            dv[i] += ct.s[i] * (d * inv_m);
-            dw[i] += ct.js_a[i] * (inv_I[i] * d);
-        }
-        db += ct.js_b * b_winv * d;
-    }
+    db = fmaf(ct.js_b, ds, fmaf(ct.jt_b, dt, ct.jn_b * dn)) * b_winv;
 }
 
 // chassis integration shared by both mappings: velocity cap, symplectic Euler, quaternion update
@@ -650,11 +635,16 @@ struct GroupLane {
     bool steerable, wheel_active;
 };
 
+// cross-lane moves inside an 8-lane group as DPP operands (no LDS traffic): quad_perm [1,0,3,2] / [2,3,0,1] = xor 1 / 2,
+// row_half_mirror = lane i <-> 7 - i inside each group of 8
+__device__ __forceinline__ float dpp_xor1(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true)); }
+__device__ __forceinline__ float dpp_xor2(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true)); }
+__device__ __forceinline__ float dpp_half_mirror(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true)); }
 __device__ __forceinline__ float group_sum8(float x)  // ((s0+s1)+(s2+s3)) + ((s4+s5)+(s6+s7)), same value in all 8 lanes
 {
-    x += __shfl_xor(x, 1, 64);
-    x += __shfl_xor(x, 2, 64);
-    x += __shfl_xor(x, 4, 64);
+    x += dpp_xor1(x);
+    x += dpp_xor2(x);
+    x += dpp_half_mirror(x);  // lanes 0-3 hold the left half-sum, 4-7 the right one; addition commutes
     return x;
 }
 
@@ -695,7 +685,7 @@ __device__ __forceinline__ void physics_substep_group(const RvParams &p, GroupLa
         v[i] += group_sum8(act ? dv[i] : 0.0f);
         w[i] += group_sum8(act ? dw[i] : 0.0f);
     }
-    bd += db + __shfl_xor(db, 1, 64);
+    bd += db + dpp_xor1(db);
     const float lt_motor = RV_WHEEL_EFFORT * h / RV_WHEEL_CONTACT_RADIUS;
     for (int it = 0; it < p.cfg.solver_iterations; ++it) {
         wheel_rows(ct, v, w, bd, inv_m, inv_I, b_winv, mu, lt_motor, g.wqd, dv, dw, db);
@@ -704,7 +694,7 @@ __device__ __forceinline__ void physics_substep_group(const RvParams &p, GroupLa
             v[i] += group_sum8(act ? dv[i] : 0.0f);
             w[i] += group_sum8(act ? dw[i] : 0.0f);
         }
-        bd += db + __shfl_xor(db, 1, 64);
+        bd += db + dpp_xor1(db);
     }
     wheel_motor(h, g.wheel_t, ct.lt, g.wq, g.wqd);
     g.lam = ct.ln;
