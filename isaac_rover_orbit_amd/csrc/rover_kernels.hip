@@ -328,17 +328,66 @@ struct Contact {
 #define RV_SPLIT_B 2.0f  // contacts sharing one bogie
 #define RV_TREE6(a, b, c, d, e, f) ((((a) + (b)) + ((c) + (d))) + (((e) + (f)) + (0.0f + 0.0f)))
 
+// fused-multiply-add forms of the small vector helpers (physics only; the oracle uses the identical sequences)
+__device__ __forceinline__ float dot3f(const float *a, const float *b) { return fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0])); }
+__device__ __forceinline__ void cross3f(const float *a, const float *b, float *o)
+{
+    o[0] = fmaf(a[1], b[2], -(a[2] * b[1]));
+    o[1] = fmaf(a[2], b[0], -(a[0] * b[2]));
+    o[2] = fmaf(a[0], b[1], -(a[1] * b[0]));
+}
+__device__ __forceinline__ void mat_vecf(const float R[3][3], const float *v, float *o)
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[i] = fmaf(R[i][2], v[2], fmaf(R[i][1], v[1], R[i][0] * v[0]));
+}
+__device__ __forceinline__ void mat_tvecf(const float R[3][3], const float *v, float *o)  // o = R^T v
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[i] = fmaf(R[2][i], v[2], fmaf(R[1][i], v[1], R[0][i] * v[0]));
+}
+
+// quantities that depend only on the physics time step (hoisted reciprocals: one division each, then products)
+struct StepConsts {
+    float h, inv_h, inv_m, inv_I[3];
+    float steer_hkp, steer_den_inv, steer_i_over_h, steer_dv_max;
+    float wheel_den_inv, wheel_h_over_i, lt_motor;
+    float bogie_keep[3], b_winv[3];
+};
+__device__ __forceinline__ void make_step_consts(float h, StepConsts &k)
+{
+    constexpr float INERTIA_B[3] = RV_INERTIA_B_INIT;
+    constexpr float BOGIE_INERTIA[3] = RV_BOGIE_INERTIA_INIT;
+    k.h = h;
+    k.inv_h = 1.0f / h;
+    k.inv_m = 1.0f / RV_M_TOTAL;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) k.inv_I[i] = 1.0f / INERTIA_B[i];
+    k.steer_hkp = h * RV_STEER_KP;
+    k.steer_den_inv = 1.0f / (RV_STEER_INERTIA + h * RV_STEER_KD + h * h * RV_STEER_KP);
+    k.steer_i_over_h = RV_STEER_INERTIA / h;
+    k.steer_dv_max = RV_STEER_EFFORT * h / RV_STEER_INERTIA;
+    k.wheel_den_inv = 1.0f / (RV_WHEEL_INERTIA + h * RV_WHEEL_KD + h * h * RV_WHEEL_KP);
+    k.wheel_h_over_i = h / RV_WHEEL_INERTIA;
+    k.lt_motor = RV_WHEEL_EFFORT * h / RV_WHEEL_CONTACT_RADIUS;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        k.bogie_keep[j] = 1.0f / (1.0f + h * RV_BOGIE_DAMPING / BOGIE_INERTIA[j]);
+        k.b_winv[j] = 1.0f / BOGIE_INERTIA[j];
+    }
+}
+
 // implicit-PD steering joint (kp 8000, kd 1000, effort 12, rate 6; aau_rover_simple.py:43-49)
-__device__ __forceinline__ void steer_joint(float h, float target, float &q, float &qd)
+__device__ __forceinline__ void steer_joint(const StepConsts &k, float target, float &q, float &qd)
 {
     const float q0 = q, qd0 = qd;
     const float e = target - q0;
-    float v = (RV_STEER_INERTIA * qd0 + h * RV_STEER_KP * e) / (RV_STEER_INERTIA + h * RV_STEER_KD + h * h * RV_STEER_KP);
-    const float tau = (v - qd0) * RV_STEER_INERTIA / h;
-    if (tau > RV_STEER_EFFORT) v = qd0 + RV_STEER_EFFORT * h / RV_STEER_INERTIA;
-    if (tau < -RV_STEER_EFFORT) v = qd0 - RV_STEER_EFFORT * h / RV_STEER_INERTIA;
+    float v = fmaf(k.steer_hkp, e, RV_STEER_INERTIA * qd0) * k.steer_den_inv;
+    const float tau = (v - qd0) * k.steer_i_over_h;
+    if (tau > RV_STEER_EFFORT) v = qd0 + k.steer_dv_max;
+    if (tau < -RV_STEER_EFFORT) v = qd0 - k.steer_dv_max;
     v = clampf(v, -RV_STEER_VLIM, RV_STEER_VLIM);
-    float x = q0 + h * v;
+    float x = fmaf(k.h, v, q0);
     if (x > RV_STEER_QLIM) { x = RV_STEER_QLIM; v = 0.0f; }
     if (x < -RV_STEER_QLIM) { x = -RV_STEER_QLIM; v = 0.0f; }
     q = x;
@@ -346,19 +395,19 @@ __device__ __forceinline__ void steer_joint(float h, float target, float &q, flo
 }
 
 // implicit-PD wheel motor about q* = 0 with velocity target (kp 100, kd 4000, effort 12, rate 6; :50-56)
-__device__ __forceinline__ void wheel_motor(float h, float target, float lt, float &q, float &qd)
+__device__ __forceinline__ void wheel_motor(const StepConsts &k, float target, float lt, float &q, float &qd)
 {
     const float q0 = q, qd0 = qd;
     const float tgt = clampf(target, -RV_WHEEL_VLIM, RV_WHEEL_VLIM);
-    const float tau_ext = -RV_WHEEL_CONTACT_RADIUS * lt / h;
-    float v = (RV_WHEEL_INERTIA * qd0 + h * (RV_WHEEL_KP * (0.0f - q0) + RV_WHEEL_KD * tgt + tau_ext)) /
-              (RV_WHEEL_INERTIA + h * RV_WHEEL_KD + h * h * RV_WHEEL_KP);
-    const float tau = RV_WHEEL_KP * (0.0f - q0 - h * v) + RV_WHEEL_KD * (tgt - v);
-    if (tau > RV_WHEEL_EFFORT) v = qd0 + h * (RV_WHEEL_EFFORT + tau_ext) / RV_WHEEL_INERTIA;
-    if (tau < -RV_WHEEL_EFFORT) v = qd0 + h * (-RV_WHEEL_EFFORT + tau_ext) / RV_WHEEL_INERTIA;
+    const float tau_ext = -RV_WHEEL_CONTACT_RADIUS * lt * k.inv_h;
+    const float drive = fmaf(RV_WHEEL_KD, tgt, tau_ext - RV_WHEEL_KP * q0);
+    float v = fmaf(k.h, drive, RV_WHEEL_INERTIA * qd0) * k.wheel_den_inv;
+    const float tau = fmaf(RV_WHEEL_KD, tgt - v, RV_WHEEL_KP * (0.0f - fmaf(k.h, v, q0)));
+    if (tau > RV_WHEEL_EFFORT) v = fmaf(RV_WHEEL_EFFORT + tau_ext, k.wheel_h_over_i, qd0);
+    if (tau < -RV_WHEEL_EFFORT) v = fmaf(-RV_WHEEL_EFFORT + tau_ext, k.wheel_h_over_i, qd0);
     v = clampf(v, -RV_WHEEL_VLIM, RV_WHEEL_VLIM);
-    float x = q0 + h * v;
-    if (x > RV_TWO_PI_F) x -= RV_TWO_PI_F;
+    float x = fmaf(k.h, v, q0);
+    if (x > RV_TWO_PI_F) x -= RV_TWO_PI_F;  // PhysX revolute joints report a wrapped position
     if (x < -RV_TWO_PI_F) x += RV_TWO_PI_F;
     q = x;
     qd = v;
@@ -366,66 +415,68 @@ __device__ __forceinline__ void wheel_motor(float h, float target, float lt, flo
 
 // contact geometry, Jacobians, split effective masses and bias of ONE wheel
 template <bool WANT_OBST>
-__device__ __forceinline__ void wheel_geometry(const RvParams &p, const float R[3][3], const float *pos, const float *com_w,
-                                               const float *wb, const float *P, const float *ax, float b_winv, float bq,
-                                               bool at_hi, bool at_lo, bool steerable, float steer_q, float inv_m,
-                                               const float *inv_I, float h, Contact &ct)
+__device__ __forceinline__ void wheel_geometry(const RvParams &p, const StepConsts &k, const float R[3][3], const float *pos,
+                                               const float *com_w, const float *wb, const float *P, const float *ax,
+                                               float b_winv, float bq, bool at_hi, bool at_lo, bool steerable, float steer_q,
+                                               Contact &ct)
 {
     const float d0[3] = {wb[0] - P[0], wb[1] - P[1], wb[2] - P[2]};
     float sb, cb;
     rv_sincosf(bq, &sb, &cb);
     float axd[3];
-    cross3(ax, d0, axd);
-    const float ad = dot3(ax, d0);
+    cross3f(ax, d0, axd);
+    const float ad = dot3f(ax, d0);
     float cen_b[3], cen_w[3], piv_w[3], ax_w[3], tmp[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) cen_b[i] = P[i] + (d0[i] * cb + axd[i] * sb + ax[i] * (ad * (1.0f - cb)));
-    mat_vec(R, cen_b, tmp);
+    for (int i = 0; i < 3; ++i) cen_b[i] = P[i] + fmaf(ax[i], ad * (1.0f - cb), fmaf(axd[i], sb, d0[i] * cb));
+    mat_vecf(R, cen_b, tmp);
 #pragma unroll
     for (int i = 0; i < 3; ++i) cen_w[i] = pos[i] + tmp[i];
-    mat_vec(R, P, tmp);
+    mat_vecf(R, P, tmp);
 #pragma unroll
     for (int i = 0; i < 3; ++i) piv_w[i] = pos[i] + tmp[i];
-    mat_vec(R, ax, ax_w);
+    mat_vecf(R, ax, ax_w);
     float hgt, gx, gy;
     ct.obst = 0.0f;
     terrain_sample<WANT_OBST>(p, cen_w[0], cen_w[1], hgt, gx, gy, ct.obst);
-    const float inv = 1.0f / sqrtf(gx * gx + gy * gy + 1.0f);
+    const float inv = 1.0f / sqrtf(fmaf(gx, gx, fmaf(gy, gy, 1.0f)));
     ct.n[0] = -gx * inv; ct.n[1] = -gy * inv; ct.n[2] = inv;
-    const float gap = (cen_w[2] - hgt) * ct.n[2] - RV_WHEEL_CONTACT_RADIUS;
+    const float gap = fmaf(cen_w[2] - hgt, ct.n[2], -RV_WHEEL_CONTACT_RADIUS);
     float cp[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) cp[i] = cen_w[i] - RV_WHEEL_CONTACT_RADIUS * ct.n[i];
+    for (int i = 0; i < 3; ++i) cp[i] = fmaf(-RV_WHEEL_CONTACT_RADIUS, ct.n[i], cen_w[i]);
     float fwd_b[3] = {1.0f, 0.0f, 0.0f}, fwd[3];
     if (steerable) rv_sincosf(steer_q, &fwd_b[1], &fwd_b[0]);
-    mat_vec(R, fwd_b, fwd);
-    const float fn = dot3(fwd, ct.n);
-    float tl = 0.0f;
+    mat_vecf(R, fwd_b, fwd);
+    const float fn = dot3f(fwd, ct.n);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { ct.t[i] = fwd[i] - fn * ct.n[i]; tl += ct.t[i] * ct.t[i]; }
+    for (int i = 0; i < 3; ++i) ct.t[i] = fmaf(-fn, ct.n[i], fwd[i]);
+    const float tl = dot3f(ct.t, ct.t);
     const float tinv = 1.0f / sqrtf(tl > 1.0e-12f ? tl : 1.0e-12f);
 #pragma unroll
     for (int i = 0; i < 3; ++i) ct.t[i] *= tinv;
-    cross3(ct.n, ct.t, ct.s);
+    cross3f(ct.n, ct.t, ct.s);
     float r[3], rp[3], x[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) { r[i] = cp[i] - com_w[i]; rp[i] = cp[i] - piv_w[i]; }
-    cross3(r, ct.n, x); mat_tvec(R, x, ct.jn_a);
-    cross3(r, ct.t, x); mat_tvec(R, x, ct.jt_a);
-    cross3(r, ct.s, x); mat_tvec(R, x, ct.js_a);
-    cross3(rp, ct.n, x); ct.jn_b = dot3(ax_w, x);
-    cross3(rp, ct.t, x); ct.jt_b = dot3(ax_w, x);
-    cross3(rp, ct.s, x); ct.js_b = dot3(ax_w, x);
+    cross3f(r, ct.n, x); mat_tvecf(R, x, ct.jn_a);
+    cross3f(r, ct.t, x); mat_tvecf(R, x, ct.jt_a);
+    cross3f(r, ct.s, x); mat_tvecf(R, x, ct.js_a);
+    cross3f(rp, ct.n, x); ct.jn_b = dot3f(ax_w, x);
+    cross3f(rp, ct.t, x); ct.jt_b = dot3f(ax_w, x);
+    cross3f(rp, ct.s, x); ct.js_b = dot3f(ax_w, x);
     // unilateral lock of a bogie that sits on its +-10 deg stop
     if ((at_hi && ct.jn_b > 0.0f) || (at_lo && ct.jn_b < 0.0f)) ct.jn_b = 0.0f;
     if (at_hi || at_lo) { ct.jt_b = 0.0f; ct.js_b = 0.0f; }
     if (gap > 0.0f) {
-        ct.bias = -gap / h;  // speculative contact while separated
+        ct.bias = -gap * k.inv_h;  // speculative contact while separated
     } else {
-        const float push = RV_BAUMGARTE * (-gap) / h;
+        const float push = RV_BAUMGARTE * (-gap) * k.inv_h;
         ct.bias = push < RV_MAX_DEPENETRATION_VEL ? push : RV_MAX_DEPENETRATION_VEL;
     }
-    // mass splitting: every contact sees 1/6 of the chassis and 1/2 of its bogie
+    // mass splitting: every contact sees 1/6 of the chassis and 1/2 of its bogie; a_* couple the wheel's own rows
+    const float *inv_I = k.inv_I;
+    const float inv_m = k.inv_m;
     ct.mn = 1.0f / (RV_SPLIT_C * inv_m + RV_SPLIT_C * wdot3(ct.jn_a, inv_I) + RV_SPLIT_B * (ct.jn_b * ct.jn_b * b_winv));
     ct.mt = 1.0f / (RV_SPLIT_C * inv_m + RV_SPLIT_C * wdot3(ct.jt_a, inv_I) + RV_SPLIT_B * (ct.jt_b * ct.jt_b * b_winv));
     ct.ms = 1.0f / (RV_SPLIT_C * inv_m + RV_SPLIT_C * wdot3(ct.js_a, inv_I) + RV_SPLIT_B * (ct.js_b * ct.js_b * b_winv));
@@ -435,20 +486,18 @@ __device__ __forceinline__ void wheel_geometry(const RvParams &p, const float R[
 }
 
 // warm-start contribution of one wheel
-__device__ __forceinline__ void wheel_warm(const Contact &ct, float inv_m, const float *inv_I, float b_winv, float *dv,
-                                           float *dw, float &db)
+__device__ __forceinline__ void wheel_warm(const StepConsts &k, const Contact &ct, float b_winv, float *dv, float *dw, float &db)
 {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { dv[i] = ct.n[i] * (ct.ln * inv_m); dw[i] = ct.jn_a[i] * (inv_I[i] * ct.ln); }
+    for (int i = 0; i < 3; ++i) { dv[i] = ct.n[i] * (ct.ln * k.inv_m); dw[i] = ct.jn_a[i] * (k.inv_I[i] * ct.ln); }
     db = ct.jn_b * b_winv * ct.ln;
 }
 
 // the three rows of one wheel against a snapshot (v, w, bogie rate) of the shared velocities: Gauss-Seidel inside the
 // wheel through the split-mass coupling terms, velocity contributions (dv, dw, db) with the TRUE masses.
 // Explicit fused multiply-adds; oracle/rover_oracle.c evaluates the identical sequence.
-__device__ __forceinline__ void wheel_rows(Contact &ct, const float *v, const float *w, float bdj, float inv_m,
-                                           const float *inv_I, float b_winv, float mu, float lt_motor, float wheel_w,
-                                           float *dv, float *dw, float &db)
+__device__ __forceinline__ void wheel_rows(const StepConsts &k, Contact &ct, const float *v, const float *w, float bdj,
+                                           float b_winv, float mu, float wheel_w, float *dv, float *dw, float &db)
 {
     const float un = fmaf(ct.jn_b, bdj, fmaf(ct.n[2], v[2], fmaf(ct.n[1], v[1], ct.n[0] * v[0])) +
                                             fmaf(ct.jn_a[2], w[2], fmaf(ct.jn_a[1], w[1], ct.jn_a[0] * w[0])));
@@ -462,7 +511,7 @@ __device__ __forceinline__ void wheel_rows(Contact &ct, const float *v, const fl
     const float dn = ln - ct.ln;
     ct.ln = ln;
     const float lim = mu * ln;
-    const float lmax = lim < lt_motor ? lim : lt_motor;
+    const float lmax = lim < k.lt_motor ? lim : k.lt_motor;
     const float lt = clampf(fmaf(-fmaf(ct.a_nt, dn, ut), ct.mt, ct.lt), -lmax, lmax);
     const float dt = lt - ct.lt;
     ct.lt = lt;
@@ -471,8 +520,8 @@ __device__ __forceinline__ void wheel_rows(Contact &ct, const float *v, const fl
     ct.ls = ls;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        dv[i] = fmaf(ct.s[i], ds, fmaf(ct.t[i], dt, ct.n[i] * dn)) * inv_m;
-        dw[i] = fmaf(ct.js_a[i], ds, fmaf(ct.jt_a[i], dt, ct.jn_a[i] * dn)) * inv_I[i];
+        dv[i] = fmaf(ct.s[i], ds, fmaf(ct.t[i], dt, ct.n[i] * dn)) * k.inv_m;
+        dw[i] = fmaf(ct.js_a[i], ds, fmaf(ct.jt_a[i], dt, ct.jn_a[i] * dn)) * k.inv_I[i];
     }
     db = fmaf(ct.js_b, ds, fmaf(ct.jt_b, dt, ct.jn_b * dn)) * b_winv;
 }
@@ -482,15 +531,15 @@ __device__ __forceinline__ void chassis_integrate(float h, const float R[3][3], 
                                                   float *pos, float *quat, float *linvel, float *angvel)
 {
     constexpr float COM_B[3] = RV_COM_B_INIT;
-    const float sp = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const float sp = sqrtf(dot3f(v, v));
     if (sp > RV_MAX_LINEAR_VEL) {
         const float sc = RV_MAX_LINEAR_VEL / sp;
         v[0] *= sc; v[1] *= sc; v[2] *= sc;
     }
     float w[3];
-    mat_vec(R, wb, w);  // angular velocity back to the world frame
+    mat_vecf(R, wb, w);  // angular velocity back to the world frame
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { com_w[i] += h * v[i]; linvel[i] = v[i]; angvel[i] = w[i]; }
+    for (int i = 0; i < 3; ++i) { com_w[i] = fmaf(h, v[i], com_w[i]); linvel[i] = v[i]; angvel[i] = w[i]; }
     {
         const float qw = quat[0], qx = quat[1], qy = quat[2], qz = quat[3];
         const float hh = 0.5f * h;
@@ -503,14 +552,14 @@ __device__ __forceinline__ void chassis_integrate(float h, const float R[3][3], 
     }
     float R2[3][3], com_off[3];
     quat_to_mat(quat, R2);
-    mat_vec(R2, COM_B, com_off);
+    mat_vecf(R2, COM_B, com_off);
 #pragma unroll
     for (int i = 0; i < 3; ++i) pos[i] = com_w[i] - com_off[i];
 }
 
 __device__ __forceinline__ void bogie_integrate(float h, float bq0, float bdv, float &q_out, float &qd_out)
 {
-    float q = bq0 + h * bdv;
+    float q = fmaf(h, bdv, bq0);
     float qd = bdv;
     if (q > RV_BOGIE_QLIM) { q = RV_BOGIE_QLIM; if (qd > 0.0f) qd = 0.0f; }
     if (q < -RV_BOGIE_QLIM) { q = -RV_BOGIE_QLIM; if (qd < 0.0f) qd = 0.0f; }
@@ -520,46 +569,41 @@ __device__ __forceinline__ void bogie_integrate(float h, float bq0, float bdv, f
 
 // ---- "lane" mapping: one physics substep of one env, S = the env's state words in registers
 template <bool RECORD_FORCE>
-__device__ __forceinline__ void physics_substep(const RvParams &p, float *S, const float *steer_t, const float *wheel_t,
-                                                float *F /* 39, only if RECORD_FORCE */)
+__device__ __forceinline__ void physics_substep(const RvParams &p, const StepConsts &K, float *S, const float *steer_t,
+                                                const float *wheel_t, float *F /* 39, only if RECORD_FORCE */)
 {
     constexpr float COM_B[3] = RV_COM_B_INIT;
-    constexpr float INERTIA_B[3] = RV_INERTIA_B_INIT;
     constexpr float WHEEL_B[6][3] = RV_WHEEL_B_INIT;
     constexpr int WHEEL_STEER[6] = RV_WHEEL_STEER_INIT;
     constexpr int WHEEL_BODY[6] = RV_WHEEL_BODY_INIT;
     constexpr int SLOT_WHEEL[6] = RV_SLOT_WHEEL_INIT;
     constexpr float BOGIE_PIVOT[3][3] = RV_BOGIE_PIVOT_INIT;
     constexpr float BOGIE_AXIS[3][3] = RV_BOGIE_AXIS_INIT;
-    constexpr float BOGIE_INERTIA[3] = RV_BOGIE_INERTIA_INIT;
 
-    const float h = p.cfg.sim_dt;
+    const float h = K.h;
     const float mu = p.cfg.friction_mu;
     // ---- 1. steering joints
 #pragma unroll
-    for (int s = 0; s < 4; ++s) steer_joint(h, steer_t[s], S[ROVER_STEER_Q + s], S[ROVER_STEER_QD + s]);
+    for (int s = 0; s < 4; ++s) steer_joint(K, steer_t[s], S[ROVER_STEER_Q + s], S[ROVER_STEER_QD + s]);
     // ---- 2. chassis frame, gravity
     float R[3][3];
     quat_to_mat(S + ROVER_QUAT, R);
     float com_off[3], com_w[3];
-    mat_vec(R, COM_B, com_off);
+    mat_vecf(R, COM_B, com_off);
 #pragma unroll
     for (int i = 0; i < 3; ++i) com_w[i] = S[ROVER_POS + i] + com_off[i];
-    const float inv_I[3] = {1.0f / INERTIA_B[0], 1.0f / INERTIA_B[1], 1.0f / INERTIA_B[2]};
-    float v[3] = {S[ROVER_LINVEL], S[ROVER_LINVEL + 1], S[ROVER_LINVEL + 2] - RV_GRAVITY * h};
+    float v[3] = {S[ROVER_LINVEL], S[ROVER_LINVEL + 1], fmaf(-RV_GRAVITY, h, S[ROVER_LINVEL + 2])};
     float w[3];
-    mat_tvec(R, S + ROVER_ANGVEL, w);
-    float bd[3], bq[3], b_winv[3];
+    mat_tvecf(R, S + ROVER_ANGVEL, w);
+    float bd[3], bq[3];
     bool at_hi[3], at_lo[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         bq[j] = S[ROVER_BOGIE_Q + j];
-        bd[j] = S[ROVER_BOGIE_QD + j] / (1.0f + h * RV_BOGIE_DAMPING / BOGIE_INERTIA[j]);
-        b_winv[j] = 1.0f / BOGIE_INERTIA[j];
+        bd[j] = S[ROVER_BOGIE_QD + j] * K.bogie_keep[j];
         at_hi[j] = bq[j] >= RV_BOGIE_QLIM - 1.0e-5f;
         at_lo[j] = bq[j] <= -RV_BOGIE_QLIM + 1.0e-5f;
     }
-    const float inv_m = 1.0f / RV_M_TOTAL;
     // ---- 3. contact geometry (slot order), warm start
     Contact C[6];
     float dv[6][3], dw[6][3], db[6];
@@ -569,12 +613,12 @@ __device__ __forceinline__ void physics_substep(const RvParams &p, float *S, con
         const float wb[3] = {WHEEL_B[k][0], WHEEL_B[k][1], WHEEL_B[k][2]};
         const float P[3] = {BOGIE_PIVOT[j][0], BOGIE_PIVOT[j][1], BOGIE_PIVOT[j][2]};
         const float ax[3] = {BOGIE_AXIS[j][0], BOGIE_AXIS[j][1], BOGIE_AXIS[j][2]};
-        wheel_geometry<RECORD_FORCE>(p, R, S + ROVER_POS, com_w, wb, P, ax, b_winv[j], bq[j], at_hi[j], at_lo[j], si >= 0,
-                                     S[ROVER_STEER_Q + (si >= 0 ? si : 0)], inv_m, inv_I, h, C[s]);
+        wheel_geometry<RECORD_FORCE>(p, K, R, S + ROVER_POS, com_w, wb, P, ax, K.b_winv[j], bq[j], at_hi[j], at_lo[j], si >= 0,
+                                     S[ROVER_STEER_Q + (si >= 0 ? si : 0)], C[s]);
         C[s].ln = RV_WARM_START * S[ROVER_LAMBDA_N + k];
         C[s].lt = 0.0f;
         C[s].ls = 0.0f;
-        wheel_warm(C[s], inv_m, inv_I, b_winv[j], dv[s], dw[s], db[s]);
+        wheel_warm(K, C[s], K.b_winv[j], dv[s], dw[s], db[s]);
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -584,12 +628,11 @@ __device__ __forceinline__ void physics_substep(const RvParams &p, float *S, con
 #pragma unroll
     for (int j = 0; j < 3; ++j) bd[j] += db[2 * j] + db[2 * j + 1];
     // ---- 4. wheel-parallel projected Jacobi with mass splitting
-    const float lt_motor = RV_WHEEL_EFFORT * h / RV_WHEEL_CONTACT_RADIUS;
     for (int it = 0; it < p.cfg.solver_iterations; ++it) {
 #pragma unroll
         for (int s = 0; s < 6; ++s) {
             const int k = SLOT_WHEEL[s], j = s >> 1;
-            wheel_rows(C[s], v, w, bd[j], inv_m, inv_I, b_winv[j], mu, lt_motor, S[ROVER_WHEEL_QD + k], dv[s], dw[s], db[s]);
+            wheel_rows(K, C[s], v, w, bd[j], K.b_winv[j], mu, S[ROVER_WHEEL_QD + k], dv[s], dw[s], db[s]);
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -607,13 +650,13 @@ __device__ __forceinline__ void physics_substep(const RvParams &p, float *S, con
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
         const int k = SLOT_WHEEL[s];
-        wheel_motor(h, wheel_t[k], C[s].lt, S[ROVER_WHEEL_Q + k], S[ROVER_WHEEL_QD + k]);
+        wheel_motor(K, wheel_t[k], C[s].lt, S[ROVER_WHEEL_Q + k], S[ROVER_WHEEL_QD + k]);
         S[ROVER_LAMBDA_N + k] = C[s].ln;
         if (RECORD_FORCE) {
             if (C[s].obst > RV_OBSTACLE_EPS) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
-                    F[WHEEL_BODY[k] * 3 + i] = (C[s].n[i] * C[s].ln + C[s].t[i] * C[s].lt + C[s].s[i] * C[s].ls) / h;
+                    F[WHEEL_BODY[k] * 3 + i] = fmaf(C[s].s[i], C[s].ls, fmaf(C[s].t[i], C[s].lt, C[s].n[i] * C[s].ln)) * K.inv_h;
             }
         }
     }
@@ -631,7 +674,7 @@ struct GroupLane {
     float bq, bqd, sq, sqd, wq, wqd, lam;
     float steer_t, wheel_t;
     // constants of this lane's slot
-    float wb[3], P[3], ax[3], b_inertia;
+    float wb[3], P[3], ax[3], b_winv, bogie_keep;
     bool steerable, wheel_active;
 };
 
@@ -649,59 +692,63 @@ __device__ __forceinline__ float group_sum8(float x)  // ((s0+s1)+(s2+s3)) + ((s
 }
 
 template <bool RECORD_FORCE>
-__device__ __forceinline__ void physics_substep_group(const RvParams &p, GroupLane &g, float *Fw /* 3: this wheel's force */)
+__device__ __forceinline__ void physics_substep_group(const RvParams &p, const StepConsts &K, GroupLane &g,
+                                                      float *Fw /* 3: this wheel's force */)
 {
     constexpr float COM_B[3] = RV_COM_B_INIT;
-    constexpr float INERTIA_B[3] = RV_INERTIA_B_INIT;
-    const float h = p.cfg.sim_dt;
+    const float h = K.h;
     const float mu = p.cfg.friction_mu;
-    if (g.steerable) steer_joint(h, g.steer_t, g.sq, g.sqd);
+    if (g.steerable) steer_joint(K, g.steer_t, g.sq, g.sqd);
     float R[3][3];
     quat_to_mat(g.quat, R);
     float com_off[3], com_w[3];
-    mat_vec(R, COM_B, com_off);
+    mat_vecf(R, COM_B, com_off);
 #pragma unroll
     for (int i = 0; i < 3; ++i) com_w[i] = g.pos[i] + com_off[i];
-    const float inv_I[3] = {1.0f / INERTIA_B[0], 1.0f / INERTIA_B[1], 1.0f / INERTIA_B[2]};
-    float v[3] = {g.linvel[0], g.linvel[1], g.linvel[2] - RV_GRAVITY * h};
+    float v[3] = {g.linvel[0], g.linvel[1], fmaf(-RV_GRAVITY, h, g.linvel[2])};
     float w[3];
-    mat_tvec(R, g.angvel, w);
+    mat_tvecf(R, g.angvel, w);
     const float bq = g.bq;
-    float bd = g.bqd / (1.0f + h * RV_BOGIE_DAMPING / g.b_inertia);
-    const float b_winv = 1.0f / g.b_inertia;
+    float bd = g.bqd * g.bogie_keep;
     const bool at_hi = bq >= RV_BOGIE_QLIM - 1.0e-5f, at_lo = bq <= -RV_BOGIE_QLIM + 1.0e-5f;
-    const float inv_m = 1.0f / RV_M_TOTAL;
     Contact ct;
-    wheel_geometry<RECORD_FORCE>(p, R, g.pos, com_w, g.wb, g.P, g.ax, b_winv, bq, at_hi, at_lo, g.steerable, g.sq, inv_m, inv_I,
-                                 h, ct);
+    wheel_geometry<RECORD_FORCE>(p, K, R, g.pos, com_w, g.wb, g.P, g.ax, g.b_winv, bq, at_hi, at_lo, g.steerable, g.sq, ct);
     ct.ln = RV_WARM_START * g.lam;
     ct.lt = 0.0f;
     ct.ls = 0.0f;
+    if (!g.wheel_active) {
+        // idle slots 6, 7: zero directions, Jacobians and masses => every impulse and every contribution is exactly +0
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { ct.n[i] = 0.0f; ct.t[i] = 0.0f; ct.s[i] = 0.0f; ct.jn_a[i] = 0.0f; ct.jt_a[i] = 0.0f; ct.js_a[i] = 0.0f; }
+        ct.jn_b = 0.0f; ct.jt_b = 0.0f; ct.js_b = 0.0f;
+        ct.mn = 0.0f; ct.mt = 0.0f; ct.ms = 0.0f;
+        ct.a_nt = 0.0f; ct.a_ns = 0.0f; ct.a_ts = 0.0f;
+        ct.bias = 0.0f; ct.ln = 0.0f;
+    }
     float dv[3], dw[3], db;
-    wheel_warm(ct, inv_m, inv_I, b_winv, dv, dw, db);
-    const bool act = g.wheel_active;
+    wheel_warm(K, ct, g.b_winv, dv, dw, db);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        v[i] += group_sum8(act ? dv[i] : 0.0f);
-        w[i] += group_sum8(act ? dw[i] : 0.0f);
+        v[i] += group_sum8(dv[i]);
+        w[i] += group_sum8(dw[i]);
     }
     bd += db + dpp_xor1(db);
-    const float lt_motor = RV_WHEEL_EFFORT * h / RV_WHEEL_CONTACT_RADIUS;
+    const float wheel_w = g.wheel_active ? g.wqd : 0.0f;
     for (int it = 0; it < p.cfg.solver_iterations; ++it) {
-        wheel_rows(ct, v, w, bd, inv_m, inv_I, b_winv, mu, lt_motor, g.wqd, dv, dw, db);
+        wheel_rows(K, ct, v, w, bd, g.b_winv, mu, wheel_w, dv, dw, db);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            v[i] += group_sum8(act ? dv[i] : 0.0f);
-            w[i] += group_sum8(act ? dw[i] : 0.0f);
+            v[i] += group_sum8(dv[i]);
+            w[i] += group_sum8(dw[i]);
         }
         bd += db + dpp_xor1(db);
     }
-    wheel_motor(h, g.wheel_t, ct.lt, g.wq, g.wqd);
+    wheel_motor(K, g.wheel_t, ct.lt, g.wq, g.wqd);
     g.lam = ct.ln;
     if (RECORD_FORCE) {
         const bool on = ct.obst > RV_OBSTACLE_EPS;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) Fw[i] = on ? (ct.n[i] * ct.ln + ct.t[i] * ct.lt + ct.s[i] * ct.ls) / h : 0.0f;
+        for (int i = 0; i < 3; ++i) Fw[i] = on ? fmaf(ct.s[i], ct.ls, fmaf(ct.t[i], ct.lt, ct.n[i] * ct.ln)) * K.inv_h : 0.0f;
     }
     chassis_integrate(h, R, v, w, com_w, g.pos, g.quat, g.linvel, g.angvel);
     bogie_integrate(h, bq, bd, g.bq, g.bqd);
@@ -839,9 +886,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
     // rover_env.py:64-72 decimation loop; the contact report is the one of the last physics step
     float F[ROVER_NUM_BODIES * 3];
-    for (int s = 0; s < c.decimation - 1; ++s) physics_substep<false>(p, S, steer_m, wheel_m, nullptr);
+    StepConsts K;
+    make_step_consts(c.sim_dt, K);
+    for (int s = 0; s < c.decimation - 1; ++s) physics_substep<false>(p, K, S, steer_m, wheel_m, nullptr);
     if (c.decimation > 0) {
-        physics_substep<true>(p, S, steer_m, wheel_m, F);
+        physics_substep<true>(p, K, S, steer_m, wheel_m, F);
     } else {
 #pragma unroll
         for (int i = 0; i < ROVER_NUM_BODIES * 3; ++i) F[i] = 0.0f;
@@ -921,7 +970,6 @@ __device__ const int d_WHEEL_BODY[6] = RV_WHEEL_BODY_INIT;
 __device__ const int d_SLOT_WHEEL[6] = RV_SLOT_WHEEL_INIT;
 __device__ const float d_BOGIE_PIVOT[3][3] = RV_BOGIE_PIVOT_INIT;
 __device__ const float d_BOGIE_AXIS[3][3] = RV_BOGIE_AXIS_INIT;
-__device__ const float d_BOGIE_INERTIA[3] = RV_BOGIE_INERTIA_INIT;
 
 struct GroupIds {
     int slot, k, j, si, body;
@@ -939,7 +987,8 @@ __device__ __forceinline__ GroupIds group_ids(int lane)
     id.body = d_WHEEL_BODY[id.k];
     return id;
 }
-__device__ __forceinline__ void group_load(const float *__restrict__ state, int N, int e, const GroupIds &id, GroupLane &g)
+__device__ __forceinline__ void group_load(const float *__restrict__ state, int N, int e, const GroupIds &id,
+                                           const StepConsts &K, GroupLane &g)
 {
 #pragma unroll
     for (int i = 0; i < 3; ++i) g.pos[i] = state[(size_t)(ROVER_POS + i) * N + e];
@@ -963,7 +1012,14 @@ __device__ __forceinline__ void group_load(const float *__restrict__ state, int 
         g.P[i] = d_BOGIE_PIVOT[id.j][i];
         g.ax[i] = d_BOGIE_AXIS[id.j][i];
     }
-    g.b_inertia = d_BOGIE_INERTIA[id.j];
+    {
+        // per-lane pick of the bogie constants (same values as K.b_winv[j] / K.bogie_keep[j])
+        float bw = K.b_winv[0], bk = K.bogie_keep[0];
+#pragma unroll
+        for (int j = 1; j < 3; ++j) { bw = (id.j == j) ? K.b_winv[j] : bw; bk = (id.j == j) ? K.bogie_keep[j] : bk; }
+        g.b_winv = bw;
+        g.bogie_keep = bk;
+    }
     g.steerable = id.si >= 0;
     g.wheel_active = id.wheel_active;
 }
@@ -1011,8 +1067,10 @@ __global__ __launch_bounds__(64) void rover_step_kernel_group(RvParams p, float 
     const rover_config &c = p.cfg;
     const GroupIds id = group_ids(lane);
 
+    StepConsts K;
+    make_step_consts(c.sim_dt, K);
     GroupLane g;
-    group_load(state, N, e, id, g);
+    group_load(state, N, e, id, K, g);
     // rover_env.py:62 ActionManager.process_action
     float act[2], prev[2];
     prev[0] = state[(size_t)(ROVER_ACTION + 0) * N + e];
@@ -1035,8 +1093,8 @@ __global__ __launch_bounds__(64) void rover_step_kernel_group(RvParams p, float 
     }
     // rover_env.py:64-72 decimation loop
     float Fw[3] = {0.0f, 0.0f, 0.0f};
-    for (int s = 0; s < c.decimation - 1; ++s) physics_substep_group<false>(p, g, nullptr);
-    if (c.decimation > 0) physics_substep_group<true>(p, g, Fw);
+    for (int s = 0; s < c.decimation - 1; ++s) physics_substep_group<false>(p, K, g, nullptr);
+    if (c.decimation > 0) physics_substep_group<true>(p, K, g, Fw);
     if (!id.wheel_active) { Fw[0] = 0.0f; Fw[1] = 0.0f; Fw[2] = 0.0f; }
     if (active) group_store(state, N, e, id, g);
 
@@ -1169,13 +1227,15 @@ __global__ __launch_bounds__(64) void rover_physics_kernel_group(RvParams p, flo
     const int e = active ? e_raw : p.n - 1;
     const int N = p.n;
     const GroupIds id = group_ids(lane);
+    StepConsts K;
+    make_step_consts(p.cfg.sim_dt, K);
     GroupLane g;
-    group_load(state, N, e, id, g);
+    group_load(state, N, e, id, K, g);
     g.steer_t = steer_t[4 * e + (id.si >= 0 ? id.si : 0)];
     g.wheel_t = wheel_t[6 * e + id.k];
     float Fw[3] = {0.0f, 0.0f, 0.0f};
-    for (int s = 0; s < substeps - 1; ++s) physics_substep_group<false>(p, g, nullptr);
-    if (substeps > 0) physics_substep_group<true>(p, g, Fw);
+    for (int s = 0; s < substeps - 1; ++s) physics_substep_group<false>(p, K, g, nullptr);
+    if (substeps > 0) physics_substep_group<true>(p, K, g, Fw);
     if (active) group_store(state, N, e, id, g);
     if (force && active && id.wheel_active) {
 #pragma unroll
@@ -1203,8 +1263,11 @@ __global__ __launch_bounds__(64) void rover_reset_kernel(RvParams p, float *__re
 // One workgroup per env.  out row = out + env * row_stride; scan values start at column col0.
 // WRITE_HEAD: also write [last_action(2), distance * 0.11, heading / pi] (ObservationCfg, rover_env_cfg.py:97-123)
 // and let block `n` reduce the log partials.
+#ifndef RV_K2_THREADS
+#define RV_K2_THREADS 512   // 8 waves share one LDS tile: LDS (36.9 KB / workgroup) admits 4 workgroups = 32 waves per CU
+#endif
 template <bool WRITE_HEAD>
-__global__ __launch_bounds__(256) void rover_scan_obs_kernel(RvParams p, const float *__restrict__ state,
+__global__ __launch_bounds__(RV_K2_THREADS) void rover_scan_obs_kernel(RvParams p, const float *__restrict__ state,
                                                              float *__restrict__ out, int row_stride, int col0,
                                                              const float *__restrict__ log_partial, int n_waves,
                                                              float *__restrict__ log_out)
@@ -1214,24 +1277,25 @@ __global__ __launch_bounds__(256) void rover_scan_obs_kernel(RvParams p, const f
     const int N = p.n;
     if (WRITE_HEAD && (int)blockIdx.x == N) {
         // deterministic reduction of the per-wave log partials: 16 groups x 16 words, then a fixed-order tree
+        constexpr int GROUPS = RV_K2_THREADS / 16;
         const int word = tid & 15, grp = tid >> 4;
         float acc = 0.0f;
-        for (int w = grp; w < n_waves; w += 16) acc += log_partial[(size_t)w * ROVER_LOG_WORDS + word];
+        for (int w = grp; w < n_waves; w += GROUPS) acc += log_partial[(size_t)w * ROVER_LOG_WORDS + word];
         lds[grp * 16 + word] = acc;
         __syncthreads();
         if (tid < 16) {
             float s = 0.0f;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) s += lds[g * 16 + tid];
-            lds[256 + tid] = s;
+            for (int g = 0; g < GROUPS; ++g) s += lds[g * 16 + tid];
+            lds[RV_K2_THREADS + tid] = s;
         }
         __syncthreads();
         if (tid < 14) {
-            const float cnt = lds[256 + 13];
+            const float cnt = lds[RV_K2_THREADS + 13];
             if (tid == 13) {
                 log_out[13] = cnt;
             } else if (cnt > 0.0f) {
-                const float s = lds[256 + tid];
+                const float s = lds[RV_K2_THREADS + tid];
                 float val;
                 if (tid < ROVER_NUM_REW) val = s / cnt / p.cfg.max_episode_length_s;  // Episode Reward/<term>
                 else if (tid < 11) val = s;                                            // Episode Termination/<term>
@@ -1284,17 +1348,17 @@ __global__ __launch_bounds__(256) void rover_scan_obs_kernel(RvParams p, const f
     if (RV_K2_ABLATE & 1) {
     } else if (vec_ok) {
         tw4 = min(tw4, (p.W - j_lo) >> 2);
-        // 8 rows x 32 float4 columns per pass: consecutive lanes read consecutive 16-B pieces of a row
+        // (threads / 32) rows x 32 float4 columns per pass: consecutive lanes read consecutive 16-B pieces of a row
         const int tx = tid & 31, ty = tid >> 5;
         if (tx < tw4) {
             const float4 *src = reinterpret_cast<const float4 *>(p.height + (size_t)i_lo * p.W + j_lo) + tx;
             float4 *dst = reinterpret_cast<float4 *>(tile) + tx;
             const int wq = p.W >> 2, pq = pitch >> 2;
-            for (int r = ty; r < th; r += 8) dst[r * pq] = src[(size_t)r * wq];
+            for (int r = ty; r < th; r += RV_K2_THREADS / 32) dst[r * pq] = src[(size_t)r * wq];
         }
     } else {
         const int tw = min(tw4 * 4, p.W - j_lo);
-        for (int r = tid >> 6; r < th; r += 4)
+        for (int r = tid >> 6; r < th; r += RV_K2_THREADS / 64)
             for (int cc = tid & 63; cc < tw; cc += 64) tile[r * pitch + cc] = p.height[(size_t)(i_lo + r) * p.W + (j_lo + cc)];
         tw4 = (tw + 3) >> 2;
     }
@@ -1305,7 +1369,7 @@ __global__ __launch_bounds__(256) void rover_scan_obs_kernel(RvParams p, const f
     const float y_max = p.min_y + (float)(p.H - 1) * p.res;
     const float inv_nx = 1.0f / (float)c.scan_nx;
     float *row = out + (size_t)e * row_stride + col0;
-    for (int ray = tid; ray < ((RV_K2_ABLATE & 2) ? 0 : p.rays); ray += 256) {
+    for (int ray = tid; ray < ((RV_K2_ABLATE & 2) ? 0 : p.rays); ray += RV_K2_THREADS) {
         const int i = (int)(((float)ray + 0.5f) * inv_nx);   // ray / scan_nx, exact for ray < 2^20
         const int j = ray - i * c.scan_nx;
         const float oy = oy_tab[i];
@@ -1379,8 +1443,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     for (int k = 0; k < 6; ++k) wt[k] = wheel_t[6 * e + k];
 #pragma unroll
     for (int i = 0; i < ROVER_NUM_BODIES * 3; ++i) F[i] = 0.0f;
-    for (int s = 0; s < substeps - 1; ++s) physics_substep<false>(p, S, st, wt, nullptr);
-    if (substeps > 0) physics_substep<true>(p, S, st, wt, F);
+    StepConsts K;
+    make_step_consts(p.cfg.sim_dt, K);
+    for (int s = 0; s < substeps - 1; ++s) physics_substep<false>(p, K, S, st, wt, nullptr);
+    if (substeps > 0) physics_substep<true>(p, K, S, st, wt, F);
 #pragma unroll
     for (int i = 0; i < ROVER_STATE_WORDS; ++i) state[(size_t)i * N + e] = S[i];
     if (force) {
@@ -1497,7 +1563,7 @@ int rover_set_terrain(rover_sim *sim, const float *height, const float *obstacle
     p.tile_pitch = ((p.tile_dim + 3 + 3) & ~3) + 4;   // + 3 cells for the 4-cell alignment of the left edge, + 4 pad
     if (p.tile_pitch > 128) return fail(ROVER_ERR_UNSUPPORTED, "ray pattern wider than 124 cells is not supported");
     sim->lds_bytes = (128 + (size_t)p.tile_dim * p.tile_pitch) * sizeof(float);
-    if (sim->lds_bytes < 512 * sizeof(float)) sim->lds_bytes = 512 * sizeof(float);
+    if (sim->lds_bytes < (RV_K2_THREADS + 16) * sizeof(float)) sim->lds_bytes = (RV_K2_THREADS + 16) * sizeof(float);
     if (sim->lds_bytes > 64 * 1024) return fail(ROVER_ERR_UNSUPPORTED, "ray pattern too large for the LDS tile (64 KiB)");
     sim->have_terrain = true;
     return ROVER_OK;
@@ -1529,7 +1595,7 @@ int rover_reset(rover_sim *sim, float *obs, void *stream)
     hipStream_t st = static_cast<hipStream_t>(stream);
     const RvParams &p = sim->p;
     hipLaunchKernelGGL(rover_reset_kernel, dim3((p.n + 63) / 64), dim3(64), 0, st, p, sim->state);
-    hipLaunchKernelGGL(rover_scan_obs_kernel<true>, dim3(p.n), dim3(256), sim->lds_bytes, st, p, sim->state, obs, p.obs_w,
+    hipLaunchKernelGGL(rover_scan_obs_kernel<true>, dim3(p.n), dim3(RV_K2_THREADS), sim->lds_bytes, st, p, sim->state, obs, p.obs_w,
                        4, (const float *)nullptr, 0, (float *)nullptr);
     HIP_TRY(hipGetLastError());
     return ROVER_OK;
@@ -1548,7 +1614,7 @@ int rover_step(rover_sim *sim, const float *action, float *obs, float *reward, u
     else
         hipLaunchKernelGGL(rover_step_kernel, dim3(sim->n_waves), dim3(64), 0, st, p, sim->state, action, reward, terminated,
                            truncated, force, sim->log_partial);
-    hipLaunchKernelGGL(rover_scan_obs_kernel<true>, dim3(p.n + 1), dim3(256), sim->lds_bytes, st, p, sim->state, obs,
+    hipLaunchKernelGGL(rover_scan_obs_kernel<true>, dim3(p.n + 1), dim3(RV_K2_THREADS), sim->lds_bytes, st, p, sim->state, obs,
                        p.obs_w, 4, sim->log_partial, sim->n_waves, log);
     HIP_TRY(hipGetLastError());
     return ROVER_OK;
@@ -1574,7 +1640,7 @@ int rover_profile_step(rover_sim *sim, const float *action, float *obs, float *r
         hipLaunchKernelGGL(rover_step_kernel, dim3(sim->n_waves), dim3(64), 0, st, p, sim->state, action, reward, terminated,
                            truncated, force, sim->log_partial);
     HIP_TRY(hipEventRecord(ev[1], st));
-    hipLaunchKernelGGL(rover_scan_obs_kernel<true>, dim3(p.n + 1), dim3(256), sim->lds_bytes, st, p, sim->state, obs,
+    hipLaunchKernelGGL(rover_scan_obs_kernel<true>, dim3(p.n + 1), dim3(RV_K2_THREADS), sim->lds_bytes, st, p, sim->state, obs,
                        p.obs_w, 4, sim->log_partial, sim->n_waves, log);
     HIP_TRY(hipEventRecord(ev[2], st));
     HIP_TRY(hipEventSynchronize(ev[2]));
@@ -1599,7 +1665,7 @@ int rover_height_scan(rover_sim *sim, float *scan, void *stream)
     if (int rc = ready(sim)) return rc;
     if (!scan) return fail(ROVER_ERR_INVALID, "scan is NULL");
     const RvParams &p = sim->p;
-    hipLaunchKernelGGL(rover_scan_obs_kernel<false>, dim3(p.n), dim3(256), sim->lds_bytes, static_cast<hipStream_t>(stream), p,
+    hipLaunchKernelGGL(rover_scan_obs_kernel<false>, dim3(p.n), dim3(RV_K2_THREADS), sim->lds_bytes, static_cast<hipStream_t>(stream), p,
                        sim->state, scan, p.rays, 0, (const float *)nullptr, 0, (float *)nullptr);
     HIP_TRY(hipGetLastError());
     return ROVER_OK;

@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Dev tool (GPU box): a short, fixed workload for rocprofv3 --pmc passes: reset + 20 env steps at N=4096."""
+import os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from isaac_rover_orbit_amd import terrain as T
+from isaac_rover_orbit_amd.cfg import RoverEnvCfg
+from isaac_rover_orbit_amd.envs import RoverEnv
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+ter = T.make_procedural_terrain((2048, 2048)); ter.make_spawns(2 * n)
+cfg = RoverEnvCfg(); cfg.scene.num_envs = n; cfg.terrain.kind = "custom"
+env = RoverEnv(cfg, terrain=ter); env.reset()
+g = torch.Generator(device="cuda").manual_seed(0)
+acts = torch.rand(steps, n, 2, device="cuda", generator=g) * 2 - 1
+for k in range(steps):
+    env.step(acts[k])
+torch.cuda.synchronize()
+env.close()
