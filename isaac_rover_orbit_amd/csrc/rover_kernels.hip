@@ -42,6 +42,8 @@ struct RvParams {
     int rays, obs_w;
     int tile_dim;    // LDS tile rows (cells) for the scan kernel
     int tile_pitch;  // floats per LDS tile row (multiple of 4)
+    float *scan_desc;  // [n][8] per-env scan descriptor written by the step kernel: px, py, pz, cos(yaw), sin(yaw),
+                       // i_lo, j_lo, (th | tw4 << 16) of the terrain window (ints as raw bits)
 };
 
 // ------------------------------------------------------------------------------------------------ small helpers
@@ -839,6 +841,60 @@ __device__ __forceinline__ void command_compute(const RvParams &p, float *S, uin
                        S + ROVER_HEADING_CMD_B);
 }
 
+// observation head [last_action(2), distance * 0.11, heading / pi] (ObservationCfg, rover_env_cfg.py:97-123)
+__device__ __forceinline__ void write_obs_head(const RvParams &p, const float *S, float *__restrict__ obs, int e)
+{
+    const float cbx = S[ROVER_CMD_B], cby = S[ROVER_CMD_B + 1];
+    float *o = obs + (size_t)e * p.obs_w;
+    o[0] = S[ROVER_ACTION];
+    o[1] = S[ROVER_ACTION + 1];
+    o[2] = sqrtf(cbx * cbx + cby * cby) * p.cfg.obs_scale_distance;
+    o[3] = rv_atan2f(cby, cbx) * p.cfg.obs_scale_heading;
+}
+
+// terrain window of the yaw-rotated ray pattern: rows [i_lo, i_lo + th), 16-byte columns [j_lo / 4, j_lo / 4 + tw4)
+struct ScanWindow {
+    float px, py, pz, cy, sy;
+    int i_lo, j_lo, th, tw4;
+};
+__device__ __forceinline__ ScanWindow scan_window(const RvParams &p, const float *pos, const float *quat)
+{
+    const rover_config &c = p.cfg;
+    ScanWindow w;
+    const float qw = quat[0], qx = quat[1], qy = quat[2], qz = quat[3];
+    // yaw-only attachment (rover_env_cfg.py:81): (cos, sin)(yaw) straight from the quaternion
+    const float a = 1.0f - 2.0f * (qy * qy + qz * qz);
+    const float b = 2.0f * (qw * qz + qx * qy);
+    const float inv = 1.0f / sqrtf(a * a + b * b);
+    w.px = pos[0]; w.py = pos[1]; w.pz = pos[2];
+    w.cy = a * inv;
+    w.sy = b * inv;
+    const float inv_res = 1.0f / p.res;
+    // window covered by the rotated pattern (+ slack), clamped to the map; the left edge is aligned down to a multiple
+    // of 4 cells so that every row can be staged with 16-byte loads
+    const float hx = 0.5f * c.scan_size_x, hy = 0.5f * c.scan_size_y;
+    const float ex = fabsf(w.cy) * hx + fabsf(w.sy) * hy, ey = fabsf(w.sy) * hx + fabsf(w.cy) * hy;
+    int j_lo = (int)floorf((w.px - ex - p.min_x) * inv_res) - 1;
+    int i_lo = (int)floorf((w.py - ey - p.min_y) * inv_res) - 1;
+    int j_hi = (int)floorf((w.px + ex - p.min_x) * inv_res) + 2;
+    int i_hi = (int)floorf((w.py + ey - p.min_y) * inv_res) + 2;
+    j_lo = max(0, min(j_lo, p.W - 1)); j_hi = max(0, min(j_hi, p.W - 1));
+    i_lo = max(0, min(i_lo, p.H - 1)); i_hi = max(0, min(i_hi, p.H - 1));
+    j_lo &= ~3;
+    w.i_lo = i_lo;
+    w.j_lo = j_lo;
+    w.th = min(i_hi - i_lo + 1, p.tile_dim);
+    w.tw4 = min(min((j_hi - j_lo + 4) >> 2, p.tile_pitch >> 2), (p.W - j_lo + 3) >> 2);
+    return w;
+}
+__device__ __forceinline__ void write_scan_desc(const RvParams &p, const float *pos, const float *quat, int e)
+{
+    const ScanWindow w = scan_window(p, pos, quat);
+    float4 *d = reinterpret_cast<float4 *>(p.scan_desc + (size_t)e * 8);
+    d[0] = make_float4(w.px, w.py, w.pz, w.cy);
+    d[1] = make_float4(w.sy, __int_as_float(w.i_lo), __int_as_float(w.j_lo), __int_as_float(w.th | (w.tw4 << 16)));
+}
+
 __device__ __forceinline__ float wave_sum(float x)
 {
     // 64-lane butterfly: every lane ends with the same (order-deterministic) sum
@@ -849,9 +905,10 @@ __device__ __forceinline__ float wave_sum(float x)
 
 // ================================================================================================ K1: step kernel
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void rover_step_kernel(RvParams p, float *__restrict__ state,
-                                                        const float *__restrict__ action, float *__restrict__ reward,
-                                                        uint8_t *__restrict__ terminated, uint8_t *__restrict__ truncated,
-                                                        float *__restrict__ force, float *__restrict__ log_partial)
+                                                        const float *__restrict__ action, float *__restrict__ obs,
+                                                        float *__restrict__ reward, uint8_t *__restrict__ terminated,
+                                                        uint8_t *__restrict__ truncated, float *__restrict__ force,
+                                                        float *__restrict__ log_partial)
 {
     const int e_raw = blockIdx.x * 64 + threadIdx.x;
     const bool active = e_raw < p.n;
@@ -951,6 +1008,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
 
     if (active) {
+        write_obs_head(p, S, obs, e);
+        write_scan_desc(p, S + ROVER_POS, S + ROVER_QUAT, e);
 #pragma unroll
         for (int i = 0; i < ROVER_STATE_WORDS; ++i) state[(size_t)i * N + e] = S[i];
         reward[e] = total;
@@ -1055,9 +1114,10 @@ __device__ __forceinline__ void group_store(float *__restrict__ state, int N, in
 // Eight lanes per env (64-thread workgroup = 8 envs).  Physics: one wheel per lane (slots 0..5), chassis replicated;
 // MDP tail (terminations, rewards, reset, command): replicated in the 8 lanes, stored by slot 0.
 __global__ __launch_bounds__(64) void rover_step_kernel_group(RvParams p, float *__restrict__ state,
-                                                              const float *__restrict__ action, float *__restrict__ reward,
-                                                              uint8_t *__restrict__ terminated, uint8_t *__restrict__ truncated,
-                                                              float *__restrict__ force, float *__restrict__ log_partial)
+                                                              const float *__restrict__ action, float *__restrict__ obs,
+                                                              float *__restrict__ reward, uint8_t *__restrict__ terminated,
+                                                              uint8_t *__restrict__ truncated, float *__restrict__ force,
+                                                              float *__restrict__ log_partial)
 {
     const int lane = threadIdx.x;
     const int e_raw = blockIdx.x * 8 + (lane >> 3);
@@ -1203,6 +1263,8 @@ __global__ __launch_bounds__(64) void rover_step_kernel_group(RvParams p, float 
         log_partial[(size_t)blockIdx.x * ROVER_LOG_WORDS + lane] = vsel;
     }
     if (writer) {
+        write_obs_head(p, S, obs, e);
+        write_scan_desc(p, S + ROVER_POS, S + ROVER_QUAT, e);
         if (do_reset) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) state[(size_t)(ROVER_POS + i) * N + e] = S[ROVER_POS + i];
@@ -1261,12 +1323,14 @@ __global__ __launch_bounds__(64) void rover_reset_kernel(RvParams p, float *__re
 
 // ================================================================================================ K2: scan + obs
 // One workgroup per env.  out row = out + env * row_stride; scan values start at column col0.
-// WRITE_HEAD: also write [last_action(2), distance * 0.11, heading / pi] (ObservationCfg, rover_env_cfg.py:97-123)
-// and let block `n` reduce the log partials.
+//   MODE 0  pose from the state tensor, scan columns only                                   (rover_height_scan)
+//   MODE 1  pose from the state tensor + observation head                                   (rover_reset)
+//   MODE 2  pose + terrain window from the 32-byte descriptor the step kernel left (one scalar load), the head was
+//           written by the step kernel; the LAST workgroup reduces the log partials          (rover_step)
 #ifndef RV_K2_THREADS
 #define RV_K2_THREADS 512   // 8 waves share one LDS tile: LDS (36.9 KB / workgroup) admits 4 workgroups = 32 waves per CU
 #endif
-template <bool WRITE_HEAD>
+template <int MODE>
 __global__ __launch_bounds__(RV_K2_THREADS) void rover_scan_obs_kernel(RvParams p, const float *__restrict__ state,
                                                              float *__restrict__ out, int row_stride, int col0,
                                                              const float *__restrict__ log_partial, int n_waves,
@@ -1275,8 +1339,8 @@ __global__ __launch_bounds__(RV_K2_THREADS) void rover_scan_obs_kernel(RvParams 
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x;
     const int N = p.n;
-    if (WRITE_HEAD && (int)blockIdx.x == N) {
-        // deterministic reduction of the per-wave log partials: 16 groups x 16 words, then a fixed-order tree
+    if (MODE == 2 && (int)blockIdx.x == N) {
+        // deterministic reduction of the per-wave log partials: GROUPS x 16 words, then a fixed-order sum
         constexpr int GROUPS = RV_K2_THREADS / 16;
         const int word = tid & 15, grp = tid >> 4;
         float acc = 0.0f;
@@ -1307,47 +1371,37 @@ __global__ __launch_bounds__(RV_K2_THREADS) void rover_scan_obs_kernel(RvParams 
     }
     const int e = blockIdx.x;
     const rover_config &c = p.cfg;
+    ScanWindow w;
+    if (MODE == 2) {
+        const float4 *d = reinterpret_cast<const float4 *>(p.scan_desc + (size_t)e * 8);
+        const float4 d0 = d[0], d1 = d[1];
+        w.px = d0.x; w.py = d0.y; w.pz = d0.z; w.cy = d0.w; w.sy = d1.x;
+        w.i_lo = __float_as_int(d1.y);
+        w.j_lo = __float_as_int(d1.z);
+        const int pk = __float_as_int(d1.w);
+        w.th = pk & 0xFFFF;
+        w.tw4 = pk >> 16;
+    } else {
+        float pos[3], quat[4];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pos[i] = state[(size_t)(ROVER_POS + i) * N + e];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) quat[i] = state[(size_t)(ROVER_QUAT + i) * N + e];
+        w = scan_window(p, pos, quat);
+    }
+    const float px = w.px, py = w.py, pz = w.pz, cy = w.cy, sy = w.sy;
+    const int i_lo = w.i_lo, j_lo = w.j_lo, th = w.th;
+    int tw4 = w.tw4;
     // LDS carve: [0, 64) ray x offsets, [64, 128) ray y offsets, [128, ...) terrain tile (16-B aligned)
     float *ox_tab = lds, *oy_tab = lds + 64, *tile = lds + 128;
     // ORBIT grid_pattern: arange(-size/2, size/2 + 1e-9, res) evaluated in double, x fastest (App. C)
     if (tid < c.scan_nx) ox_tab[tid] = (float)(-0.5 * (double)c.scan_size_x + (double)c.scan_resolution * (double)tid);
     if (tid >= 64 && tid < 64 + c.scan_ny)
         oy_tab[tid - 64] = (float)(-0.5 * (double)c.scan_size_y + (double)c.scan_resolution * (double)(tid - 64));
-    const float px = state[(size_t)(ROVER_POS + 0) * N + e];
-    const float py = state[(size_t)(ROVER_POS + 1) * N + e];
-    const float pz = state[(size_t)(ROVER_POS + 2) * N + e];
-    const float qw = state[(size_t)(ROVER_QUAT + 0) * N + e];
-    const float qx = state[(size_t)(ROVER_QUAT + 1) * N + e];
-    const float qy = state[(size_t)(ROVER_QUAT + 2) * N + e];
-    const float qz = state[(size_t)(ROVER_QUAT + 3) * N + e];
-    // yaw-only attachment (rover_env_cfg.py:81): (cos, sin)(yaw) straight from the quaternion
-    const float a = 1.0f - 2.0f * (qy * qy + qz * qz);
-    const float b = 2.0f * (qw * qz + qx * qy);
-    const float inv = 1.0f / sqrtf(a * a + b * b);
-    const float cy = a * inv, sy = b * inv;
     const float inv_res = 1.0f / p.res;
-
-    // window of the heightfield covered by the rotated pattern (+ slack), clamped to the map; the left edge is
-    // aligned down to a multiple of 4 cells so that every row can be staged with 16-byte loads
-    const float hx = 0.5f * c.scan_size_x, hy = 0.5f * c.scan_size_y;
-    const float ex = fabsf(cy) * hx + fabsf(sy) * hy, ey = fabsf(sy) * hx + fabsf(cy) * hy;
-    int j_lo = (int)floorf((px - ex - p.min_x) * inv_res) - 1;
-    int i_lo = (int)floorf((py - ey - p.min_y) * inv_res) - 1;
-    int j_hi = (int)floorf((px + ex - p.min_x) * inv_res) + 2;
-    int i_hi = (int)floorf((py + ey - p.min_y) * inv_res) + 2;
-    j_lo = max(0, min(j_lo, p.W - 1)); j_hi = max(0, min(j_hi, p.W - 1));
-    i_lo = max(0, min(i_lo, p.H - 1)); i_hi = max(0, min(i_hi, p.H - 1));
-    j_lo &= ~3;
-    const int pitch = p.tile_pitch;                 // floats per LDS row, multiple of 4
-    const int th = min(i_hi - i_lo + 1, p.tile_dim);
-    int tw4 = min((j_hi - j_lo + 4) >> 2, pitch >> 2);   // float4 columns
+    const int pitch = p.tile_pitch;  // floats per LDS row, multiple of 4
     const bool vec_ok = ((p.W & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.height) & 15) == 0);
-#ifndef RV_K2_ABLATE
-#define RV_K2_ABLATE 0
-#endif
-    if (RV_K2_ABLATE & 1) {
-    } else if (vec_ok) {
-        tw4 = min(tw4, (p.W - j_lo) >> 2);
+    if (vec_ok) {
         // (threads / 32) rows x 32 float4 columns per pass: consecutive lanes read consecutive 16-B pieces of a row
         const int tx = tid & 31, ty = tid >> 5;
         if (tx < tw4) {
@@ -1360,16 +1414,15 @@ __global__ __launch_bounds__(RV_K2_THREADS) void rover_scan_obs_kernel(RvParams 
         const int tw = min(tw4 * 4, p.W - j_lo);
         for (int r = tid >> 6; r < th; r += RV_K2_THREADS / 64)
             for (int cc = tid & 63; cc < tw; cc += 64) tile[r * pitch + cc] = p.height[(size_t)(i_lo + r) * p.W + (j_lo + cc)];
-        tw4 = (tw + 3) >> 2;
     }
-    const int tw = tw4 * 4;
+    const int tw = min(tw4 * 4, p.W - j_lo);
     __syncthreads();
 
     const float x_max = p.min_x + (float)(p.W - 1) * p.res;
     const float y_max = p.min_y + (float)(p.H - 1) * p.res;
     const float inv_nx = 1.0f / (float)c.scan_nx;
     float *row = out + (size_t)e * row_stride + col0;
-    for (int ray = tid; ray < ((RV_K2_ABLATE & 2) ? 0 : p.rays); ray += RV_K2_THREADS) {
+    for (int ray = tid; ray < p.rays; ray += RV_K2_THREADS) {
         const int i = (int)(((float)ray + 0.5f) * inv_nx);   // ray / scan_nx, exact for ray < 2^20
         const int j = ray - i * c.scan_nx;
         const float oy = oy_tab[i];
@@ -1402,9 +1455,9 @@ __global__ __launch_bounds__(RV_K2_THREADS) void rover_scan_obs_kernel(RvParams 
             const float hx1 = h10 + fx * dx1;
             hgt = hx0 + fy * (hx1 - hx0);
         }
-        if (!(RV_K2_ABLATE & 4) || hgt == 12345.0f) row[ray] = pz - hgt - c.scan_height_offset;  // observations.py:45
+        row[ray] = pz - hgt - c.scan_height_offset;  // observations.py:45
     }
-    if (WRITE_HEAD && tid == 0) {
+    if (MODE == 1 && tid == 0) {
         const float cbx = state[(size_t)(ROVER_CMD_B + 0) * N + e];
         const float cby = state[(size_t)(ROVER_CMD_B + 1) * N + e];
         float *o = out + (size_t)e * row_stride;
@@ -1476,6 +1529,7 @@ struct rover_sim {
     bool have_terrain;
     float *state;
     float *log_partial;
+    size_t ws_log_floats;
     size_t ws_bytes;
     int n_waves;       // log-partial rows written by the step kernel of the selected mapping
     bool group_mapping; // eight lanes per env
@@ -1537,7 +1591,9 @@ int rover_create(const rover_config *cfg, int32_t num_envs, int32_t env_id_offse
     // latency mapping (8 lanes per env) while one-env-per-lane would leave most SIMDs without a wave
     s->group_mapping = cfg->step_mapping == 2 || (cfg->step_mapping == 0 && num_envs < 65536);
     s->n_waves = s->group_mapping ? (num_envs + 7) / 8 : (num_envs + 63) / 64;
-    s->ws_bytes = (size_t)((num_envs + 7) / 8) * ROVER_LOG_WORDS * sizeof(float);
+    // workspace: [log partials, padded to 128 B][scan descriptors: n x 32 B]
+    s->ws_log_floats = (((size_t)((num_envs + 7) / 8) * ROVER_LOG_WORDS) + 31) & ~(size_t)31;
+    s->ws_bytes = (s->ws_log_floats + (size_t)num_envs * 8) * sizeof(float);
     *out = s;
     return ROVER_OK;
 }
@@ -1575,8 +1631,10 @@ int rover_bind(rover_sim *sim, float *state, void *workspace, size_t workspace_b
 {
     if (!sim || !state || !workspace) return fail(ROVER_ERR_INVALID, "NULL argument");
     if (workspace_bytes < sim->ws_bytes) return fail(ROVER_ERR_INVALID, "workspace too small");
+    if (reinterpret_cast<uintptr_t>(workspace) & 127) return fail(ROVER_ERR_INVALID, "workspace must be 128-byte aligned");
     sim->state = state;
     sim->log_partial = static_cast<float *>(workspace);
+    sim->p.scan_desc = sim->log_partial + sim->ws_log_floats;
     return ROVER_OK;
 }
 
@@ -1595,7 +1653,7 @@ int rover_reset(rover_sim *sim, float *obs, void *stream)
     hipStream_t st = static_cast<hipStream_t>(stream);
     const RvParams &p = sim->p;
     hipLaunchKernelGGL(rover_reset_kernel, dim3((p.n + 63) / 64), dim3(64), 0, st, p, sim->state);
-    hipLaunchKernelGGL(rover_scan_obs_kernel<true>, dim3(p.n), dim3(RV_K2_THREADS), sim->lds_bytes, st, p, sim->state, obs, p.obs_w,
+    hipLaunchKernelGGL(rover_scan_obs_kernel<1>, dim3(p.n), dim3(RV_K2_THREADS), sim->lds_bytes, st, p, sim->state, obs, p.obs_w,
                        4, (const float *)nullptr, 0, (float *)nullptr);
     HIP_TRY(hipGetLastError());
     return ROVER_OK;
@@ -1609,12 +1667,12 @@ int rover_step(rover_sim *sim, const float *action, float *obs, float *reward, u
     hipStream_t st = static_cast<hipStream_t>(stream);
     const RvParams &p = sim->p;
     if (sim->group_mapping)
-        hipLaunchKernelGGL(rover_step_kernel_group, dim3(sim->n_waves), dim3(64), 0, st, p, sim->state, action, reward,
+        hipLaunchKernelGGL(rover_step_kernel_group, dim3(sim->n_waves), dim3(64), 0, st, p, sim->state, action, obs, reward,
                            terminated, truncated, force, sim->log_partial);
     else
-        hipLaunchKernelGGL(rover_step_kernel, dim3(sim->n_waves), dim3(64), 0, st, p, sim->state, action, reward, terminated,
-                           truncated, force, sim->log_partial);
-    hipLaunchKernelGGL(rover_scan_obs_kernel<true>, dim3(p.n + 1), dim3(RV_K2_THREADS), sim->lds_bytes, st, p, sim->state, obs,
+        hipLaunchKernelGGL(rover_step_kernel, dim3(sim->n_waves), dim3(64), 0, st, p, sim->state, action, obs, reward,
+                           terminated, truncated, force, sim->log_partial);
+    hipLaunchKernelGGL(rover_scan_obs_kernel<2>, dim3(p.n + 1), dim3(RV_K2_THREADS), sim->lds_bytes, st, p, sim->state, obs,
                        p.obs_w, 4, sim->log_partial, sim->n_waves, log);
     HIP_TRY(hipGetLastError());
     return ROVER_OK;
@@ -1634,13 +1692,13 @@ int rover_profile_step(rover_sim *sim, const float *action, float *obs, float *r
     for (int i = 0; i < 3; ++i) HIP_TRY(hipEventCreate(&ev[i]));
     HIP_TRY(hipEventRecord(ev[0], st));
     if (sim->group_mapping)
-        hipLaunchKernelGGL(rover_step_kernel_group, dim3(sim->n_waves), dim3(64), 0, st, p, sim->state, action, reward,
+        hipLaunchKernelGGL(rover_step_kernel_group, dim3(sim->n_waves), dim3(64), 0, st, p, sim->state, action, obs, reward,
                            terminated, truncated, force, sim->log_partial);
     else
-        hipLaunchKernelGGL(rover_step_kernel, dim3(sim->n_waves), dim3(64), 0, st, p, sim->state, action, reward, terminated,
-                           truncated, force, sim->log_partial);
+        hipLaunchKernelGGL(rover_step_kernel, dim3(sim->n_waves), dim3(64), 0, st, p, sim->state, action, obs, reward,
+                           terminated, truncated, force, sim->log_partial);
     HIP_TRY(hipEventRecord(ev[1], st));
-    hipLaunchKernelGGL(rover_scan_obs_kernel<true>, dim3(p.n + 1), dim3(RV_K2_THREADS), sim->lds_bytes, st, p, sim->state, obs,
+    hipLaunchKernelGGL(rover_scan_obs_kernel<2>, dim3(p.n + 1), dim3(RV_K2_THREADS), sim->lds_bytes, st, p, sim->state, obs,
                        p.obs_w, 4, sim->log_partial, sim->n_waves, log);
     HIP_TRY(hipEventRecord(ev[2], st));
     HIP_TRY(hipEventSynchronize(ev[2]));
@@ -1665,7 +1723,7 @@ int rover_height_scan(rover_sim *sim, float *scan, void *stream)
     if (int rc = ready(sim)) return rc;
     if (!scan) return fail(ROVER_ERR_INVALID, "scan is NULL");
     const RvParams &p = sim->p;
-    hipLaunchKernelGGL(rover_scan_obs_kernel<false>, dim3(p.n), dim3(RV_K2_THREADS), sim->lds_bytes, static_cast<hipStream_t>(stream), p,
+    hipLaunchKernelGGL(rover_scan_obs_kernel<0>, dim3(p.n), dim3(RV_K2_THREADS), sim->lds_bytes, static_cast<hipStream_t>(stream), p,
                        sim->state, scan, p.rays, 0, (const float *)nullptr, 0, (float *)nullptr);
     HIP_TRY(hipGetLastError());
     return ROVER_OK;
