@@ -44,6 +44,7 @@ struct RvParams {
     int tile_pitch;  // floats per LDS tile row (multiple of 4)
     float *scan_desc;  // [n][8] per-env scan descriptor written by the step kernel: px, py, pz, cos(yaw), sin(yaw),
                        // i_lo, j_lo, (th | tw4 << 16) of the terrain window (ints as raw bits)
+    const int *scan_slot;  // [n] env -> descriptor slot (workgroup order of the scan kernel), nullptr = identity
 };
 
 // ------------------------------------------------------------------------------------------------ small helpers
@@ -890,9 +891,10 @@ __device__ __forceinline__ ScanWindow scan_window(const RvParams &p, const float
 __device__ __forceinline__ void write_scan_desc(const RvParams &p, const float *pos, const float *quat, int e)
 {
     const ScanWindow w = scan_window(p, pos, quat);
-    float4 *d = reinterpret_cast<float4 *>(p.scan_desc + (size_t)e * 8);
+    const int slot = p.scan_slot ? p.scan_slot[e] : e;
+    float4 *d = reinterpret_cast<float4 *>(p.scan_desc + (size_t)slot * 8);
     d[0] = make_float4(w.px, w.py, w.pz, w.cy);
-    d[1] = make_float4(w.sy, __int_as_float(w.i_lo), __int_as_float(w.j_lo), __int_as_float(w.th | (w.tw4 << 16)));
+    d[1] = make_float4(w.sy, __int_as_float(w.i_lo | (e << 12)), __int_as_float(w.j_lo), __int_as_float(w.th | (w.tw4 << 16)));
 }
 
 __device__ __forceinline__ float wave_sum(float x)
@@ -1339,7 +1341,7 @@ __global__ __launch_bounds__(RV_K2_THREADS) void rover_scan_obs_kernel(RvParams 
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x;
     const int N = p.n;
-    if (MODE == 2 && (int)blockIdx.x == N) {
+    if (MODE == 2 && blockIdx.x == gridDim.x - 1) {
         // deterministic reduction of the per-wave log partials: GROUPS x 16 words, then a fixed-order sum
         constexpr int GROUPS = RV_K2_THREADS / 16;
         const int word = tid & 15, grp = tid >> 4;
@@ -1369,14 +1371,25 @@ __global__ __launch_bounds__(RV_K2_THREADS) void rover_scan_obs_kernel(RvParams 
         }
         return;
     }
-    const int e = blockIdx.x;
+    int e = blockIdx.x;
     const rover_config &c = p.cfg;
+#ifdef RV_K2_STAMP
+#define RV_STAMP(k) do { if (MODE == 0 && tid == 0) { reinterpret_cast<unsigned long long *>(const_cast<float *>(log_partial))[(size_t)e * 8 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define RV_STAMP(k) do { } while (0)
+#endif
+    RV_STAMP(0);
     ScanWindow w;
     if (MODE == 2) {
-        const float4 *d = reinterpret_cast<const float4 *>(p.scan_desc + (size_t)e * 8);
+        // workgroups b, b + 8, ... share an XCD (and its L2): XCD x walks the contiguous slots [x * chunk, (x + 1) * chunk)
+        const int chunk = (N + 7) >> 3;
+        const int slot = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+        if (slot >= N) return;
+        const float4 *d = reinterpret_cast<const float4 *>(p.scan_desc + (size_t)slot * 8);
         const float4 d0 = d[0], d1 = d[1];
         w.px = d0.x; w.py = d0.y; w.pz = d0.z; w.cy = d0.w; w.sy = d1.x;
-        w.i_lo = __float_as_int(d1.y);
+        w.i_lo = __float_as_int(d1.y) & 0xFFF;
+        e = __float_as_int(d1.y) >> 12;
         w.j_lo = __float_as_int(d1.z);
         const int pk = __float_as_int(d1.w);
         w.th = pk & 0xFFFF;
@@ -1392,6 +1405,8 @@ __global__ __launch_bounds__(RV_K2_THREADS) void rover_scan_obs_kernel(RvParams 
     const float px = w.px, py = w.py, pz = w.pz, cy = w.cy, sy = w.sy;
     const int i_lo = w.i_lo, j_lo = w.j_lo, th = w.th;
     int tw4 = w.tw4;
+    if (px == 12345.678f) return;  // keeps the pose loads ahead of the stamp in diagnostic builds (never true)
+    RV_STAMP(1);
     // LDS carve: [0, 64) ray x offsets, [64, 128) ray y offsets, [128, ...) terrain tile (16-B aligned)
     float *ox_tab = lds, *oy_tab = lds + 64, *tile = lds + 128;
     // ORBIT grid_pattern: arange(-size/2, size/2 + 1e-9, res) evaluated in double, x fastest (App. C)
@@ -1402,13 +1417,29 @@ __global__ __launch_bounds__(RV_K2_THREADS) void rover_scan_obs_kernel(RvParams 
     const int pitch = p.tile_pitch;  // floats per LDS row, multiple of 4
     const bool vec_ok = ((p.W & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.height) & 15) == 0);
     if (vec_ok) {
-        // (threads / 32) rows x 32 float4 columns per pass: consecutive lanes read consecutive 16-B pieces of a row
-        const int tx = tid & 31, ty = tid >> 5;
-        if (tx < tw4) {
-            const float4 *src = reinterpret_cast<const float4 *>(p.height + (size_t)i_lo * p.W + j_lo) + tx;
-            float4 *dst = reinterpret_cast<float4 *>(tile) + tx;
-            const int wq = p.W >> 2, pq = pitch >> 2;
-            for (int r = ty; r < th; r += RV_K2_THREADS / 32) dst[r * pq] = src[(size_t)r * wq];
+        // the window is th rows x tw4 16-byte chunks; chunk k of the row-major list goes to thread k % THREADS, so every
+        // lane of a wave moves a useful chunk and consecutive lanes read consecutive 16-B pieces of a row.  Four chunks
+        // per thread are in flight before the first LDS store waits for data (memory-level parallelism).
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f *src = reinterpret_cast<const v4f *>(p.height + (size_t)i_lo * p.W + j_lo);
+        v4f *dst = reinterpret_cast<v4f *>(tile);
+        const int wq = p.W >> 2, pq = pitch >> 2;
+        const int nchunk = th * tw4;
+        const float inv_tw4 = 1.0f / (float)tw4;
+        for (int k0 = tid; k0 < nchunk; k0 += 4 * RV_K2_THREADS) {
+            int rr[4], cc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = min(k0 + u * RV_K2_THREADS, nchunk - 1);  // clamped: every load is issued, no divergence
+                rr[u] = (int)(((float)k + 0.5f) * inv_tw4);             // k / tw4, exact for k < 2^20
+                cc[u] = k - rr[u] * tw4;
+            }
+            const v4f b0 = src[(size_t)rr[0] * wq + cc[0]], b1 = src[(size_t)rr[1] * wq + cc[1]];
+            const v4f b2 = src[(size_t)rr[2] * wq + cc[2]], b3 = src[(size_t)rr[3] * wq + cc[3]];
+            if (k0 + 0 * RV_K2_THREADS < nchunk) dst[rr[0] * pq + cc[0]] = b0;
+            if (k0 + 1 * RV_K2_THREADS < nchunk) dst[rr[1] * pq + cc[1]] = b1;
+            if (k0 + 2 * RV_K2_THREADS < nchunk) dst[rr[2] * pq + cc[2]] = b2;
+            if (k0 + 3 * RV_K2_THREADS < nchunk) dst[rr[3] * pq + cc[3]] = b3;
         }
     } else {
         const int tw = min(tw4 * 4, p.W - j_lo);
@@ -1416,13 +1447,16 @@ __global__ __launch_bounds__(RV_K2_THREADS) void rover_scan_obs_kernel(RvParams 
             for (int cc = tid & 63; cc < tw; cc += 64) tile[r * pitch + cc] = p.height[(size_t)(i_lo + r) * p.W + (j_lo + cc)];
     }
     const int tw = min(tw4 * 4, p.W - j_lo);
+    RV_STAMP(2);
     __syncthreads();
+    RV_STAMP(3);
 
     const float x_max = p.min_x + (float)(p.W - 1) * p.res;
     const float y_max = p.min_y + (float)(p.H - 1) * p.res;
     const float inv_nx = 1.0f / (float)c.scan_nx;
     float *row = out + (size_t)e * row_stride + col0;
-    for (int ray = tid; ray < p.rays; ray += RV_K2_THREADS) {
+    // one vertical ray: bilinear height of the staged tile at the yaw-rotated grid point
+    auto ray_obs = [&](int ray) -> float {
         const int i = (int)(((float)ray + 0.5f) * inv_nx);   // ray / scan_nx, exact for ray < 2^20
         const int j = ray - i * c.scan_nx;
         const float oy = oy_tab[i];
@@ -1455,8 +1489,19 @@ __global__ __launch_bounds__(RV_K2_THREADS) void rover_scan_obs_kernel(RvParams 
             const float hx1 = h10 + fx * dx1;
             hgt = hx0 + fy * (hx1 - hx0);
         }
-        row[ray] = pz - hgt - c.scan_height_offset;  // observations.py:45
+        return pz - hgt - c.scan_height_offset;  // observations.py:45
+    };
+    // two independent rays per thread first (their LDS reads overlap), then whatever is left for larger patterns
+    {
+        const int r0 = tid, r1 = tid + RV_K2_THREADS;
+        const bool v0 = r0 < p.rays, v1 = r1 < p.rays;
+        const float o0 = ray_obs(v0 ? r0 : 0);
+        const float o1 = ray_obs(v1 ? r1 : 0);
+        if (v0) row[r0] = o0;
+        if (v1) row[r1] = o1;
     }
+    for (int ray = tid + 2 * RV_K2_THREADS; ray < p.rays; ray += RV_K2_THREADS) row[ray] = ray_obs(ray);
+    RV_STAMP(4);
     if (MODE == 1 && tid == 0) {
         const float cbx = state[(size_t)(ROVER_CMD_B + 0) * N + e];
         const float cby = state[(size_t)(ROVER_CMD_B + 1) * N + e];
@@ -1672,8 +1717,8 @@ int rover_step(rover_sim *sim, const float *action, float *obs, float *reward, u
     else
         hipLaunchKernelGGL(rover_step_kernel, dim3(sim->n_waves), dim3(64), 0, st, p, sim->state, action, obs, reward,
                            terminated, truncated, force, sim->log_partial);
-    hipLaunchKernelGGL(rover_scan_obs_kernel<2>, dim3(p.n + 1), dim3(RV_K2_THREADS), sim->lds_bytes, st, p, sim->state, obs,
-                       p.obs_w, 4, sim->log_partial, sim->n_waves, log);
+    hipLaunchKernelGGL(rover_scan_obs_kernel<2>, dim3(8 * ((p.n + 7) / 8) + 1), dim3(RV_K2_THREADS), sim->lds_bytes, st, p,
+                       sim->state, obs, p.obs_w, 4, sim->log_partial, sim->n_waves, log);
     HIP_TRY(hipGetLastError());
     return ROVER_OK;
 }
@@ -1698,8 +1743,8 @@ int rover_profile_step(rover_sim *sim, const float *action, float *obs, float *r
         hipLaunchKernelGGL(rover_step_kernel, dim3(sim->n_waves), dim3(64), 0, st, p, sim->state, action, obs, reward,
                            terminated, truncated, force, sim->log_partial);
     HIP_TRY(hipEventRecord(ev[1], st));
-    hipLaunchKernelGGL(rover_scan_obs_kernel<2>, dim3(p.n + 1), dim3(RV_K2_THREADS), sim->lds_bytes, st, p, sim->state, obs,
-                       p.obs_w, 4, sim->log_partial, sim->n_waves, log);
+    hipLaunchKernelGGL(rover_scan_obs_kernel<2>, dim3(8 * ((p.n + 7) / 8) + 1), dim3(RV_K2_THREADS), sim->lds_bytes, st, p,
+                       sim->state, obs, p.obs_w, 4, sim->log_partial, sim->n_waves, log);
     HIP_TRY(hipEventRecord(ev[2], st));
     HIP_TRY(hipEventSynchronize(ev[2]));
     HIP_TRY(hipEventElapsedTime(ms_step_kernel, ev[0], ev[1]));
@@ -1726,6 +1771,22 @@ int rover_height_scan(rover_sim *sim, float *scan, void *stream)
     hipLaunchKernelGGL(rover_scan_obs_kernel<0>, dim3(p.n), dim3(RV_K2_THREADS), sim->lds_bytes, static_cast<hipStream_t>(stream), p,
                        sim->state, scan, p.rays, 0, (const float *)nullptr, 0, (float *)nullptr);
     HIP_TRY(hipGetLastError());
+    return ROVER_OK;
+}
+
+#ifdef RV_K2_STAMP
+int rover_debug_scan(rover_sim *sim, float *scan, void *stamps, void *stream)
+{
+    const RvParams &p = sim->p;
+    hipLaunchKernelGGL(rover_scan_obs_kernel<0>, dim3(p.n), dim3(RV_K2_THREADS), sim->lds_bytes, static_cast<hipStream_t>(stream), p,
+                       sim->state, scan, p.rays, 0, (const float *)stamps, 0, (float *)nullptr);
+    return ROVER_OK;
+}
+#endif
+
+int rover_debug_set_scan_slot(rover_sim *sim, const int *slot_dev)
+{
+    sim->p.scan_slot = slot_dev;
     return ROVER_OK;
 }
 
