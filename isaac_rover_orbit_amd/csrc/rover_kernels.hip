@@ -693,11 +693,55 @@ __device__ __forceinline__ float group_sum8(float x)  // ((s0+s1)+(s2+s3)) + ((s
     x += dpp_half_mirror(x);  // lanes 0-3 hold the left half-sum, 4-7 the right one; addition commutes
     return x;
 }
+// the seven per-iteration sums (dv[3], dw[3] over the 8-lane group, db over the bogie pair) as 3 x 7 fused v_add_f32_dpp:
+// hipcc would otherwise SLP-pack the adds into v_pk_add_f32, which cannot take a DPP operand (2 extra v_mov_dpp each).
+// s_nop 1 covers the VALU-write -> DPP-read hazard (2 wait states) for the first instruction of every level.
+__device__ __forceinline__ void group_sum8x6_pair(float &a0, float &a1, float &a2, float &a3, float &a4, float &a5, float &b)
+{
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %5, %5, %5 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(b));
+}
 
+#ifdef RV_K1_STAMP
+__device__ unsigned long long *g_k1_stamps;
+__device__ __forceinline__ void k1_stamp(int slot)
+{
+    if (threadIdx.x == 0) {
+        unsigned long long t;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        g_k1_stamps[(size_t)blockIdx.x * 32 + slot] = t;
+    }
+}
+#define K1_STAMP(k) k1_stamp(k)
+#else
+#define K1_STAMP(k) do { } while (0)
+#endif
 template <bool RECORD_FORCE>
 __device__ __forceinline__ void physics_substep_group(const RvParams &p, const StepConsts &K, GroupLane &g,
-                                                      float *Fw /* 3: this wheel's force */)
+                                                      float *Fw /* 3: this wheel's force */, int sidx = 0)
 {
+    K1_STAMP(2 + 3 * sidx);
     constexpr float COM_B[3] = RV_COM_B_INIT;
     const float h = K.h;
     const float mu = p.cfg.friction_mu;
@@ -716,6 +760,7 @@ __device__ __forceinline__ void physics_substep_group(const RvParams &p, const S
     const bool at_hi = bq >= RV_BOGIE_QLIM - 1.0e-5f, at_lo = bq <= -RV_BOGIE_QLIM + 1.0e-5f;
     Contact ct;
     wheel_geometry<RECORD_FORCE>(p, K, R, g.pos, com_w, g.wb, g.P, g.ax, g.b_winv, bq, at_hi, at_lo, g.steerable, g.sq, ct);
+    K1_STAMP(3 + 3 * sidx);
     ct.ln = RV_WARM_START * g.lam;
     ct.lt = 0.0f;
     ct.ls = 0.0f;
@@ -739,13 +784,15 @@ __device__ __forceinline__ void physics_substep_group(const RvParams &p, const S
     const float wheel_w = g.wheel_active ? g.wqd : 0.0f;
     for (int it = 0; it < p.cfg.solver_iterations; ++it) {
         wheel_rows(K, ct, v, w, bd, g.b_winv, mu, wheel_w, dv, dw, db);
+        group_sum8x6_pair(dv[0], dv[1], dv[2], dw[0], dw[1], dw[2], db);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            v[i] += group_sum8(dv[i]);
-            w[i] += group_sum8(dw[i]);
+            v[i] += dv[i];
+            w[i] += dw[i];
         }
-        bd += db + dpp_xor1(db);
+        bd += db;
     }
+    K1_STAMP(4 + 3 * sidx);
     wheel_motor(K, g.wheel_t, ct.lt, g.wq, g.wqd);
     g.lam = ct.ln;
     if (RECORD_FORCE) {
@@ -1128,6 +1175,7 @@ __global__ __launch_bounds__(64) void rover_step_kernel_group(RvParams p, float 
     const int N = p.n;
     const rover_config &c = p.cfg;
     const GroupIds id = group_ids(lane);
+    K1_STAMP(0);
 
     StepConsts K;
     make_step_consts(c.sim_dt, K);
@@ -1153,10 +1201,19 @@ __global__ __launch_bounds__(64) void rover_step_kernel_group(RvParams p, float 
         g.steer_t = st;
         g.wheel_t = wt;
     }
+    // manager words: issued now so that their latency hides under the physics (the group mapping has registers to spare)
+    float S[ROVER_STATE_WORDS];
+#pragma unroll
+    for (int i = ROVER_TARGET_W; i < ROVER_ACTION; ++i) S[i] = state[(size_t)i * N + e];
+#pragma unroll
+    for (int i = ROVER_TIME_LEFT; i < ROVER_LAMBDA_N; ++i) S[i] = state[(size_t)i * N + e];
+    S[ROVER_RESET_COUNT] = state[(size_t)ROVER_RESET_COUNT * N + e];
     // rover_env.py:64-72 decimation loop
     float Fw[3] = {0.0f, 0.0f, 0.0f};
-    for (int s = 0; s < c.decimation - 1; ++s) physics_substep_group<false>(p, K, g, nullptr);
-    if (c.decimation > 0) physics_substep_group<true>(p, K, g, Fw);
+    K1_STAMP(1);
+    for (int s = 0; s < c.decimation - 1; ++s) physics_substep_group<false>(p, K, g, nullptr, s);
+    if (c.decimation > 0) physics_substep_group<true>(p, K, g, Fw, c.decimation - 1);
+    K1_STAMP(20);
     if (!id.wheel_active) { Fw[0] = 0.0f; Fw[1] = 0.0f; Fw[2] = 0.0f; }
     if (active) group_store(state, N, e, id, g);
 
@@ -1177,17 +1234,11 @@ __global__ __launch_bounds__(64) void rover_step_kernel_group(RvParams p, float 
         for (int i = 0; i < 3; ++i) force[(size_t)(id.body * 3 + i) * N + e] = Fw[i];
     }
 
-    // ---- MDP tail on the manager words (replicated in the group)
-    float S[ROVER_STATE_WORDS];
+    // ---- MDP tail on the manager words (replicated in the group; loaded before the physics, see above)
 #pragma unroll
     for (int i = 0; i < 3; ++i) S[ROVER_POS + i] = g.pos[i];
 #pragma unroll
     for (int i = 0; i < 4; ++i) S[ROVER_QUAT + i] = g.quat[i];
-#pragma unroll
-    for (int i = ROVER_TARGET_W; i < ROVER_ACTION; ++i) S[i] = state[(size_t)i * N + e];
-#pragma unroll
-    for (int i = ROVER_TIME_LEFT; i < ROVER_LAMBDA_N; ++i) S[i] = state[(size_t)i * N + e];
-    S[ROVER_RESET_COUNT] = state[(size_t)ROVER_RESET_COUNT * N + e];
     S[ROVER_ACTION] = act[0]; S[ROVER_ACTION + 1] = act[1];
     S[ROVER_PREV_ACTION] = prev[0]; S[ROVER_PREV_ACTION + 1] = prev[1];
     // words reset_one may clear in reset_mode 1 (stored by their owner lanes only when that happens)
@@ -1254,7 +1305,9 @@ __global__ __launch_bounds__(64) void rover_step_kernel_group(RvParams p, float 
             }
         }
     }
+    K1_STAMP(21);
     command_compute(p, S, gid, step_dt);
+    K1_STAMP(22);
 
 #pragma unroll
     for (int i = 0; i < 14; ++i) lg[i] = wave_sum(lg[i]);
@@ -1774,6 +1827,12 @@ int rover_height_scan(rover_sim *sim, float *scan, void *stream)
     return ROVER_OK;
 }
 
+#ifdef RV_K1_STAMP
+int rover_debug_set_k1_stamps(void *buf)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_k1_stamps), &buf, sizeof(buf)) == hipSuccess ? ROVER_OK : ROVER_ERR_HIP;
+}
+#endif
 #ifdef RV_K2_STAMP
 int rover_debug_scan(rover_sim *sim, float *scan, void *stamps, void *stream)
 {

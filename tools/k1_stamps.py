@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Dev tool (GPU box): phase timeline of the group step kernel from s_memtime stamps (diagnostic build)."""
+import ctypes as C, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from isaac_rover_orbit_amd import _lib, terrain as T
+from isaac_rover_orbit_amd.cfg import RoverEnvCfg
+from isaac_rover_orbit_amd.envs import RoverEnv
+n = 4096
+_lib.LIB_PATH = os.path.join(ROOT, "build", "abl", "librover_ablK1STAMP.so")
+_lib.EXPORTS.append("rover_debug_set_k1_stamps")
+ter = T.make_procedural_terrain((2048, 2048)); ter.make_spawns(2 * n)
+cfg = RoverEnvCfg(); cfg.scene.num_envs = n; cfg.terrain.kind = "custom"
+env = RoverEnv(cfg, terrain=ter); env.reset()
+stamps = torch.zeros(n // 8, 32, dtype=torch.int64, device="cuda")
+fn = env._lib.rover_debug_set_k1_stamps; fn.argtypes = [C.c_void_p]
+assert fn(C.c_void_p(stamps.data_ptr())) == 0
+g = torch.Generator(device="cuda").manual_seed(0)
+acts = torch.rand(8, n, 2, device="cuda", generator=g) * 2 - 1
+for k in range(8):
+    env.step(acts[k])
+torch.cuda.synchronize()
+s = stamps.cpu().numpy().astype(np.float64)
+names = {0: "start", 1: "state loaded + ackermann"}
+for i in range(6):
+    names[2 + 3 * i] = f"sub{i} start"; names[3 + 3 * i] = f"sub{i} geometry done"; names[4 + 3 * i] = f"sub{i} solver done"
+names.update({20: "physics done", 21: "mdp/reset done", 22: "command done"})
+keys = sorted(names)
+prev = None
+tot = np.median(s[:, 22] - s[:, 0])
+for k in keys:
+    if prev is not None:
+        d = s[:, k] - s[:, prev]
+        print(f"{names[k]:28s} +{np.median(d):8.0f} cycles (p90 {np.percentile(d, 90):8.0f})")
+    prev = k
+print("total start->command done median", tot, "cycles")
