@@ -219,6 +219,27 @@ def test_step_procedural_closed_loop_64(oracle, mapping):
     env.close()
 
 
+def test_config4_dense_scanner_rough_terrain(oracle):
+    """BASELINE config 4: 32 x 32 ray pattern at 0.05 m spacing on rougher terrain (sigma_z 0.4 m): bit-exact parity."""
+    from isaac_rover_orbit_amd import terrain as T
+    ter = T.make_procedural_terrain((1024, 1024), seed=11, sigma_z=0.4, n_rocks=80)
+    from isaac_rover_orbit_amd.cfg import RoverEnvCfg
+    from isaac_rover_orbit_amd.envs import RoverEnv
+    n = 512
+    ter.make_spawns(2 * n)
+    cfg = RoverEnvCfg()
+    cfg.scene.num_envs = n
+    cfg.terrain.kind = "custom"
+    cfg.height_scanner.resolution, cfg.height_scanner.size = 0.05, (1.55, 1.55)
+    env = RoverEnv(cfg, terrain=ter)
+    assert env.num_rays == 1024 and env.obs_dim == 1028
+    rng = np.random.RandomState(4)
+    actions = rng.uniform(-1, 1, (24, n, 2)).astype(np.float32)
+    flips = rollout_compare(oracle, env, 24, actions, 0.0, 0.0, resync=False)
+    assert flips == 0
+    env.close()
+
+
 def test_sharding_invariance_gpu(oracle):
     """Two shards with env_id_offset reproduce the corresponding rows of one big env (RNG keyed by global id)."""
     ter = small_procedural()

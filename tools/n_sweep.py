@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Dev tool (GPU box): env-steps/s and kernel times versus num_envs and step-kernel mapping (1 GPU)."""
+import os, sys, time, json
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from isaac_rover_orbit_amd import terrain as T
+from isaac_rover_orbit_amd.cfg import RoverEnvCfg
+from isaac_rover_orbit_amd.envs import RoverEnv
+ter = T.make_procedural_terrain((2048, 2048))
+out = []
+for n, mapping in [(1024, "group"), (4096, "group"), (4096, "lane"), (16384, "group"), (32768, "group"), (32768, "lane"),
+                   (65536, "group"), (65536, "lane"), (131072, "group"), (131072, "lane")]:
+    ter.make_spawns(2 * n)
+    cfg = RoverEnvCfg(); cfg.scene.num_envs = n; cfg.terrain.kind = "custom"; cfg.step_mapping = mapping
+    env = RoverEnv(cfg, terrain=ter); env.reset()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    acts = torch.rand(16, n, 2, device="cuda", generator=g) * 2 - 1
+    for k in range(20): env.step(acts[k % 16])
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    steps = 200
+    for k in range(steps): env.step(acts[k % 16])
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    a = b = 0.0
+    for k in range(20):
+        x, y = env.profile_step(acts[k % 16]); a += x; b += y
+    r = {"num_envs": n, "mapping": mapping, "env_steps_per_s": n * steps / dt, "us_per_step": dt / steps * 1e6,
+         "step_kernel_us": a / 20 * 1e3, "scan_kernel_us": b / 20 * 1e3}
+    print(json.dumps(r)); out.append(r)
+    env.close(); del env; torch.cuda.empty_cache()
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "n_sweep.json"), "w"), indent=1)
