@@ -1,0 +1,88 @@
+"""Translate a reference-style cfg object (an instance of the reference's ``AAURoverEnvCfg`` built on ORBIT -- or on
+``compat.orbit_shim`` -- configclasses) into this package's ``RoverEnvCfg`` / kernel parameter block.
+
+Field map (reference file:line -> here):
+  scene.num_envs                                   rover_env_cfg.py:233-234      -> scene.num_envs
+  sim.dt / decimation / episode_length_s           rover_env_cfg.py:269-271      -> sim.dt / decimation / episode_length_s
+  actions.actions (AckermannActionCfg)             aau_rover/env_cfg.py:21-31    -> actions.*
+  observations.policy.<term>.scale                 rover_env_cfg.py:97-123       -> observations[...].scale
+  rewards.<term>.weight / params                   rover_env_cfg.py:126-163      -> rewards[...]
+  terminations.<term>.params / time_out            rover_env_cfg.py:166-183      -> terminations[...]
+  commands.target_pose.*                           rover_env_cfg.py:187-200      -> commands.*
+  scene.height_scanner.pattern_cfg / offset        rover_env_cfg.py:78-86        -> height_scanner.*
+Term functions are matched by ``func.__name__``; a table that uses a function the kernels do not implement raises.
+"""
+from __future__ import annotations
+
+from ..cfg import OBS_ORDER, REWARD_ORDER, TERMINATION_ORDER, RoverEnvCfg, TermCfg
+
+
+def is_reference_cfg(cfg) -> bool:
+    return hasattr(cfg, "scene") and hasattr(cfg, "rewards") and not isinstance(getattr(cfg, "rewards"), dict)
+
+
+def _func_name(f):
+    return f if isinstance(f, str) else getattr(f, "__name__", str(f))
+
+
+def _plain_params(params):
+    out = {}
+    for k, v in (params or {}).items():
+        out[k] = getattr(v, "name", v) if v.__class__.__name__ == "SceneEntityCfg" else v
+    return out
+
+
+def _terms(table, order, what):
+    found = {k: v for k, v in vars(table).items() if hasattr(v, "func")}
+    if list(found) != order:
+        raise ValueError(f"{what} terms of the cfg are {list(found)}; the fused kernels implement exactly {order}")
+    return found
+
+
+def from_reference_cfg(ref) -> RoverEnvCfg:
+    out = RoverEnvCfg()
+    out.scene.num_envs = int(ref.scene.num_envs)
+    out.scene.env_spacing = getattr(ref.scene, "env_spacing", out.scene.env_spacing)
+    out.sim.dt = float(ref.sim.dt)
+    dev = getattr(ref.sim, "device", None)
+    if dev:
+        out.sim.device = dev
+    out.decimation = int(ref.decimation)
+    out.episode_length_s = float(ref.episode_length_s)
+
+    act = ref.actions.actions
+    a = out.actions
+    a.scale, a.offset = tuple(act.scale), act.offset
+    a.wheelbase_length, a.middle_wheel_distance = act.wheelbase_length, act.middle_wheel_distance
+    a.rear_and_front_wheel_distance, a.wheel_radius = act.rear_and_front_wheel_distance, act.wheel_radius
+    a.min_steering_radius = act.min_steering_radius
+
+    obs = _terms(ref.observations.policy, OBS_ORDER, "observation")
+    for name, t in obs.items():
+        out.observations[name] = TermCfg(_func_name(t.func), scale=1.0 if t.scale is None else float(t.scale),
+                                         params=_plain_params(t.params))
+        if getattr(t, "noise", None) is not None or getattr(t, "clip", None) is not None:
+            raise ValueError(f"observation term '{name}': noise / clip are not implemented by the fused kernels")
+    for name, t in _terms(ref.rewards, REWARD_ORDER, "reward").items():
+        out.rewards[name] = TermCfg(_func_name(t.func), weight=float(t.weight), params=_plain_params(t.params))
+    for name, t in _terms(ref.terminations, TERMINATION_ORDER, "termination").items():
+        out.terminations[name] = TermCfg(_func_name(t.func), params=_plain_params(t.params), time_out=bool(t.time_out))
+
+    cmd = ref.commands.target_pose
+    out.commands.resampling_time_range = tuple(cmd.resampling_time_range)
+    out.commands.heading_range = tuple(cmd.ranges.heading)
+    out.commands.simple_heading = bool(cmd.simple_heading)
+
+    hs = ref.scene.height_scanner
+    out.height_scanner.resolution = float(hs.pattern_cfg.resolution)
+    out.height_scanner.size = tuple(hs.pattern_cfg.size)
+    out.height_scanner.offset_z = float(hs.offset.pos[2])
+    out.height_scanner.attach_yaw_only = bool(hs.attach_yaw_only)
+    out.height_scanner.max_distance = float(hs.max_distance)
+    if not out.height_scanner.attach_yaw_only:
+        raise ValueError("attach_yaw_only=False is not supported (the reference cfg uses True, rover_env_cfg.py:81)")
+    rnd = getattr(ref, "randomization", None)
+    if rnd is not None and hasattr(rnd, "reset_state"):
+        out.reset_z_offset = float(rnd.reset_state.params.get("z_offset", 0.5))
+    out.validate()
+    return out

@@ -197,6 +197,12 @@ class RoverEnv(RLTaskEnv):
     """MI355X-native ``AAURoverEnv-v0``.  ``RoverEnv(cfg)`` / ``gym.make("AAURoverEnv-v0", cfg=cfg)``."""
 
     def __init__(self, cfg: RoverEnvCfg | None = None, terrain: Terrain | None = None, render_mode=None, **kwargs):
+        if cfg is not None and not isinstance(cfg, RoverEnvCfg):
+            # a reference-style cfg (the reference's AAURoverEnvCfg on ORBIT / compat configclasses): translate it
+            from ..compat.convert import from_reference_cfg, is_reference_cfg
+            if not is_reference_cfg(cfg):
+                raise TypeError(f"unsupported cfg type {type(cfg)}")
+            cfg = from_reference_cfg(cfg)
         self.cfg = cfg if cfg is not None else RoverEnvCfg()
         self.render_mode = render_mode
         self.cfg.validate()
