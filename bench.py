@@ -59,8 +59,13 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        raise SystemExit("bench.py needs a ROCm GPU (the rover hot path has no CPU fallback)")
+    dev_index = local_rank % n_dev          # one rank per GPU in production; ranks share a card only in gloo rehearsals
+    torch.cuda.set_device(dev_index)
+    dev = torch.device(f"cuda:{dev_index}")
+    nccl = world > 1 and dist.get_backend() == "nccl"
     n = args.num_envs
     shard = rd.weak_shard(n, rank, world)
 
@@ -96,7 +101,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if nccl else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     value = shard.global_num_envs * args.steps / elapsed
@@ -140,7 +145,7 @@ def main():
     }
 
     # ---- RCCL rollout gather (BASELINE config 3): one 60-step rollout shard of observations, not in `value`
-    if world > 1:
+    if world > 1 and nccl:
         T_roll = 60
         roll = torch.empty(T_roll, n, env.obs_dim, device=dev)
         roll.normal_()
