@@ -1529,14 +1529,15 @@ __global__ __launch_bounds__(RV_K2_THREADS) void rover_scan_obs_kernel(RvParams 
             if (i0 > p.H - 2) i0 = p.H - 2;
             const float fx = u - (float)j0, fy = v - (float)i0;
             const int jl = j0 - j_lo, il = i0 - i_lo;
-            float h00, h01, h10, h11;
-            if (jl >= 0 && il >= 0 && jl + 1 < tw && il + 1 < th) {
-                const float *q = tile + il * pitch + jl;
-                h00 = q[0]; h01 = q[1]; h10 = q[pitch]; h11 = q[pitch + 1];
-            } else {  // outside the staged window (cannot happen with the slack above; kept for safety)
-                const float *q = p.height + (size_t)i0 * p.W + j0;
-                h00 = q[0]; h01 = q[1]; h10 = q[p.W]; h11 = q[p.W + 1];
-            }
+            // The staged window covers every in-map ray by construction (scan_window(): pattern extent + slack, tile sized
+            // for the diagonal).  Indices are clamped so the LDS reads are always valid plain ds_read instructions (a
+            // pointer that may be LDS or global would become a slow flat load); a ray outside the window -- a bug --
+            // yields NaN, which the parity tests would catch.
+            const bool in_tile = jl >= 0 && il >= 0 && jl + 1 < tw && il + 1 < th;
+            const int jc = max(0, min(jl, tw - 2)), ic = max(0, min(il, th - 2));
+            const float *q = tile + ic * pitch + jc;
+            const float h00 = q[0], h01 = q[1], h10 = q[pitch], h11 = q[pitch + 1];
+            if (!in_tile) return __int_as_float(0x7fc00000);
             const float dx0 = h01 - h00, dx1 = h11 - h10;
             const float hx0 = h00 + fx * dx0;
             const float hx1 = h10 + fx * dx1;
