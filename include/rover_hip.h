@@ -99,6 +99,12 @@ int rover_destroy(rover_sim *sim);
 int rover_set_terrain(rover_sim *sim, const float *height, const float *obstacle, const uint8_t *safe_mask, int32_t H,
                       int32_t W, float resolution, float min_x, float min_y, const float *spawns, int32_t n_spawns);
 
+/* Optional: an EXACT 16-bit copy of `height` for the ray-caster kernel -- height[i] == height_q[i] * q_scale for every
+ * cell (q_scale a power of two; the caller guarantees it, isaac_rover_orbit_amd/terrain.py quantises generated terrain
+ * to 2^-13 m and checks ingested terrain).  Halves the bytes the scan kernel stages per env; results are bit-identical
+ * to the fp32 array.  NULL switches back to fp32.  No reference counterpart (the reference ray-casts a mesh with Warp). */
+int rover_set_terrain_q16(rover_sim *sim, const int16_t *height_q, float q_scale);
+
 /* Scratch the library needs from the caller (per-wave log partials); bytes. */
 size_t rover_workspace_bytes(const rover_sim *sim);
 

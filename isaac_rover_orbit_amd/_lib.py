@@ -19,7 +19,7 @@ TARGET_W, HEADING_CMD_W, ENV_ORIGIN, ACTION, PREV_ACTION, TIME_LEFT, EP_LEN = 39
 CMD_B, HEADING_CMD_B, EP_SUM, METRIC_POS, METRIC_HEAD, LAMBDA_N, RESET_COUNT = 52, 55, 56, 63, 64, 65, 71
 
 EXPORTS = [
-    "rover_default_config", "rover_create", "rover_destroy", "rover_set_terrain", "rover_workspace_bytes", "rover_bind",
+    "rover_default_config", "rover_create", "rover_destroy", "rover_set_terrain", "rover_set_terrain_q16", "rover_workspace_bytes", "rover_bind",
     "rover_reset", "rover_step", "rover_profile_step", "rover_ackermann", "rover_height_scan", "rover_physics", "rover_model_constants",
     "rover_state_words", "rover_config_bytes", "rover_last_error", "rover_version",
 ]
@@ -85,6 +85,7 @@ def load():
     lib.rover_create.argtypes = [C.POINTER(RoverConfig), i32, i32, i32, C.POINTER(vp)]
     lib.rover_destroy.argtypes = [vp]
     lib.rover_set_terrain.argtypes = [vp, vp, vp, vp, i32, i32, f32, f32, f32, vp, i32]
+    lib.rover_set_terrain_q16.argtypes = [vp, vp, f32]
     lib.rover_workspace_bytes.argtypes = [vp]
     lib.rover_workspace_bytes.restype = C.c_size_t
     lib.rover_bind.argtypes = [vp, vp, vp, C.c_size_t]

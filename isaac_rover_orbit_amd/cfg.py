@@ -156,6 +156,7 @@ class RoverEnvCfg:
     solver_iterations: int = 16             # Jacobi sweeps of the contact solver (ORBIT cfg: 32 position iterations)
     step_mapping: str = "auto"              # "auto" | "lane" (one env per lane) | "group" (eight lanes per env)
     record_contact_forces: bool = True       # materialise contact_sensor.data.force_matrix_w every step
+    use_int16_terrain: bool = True           # stage the exact int16 copy of the heightfield in the scan kernel when it exists
     # multi-GPU sharding: this process simulates global env ids [env_id_offset, env_id_offset + num_envs)
     env_id_offset: int = 0
     global_num_envs: int | None = None

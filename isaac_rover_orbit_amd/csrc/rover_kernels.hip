@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <type_traits>
 
 #include "../../include/rover_hip.h"
 #include "rover_model.hpp"
@@ -41,10 +42,14 @@ struct RvParams {
     int n, env_id_offset;
     int rays, obs_w;
     int tile_dim;    // LDS tile rows (cells) for the scan kernel
-    int tile_pitch;  // floats per LDS tile row (multiple of 4)
+    int tile_pitch;  // cells per LDS tile row (multiple of the cells per 16-byte chunk)
+    // optional exact 16-bit copy of `height` (height == height_q * q_scale for every cell): halves the bytes the scan
+    // kernel stages; chunk_cells = cells per 16-byte chunk of the array the scan kernel reads (4: fp32, 8: int16)
+    const int16_t *height_q;
+    float q_scale;
+    int chunk_cells;
     float *scan_desc;  // [n][8] per-env scan descriptor written by the step kernel: px, py, pz, cos(yaw), sin(yaw),
                        // i_lo, j_lo, (th | tw4 << 16) of the terrain window (ints as raw bits)
-    const int *scan_slot;  // [n] env -> descriptor slot (workgroup order of the scan kernel), nullptr = identity
 };
 
 // ------------------------------------------------------------------------------------------------ small helpers
@@ -900,7 +905,8 @@ __device__ __forceinline__ void write_obs_head(const RvParams &p, const float *S
     o[3] = rv_atan2f(cby, cbx) * p.cfg.obs_scale_heading;
 }
 
-// terrain window of the yaw-rotated ray pattern: rows [i_lo, i_lo + th), 16-byte columns [j_lo / 4, j_lo / 4 + tw4)
+// terrain window of the yaw-rotated ray pattern: rows [i_lo, i_lo + th), tw4 16-byte chunks per row starting at cell
+// j_lo (a multiple of the cells per chunk: 4 for the fp32 heightfield, 8 for its exact int16 copy)
 struct ScanWindow {
     float px, py, pz, cy, sy;
     int i_lo, j_lo, th, tw4;
@@ -918,8 +924,8 @@ __device__ __forceinline__ ScanWindow scan_window(const RvParams &p, const float
     w.cy = a * inv;
     w.sy = b * inv;
     const float inv_res = 1.0f / p.res;
-    // window covered by the rotated pattern (+ slack), clamped to the map; the left edge is aligned down to a multiple
-    // of 4 cells so that every row can be staged with 16-byte loads
+    // window covered by the rotated pattern (+ slack), clamped to the map; the left edge is aligned down to a whole
+    // 16-byte chunk so that every row can be staged with 16-byte loads
     const float hx = 0.5f * c.scan_size_x, hy = 0.5f * c.scan_size_y;
     const float ex = fabsf(w.cy) * hx + fabsf(w.sy) * hy, ey = fabsf(w.sy) * hx + fabsf(w.cy) * hy;
     int j_lo = (int)floorf((w.px - ex - p.min_x) * inv_res) - 1;
@@ -928,20 +934,20 @@ __device__ __forceinline__ ScanWindow scan_window(const RvParams &p, const float
     int i_hi = (int)floorf((w.py + ey - p.min_y) * inv_res) + 2;
     j_lo = max(0, min(j_lo, p.W - 1)); j_hi = max(0, min(j_hi, p.W - 1));
     i_lo = max(0, min(i_lo, p.H - 1)); i_hi = max(0, min(i_hi, p.H - 1));
-    j_lo &= ~3;
+    const int cc = p.chunk_cells, sh = (cc == 8) ? 3 : 2;
+    j_lo &= ~(cc - 1);
     w.i_lo = i_lo;
     w.j_lo = j_lo;
     w.th = min(i_hi - i_lo + 1, p.tile_dim);
-    w.tw4 = min(min((j_hi - j_lo + 4) >> 2, p.tile_pitch >> 2), (p.W - j_lo + 3) >> 2);
+    w.tw4 = min(min((j_hi - j_lo + cc) >> sh, p.tile_pitch >> sh), (p.W - j_lo + cc - 1) >> sh);   // 16-byte chunks per row
     return w;
 }
 __device__ __forceinline__ void write_scan_desc(const RvParams &p, const float *pos, const float *quat, int e)
 {
     const ScanWindow w = scan_window(p, pos, quat);
-    const int slot = p.scan_slot ? p.scan_slot[e] : e;
-    float4 *d = reinterpret_cast<float4 *>(p.scan_desc + (size_t)slot * 8);
+    float4 *d = reinterpret_cast<float4 *>(p.scan_desc + (size_t)e * 8);
     d[0] = make_float4(w.px, w.py, w.pz, w.cy);
-    d[1] = make_float4(w.sy, __int_as_float(w.i_lo | (e << 12)), __int_as_float(w.j_lo), __int_as_float(w.th | (w.tw4 << 16)));
+    d[1] = make_float4(w.sy, __int_as_float(w.i_lo), __int_as_float(w.j_lo), __int_as_float(w.th | (w.tw4 << 16)));
 }
 
 __device__ __forceinline__ float wave_sum(float x)
@@ -1385,7 +1391,7 @@ __global__ __launch_bounds__(64) void rover_reset_kernel(RvParams p, float *__re
 #ifndef RV_K2_THREADS
 #define RV_K2_THREADS 512   // 8 waves share one LDS tile: LDS (36.9 KB / workgroup) admits 4 workgroups = 32 waves per CU
 #endif
-template <int MODE>
+template <int MODE, bool Q16>
 __global__ __launch_bounds__(RV_K2_THREADS) void rover_scan_obs_kernel(RvParams p, const float *__restrict__ state,
                                                              float *__restrict__ out, int row_stride, int col0,
                                                              const float *__restrict__ log_partial, int n_waves,
@@ -1394,7 +1400,7 @@ __global__ __launch_bounds__(RV_K2_THREADS) void rover_scan_obs_kernel(RvParams 
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x;
     const int N = p.n;
-    if (MODE == 2 && blockIdx.x == gridDim.x - 1) {
+    if (MODE == 2 && (int)blockIdx.x == N) {
         // deterministic reduction of the per-wave log partials: GROUPS x 16 words, then a fixed-order sum
         constexpr int GROUPS = RV_K2_THREADS / 16;
         const int word = tid & 15, grp = tid >> 4;
@@ -1424,7 +1430,7 @@ __global__ __launch_bounds__(RV_K2_THREADS) void rover_scan_obs_kernel(RvParams 
         }
         return;
     }
-    int e = blockIdx.x;
+    const int e = blockIdx.x;
     const rover_config &c = p.cfg;
 #ifdef RV_K2_STAMP
 #define RV_STAMP(k) do { if (MODE == 0 && tid == 0) { reinterpret_cast<unsigned long long *>(const_cast<float *>(log_partial))[(size_t)e * 8 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
@@ -1434,15 +1440,10 @@ __global__ __launch_bounds__(RV_K2_THREADS) void rover_scan_obs_kernel(RvParams 
     RV_STAMP(0);
     ScanWindow w;
     if (MODE == 2) {
-        // workgroups b, b + 8, ... share an XCD (and its L2): XCD x walks the contiguous slots [x * chunk, (x + 1) * chunk)
-        const int chunk = (N + 7) >> 3;
-        const int slot = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
-        if (slot >= N) return;
-        const float4 *d = reinterpret_cast<const float4 *>(p.scan_desc + (size_t)slot * 8);
+        const float4 *d = reinterpret_cast<const float4 *>(p.scan_desc + (size_t)e * 8);
         const float4 d0 = d[0], d1 = d[1];
         w.px = d0.x; w.py = d0.y; w.pz = d0.z; w.cy = d0.w; w.sy = d1.x;
-        w.i_lo = __float_as_int(d1.y) & 0xFFF;
-        e = __float_as_int(d1.y) >> 12;
+        w.i_lo = __float_as_int(d1.y);
         w.j_lo = __float_as_int(d1.z);
         const int pk = __float_as_int(d1.w);
         w.th = pk & 0xFFFF;
@@ -1460,23 +1461,28 @@ __global__ __launch_bounds__(RV_K2_THREADS) void rover_scan_obs_kernel(RvParams 
     int tw4 = w.tw4;
     if (px == 12345.678f) return;  // keeps the pose loads ahead of the stamp in diagnostic builds (never true)
     RV_STAMP(1);
-    // LDS carve: [0, 64) ray x offsets, [64, 128) ray y offsets, [128, ...) terrain tile (16-B aligned)
-    float *ox_tab = lds, *oy_tab = lds + 64, *tile = lds + 128;
+    // LDS carve: [0, 64) ray x offsets, [64, 128) ray y offsets, [128, ...) terrain tile (16-B aligned) of fp32 heights
+    // or, when the terrain has an exact 16-bit copy, of int16 heights (half the bytes to stage)
+    using cell_t = typename std::conditional<Q16, int16_t, float>::type;
+    constexpr int CC = Q16 ? 8 : 4;  // cells per 16-byte chunk
+    float *ox_tab = lds, *oy_tab = lds + 64;
+    cell_t *tile = reinterpret_cast<cell_t *>(lds + 128);
+    const cell_t *hsrc = Q16 ? reinterpret_cast<const cell_t *>(p.height_q) : reinterpret_cast<const cell_t *>(p.height);
     // ORBIT grid_pattern: arange(-size/2, size/2 + 1e-9, res) evaluated in double, x fastest (App. C)
     if (tid < c.scan_nx) ox_tab[tid] = (float)(-0.5 * (double)c.scan_size_x + (double)c.scan_resolution * (double)tid);
     if (tid >= 64 && tid < 64 + c.scan_ny)
         oy_tab[tid - 64] = (float)(-0.5 * (double)c.scan_size_y + (double)c.scan_resolution * (double)(tid - 64));
     const float inv_res = 1.0f / p.res;
-    const int pitch = p.tile_pitch;  // floats per LDS row, multiple of 4
-    const bool vec_ok = ((p.W & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.height) & 15) == 0);
+    const int pitch = p.tile_pitch;  // cells per LDS row, multiple of CC
+    const bool vec_ok = ((p.W & (CC - 1)) == 0) && ((reinterpret_cast<uintptr_t>(hsrc) & 15) == 0);
     if (vec_ok) {
         // the window is th rows x tw4 16-byte chunks; chunk k of the row-major list goes to thread k % THREADS, so every
         // lane of a wave moves a useful chunk and consecutive lanes read consecutive 16-B pieces of a row.  Four chunks
         // per thread are in flight before the first LDS store waits for data (memory-level parallelism).
         typedef float v4f __attribute__((ext_vector_type(4)));
-        const v4f *src = reinterpret_cast<const v4f *>(p.height + (size_t)i_lo * p.W + j_lo);
+        const v4f *src = reinterpret_cast<const v4f *>(hsrc + (size_t)i_lo * p.W + j_lo);
         v4f *dst = reinterpret_cast<v4f *>(tile);
-        const int wq = p.W >> 2, pq = pitch >> 2;
+        const int wq = p.W / CC, pq = pitch / CC;
         const int nchunk = th * tw4;
         const float inv_tw4 = 1.0f / (float)tw4;
         for (int k0 = tid; k0 < nchunk; k0 += 4 * RV_K2_THREADS) {
@@ -1495,11 +1501,11 @@ __global__ __launch_bounds__(RV_K2_THREADS) void rover_scan_obs_kernel(RvParams 
             if (k0 + 3 * RV_K2_THREADS < nchunk) dst[rr[3] * pq + cc[3]] = b3;
         }
     } else {
-        const int tw = min(tw4 * 4, p.W - j_lo);
+        const int tw = min(tw4 * CC, p.W - j_lo);
         for (int r = tid >> 6; r < th; r += RV_K2_THREADS / 64)
-            for (int cc = tid & 63; cc < tw; cc += 64) tile[r * pitch + cc] = p.height[(size_t)(i_lo + r) * p.W + (j_lo + cc)];
+            for (int cc = tid & 63; cc < tw; cc += 64) tile[r * pitch + cc] = hsrc[(size_t)(i_lo + r) * p.W + (j_lo + cc)];
     }
-    const int tw = min(tw4 * 4, p.W - j_lo);
+    const int tw = min(tw4 * CC, p.W - j_lo);
     RV_STAMP(2);
     __syncthreads();
     RV_STAMP(3);
@@ -1535,8 +1541,14 @@ __global__ __launch_bounds__(RV_K2_THREADS) void rover_scan_obs_kernel(RvParams 
             // yields NaN, which the parity tests would catch.
             const bool in_tile = jl >= 0 && il >= 0 && jl + 1 < tw && il + 1 < th;
             const int jc = max(0, min(jl, tw - 2)), ic = max(0, min(il, th - 2));
-            const float *q = tile + ic * pitch + jc;
-            const float h00 = q[0], h01 = q[1], h10 = q[pitch], h11 = q[pitch + 1];
+            const cell_t *q = tile + ic * pitch + jc;
+            float h00, h01, h10, h11;
+            if (Q16) {  // exact: every height is an integer multiple of q_scale (a power of two) below 2^15 steps
+                h00 = (float)q[0] * p.q_scale; h01 = (float)q[1] * p.q_scale;
+                h10 = (float)q[pitch] * p.q_scale; h11 = (float)q[pitch + 1] * p.q_scale;
+            } else {
+                h00 = q[0]; h01 = q[1]; h10 = q[pitch]; h11 = q[pitch + 1];
+            }
             if (!in_tile) return __int_as_float(0x7fc00000);
             const float dx0 = h01 - h00, dx1 = h11 - h10;
             const float hx0 = h00 + fx * dx0;
@@ -1635,6 +1647,20 @@ struct rover_sim {
     size_t lds_bytes;
 };
 
+static void configure_tile(rover_sim *sim, int chunk_cells);
+
+template <int MODE>
+static void launch_scan(rover_sim *sim, int grid, hipStream_t st, float *out, int row_stride, int col0, const float *log_partial,
+                        int n_waves, float *log_out)
+{
+    if (sim->p.height_q)
+        hipLaunchKernelGGL((rover_scan_obs_kernel<MODE, true>), dim3(grid), dim3(RV_K2_THREADS), sim->lds_bytes, st, sim->p,
+                           sim->state, out, row_stride, col0, log_partial, n_waves, log_out);
+    else
+        hipLaunchKernelGGL((rover_scan_obs_kernel<MODE, false>), dim3(grid), dim3(RV_K2_THREADS), sim->lds_bytes, st, sim->p,
+                           sim->state, out, row_stride, col0, log_partial, n_waves, log_out);
+}
+
 extern "C" {
 
 int rover_default_config(rover_config *c)
@@ -1715,12 +1741,28 @@ int rover_set_terrain(rover_sim *sim, const float *height, const float *obstacle
     // LDS tile: diagonal of the ray pattern in cells + slack
     const float diag = sqrtf(p.cfg.scan_size_x * p.cfg.scan_size_x + p.cfg.scan_size_y * p.cfg.scan_size_y);
     p.tile_dim = (int)ceilf(diag / resolution) + 6;
-    p.tile_pitch = ((p.tile_dim + 3 + 3) & ~3) + 4;   // + 3 cells for the 4-cell alignment of the left edge, + 4 pad
-    if (p.tile_pitch > 128) return fail(ROVER_ERR_UNSUPPORTED, "ray pattern wider than 124 cells is not supported");
-    sim->lds_bytes = (128 + (size_t)p.tile_dim * p.tile_pitch) * sizeof(float);
-    if (sim->lds_bytes < (RV_K2_THREADS + 16) * sizeof(float)) sim->lds_bytes = (RV_K2_THREADS + 16) * sizeof(float);
+    p.height_q = nullptr;
+    p.q_scale = 0.0f;
+    configure_tile(sim, 4);
     if (sim->lds_bytes > 64 * 1024) return fail(ROVER_ERR_UNSUPPORTED, "ray pattern too large for the LDS tile (64 KiB)");
     sim->have_terrain = true;
+    return ROVER_OK;
+}
+
+int rover_set_terrain_q16(rover_sim *sim, const int16_t *height_q, float q_scale)
+{
+    if (!sim) return fail(ROVER_ERR_INVALID, "sim is NULL");
+    if (!sim->have_terrain) return fail(ROVER_ERR_STATE, "rover_set_terrain has not been called");
+    if (!height_q) {  // back to the fp32 heightfield
+        sim->p.height_q = nullptr;
+        sim->p.q_scale = 0.0f;
+        configure_tile(sim, 4);
+        return ROVER_OK;
+    }
+    if (!(q_scale > 0.0f)) return fail(ROVER_ERR_INVALID, "q_scale must be > 0");
+    sim->p.height_q = height_q;
+    sim->p.q_scale = q_scale;
+    configure_tile(sim, 8);
     return ROVER_OK;
 }
 
@@ -1735,6 +1777,18 @@ int rover_bind(rover_sim *sim, float *state, void *workspace, size_t workspace_b
     sim->log_partial = static_cast<float *>(workspace);
     sim->p.scan_desc = sim->log_partial + sim->ws_log_floats;
     return ROVER_OK;
+}
+
+// LDS tile geometry for a heightfield array with `chunk_cells` cells per 16-byte chunk (4: fp32, 8: int16)
+static void configure_tile(rover_sim *sim, int chunk_cells)
+{
+    RvParams &p = sim->p;
+    p.chunk_cells = chunk_cells;
+    // + (chunk - 1) cells for the alignment of the left edge, + one chunk of padding
+    p.tile_pitch = ((p.tile_dim + 2 * (chunk_cells - 1)) & ~(chunk_cells - 1)) + chunk_cells;
+    const size_t cell_bytes = chunk_cells == 8 ? 2 : 4;
+    sim->lds_bytes = 128 * sizeof(float) + (size_t)p.tile_dim * p.tile_pitch * cell_bytes;
+    if (sim->lds_bytes < (RV_K2_THREADS + 16) * sizeof(float)) sim->lds_bytes = (RV_K2_THREADS + 16) * sizeof(float);
 }
 
 static int ready(rover_sim *sim)
@@ -1752,8 +1806,7 @@ int rover_reset(rover_sim *sim, float *obs, void *stream)
     hipStream_t st = static_cast<hipStream_t>(stream);
     const RvParams &p = sim->p;
     hipLaunchKernelGGL(rover_reset_kernel, dim3((p.n + 63) / 64), dim3(64), 0, st, p, sim->state);
-    hipLaunchKernelGGL(rover_scan_obs_kernel<1>, dim3(p.n), dim3(RV_K2_THREADS), sim->lds_bytes, st, p, sim->state, obs, p.obs_w,
-                       4, (const float *)nullptr, 0, (float *)nullptr);
+    launch_scan<1>(sim, p.n, st, obs, p.obs_w, 4, nullptr, 0, nullptr);
     HIP_TRY(hipGetLastError());
     return ROVER_OK;
 }
@@ -1771,8 +1824,7 @@ int rover_step(rover_sim *sim, const float *action, float *obs, float *reward, u
     else
         hipLaunchKernelGGL(rover_step_kernel, dim3(sim->n_waves), dim3(64), 0, st, p, sim->state, action, obs, reward,
                            terminated, truncated, force, sim->log_partial);
-    hipLaunchKernelGGL(rover_scan_obs_kernel<2>, dim3(8 * ((p.n + 7) / 8) + 1), dim3(RV_K2_THREADS), sim->lds_bytes, st, p,
-                       sim->state, obs, p.obs_w, 4, sim->log_partial, sim->n_waves, log);
+    launch_scan<2>(sim, p.n + 1, st, obs, p.obs_w, 4, sim->log_partial, sim->n_waves, log);
     HIP_TRY(hipGetLastError());
     return ROVER_OK;
 }
@@ -1797,8 +1849,7 @@ int rover_profile_step(rover_sim *sim, const float *action, float *obs, float *r
         hipLaunchKernelGGL(rover_step_kernel, dim3(sim->n_waves), dim3(64), 0, st, p, sim->state, action, obs, reward,
                            terminated, truncated, force, sim->log_partial);
     HIP_TRY(hipEventRecord(ev[1], st));
-    hipLaunchKernelGGL(rover_scan_obs_kernel<2>, dim3(8 * ((p.n + 7) / 8) + 1), dim3(RV_K2_THREADS), sim->lds_bytes, st, p,
-                       sim->state, obs, p.obs_w, 4, sim->log_partial, sim->n_waves, log);
+    launch_scan<2>(sim, p.n + 1, st, obs, p.obs_w, 4, sim->log_partial, sim->n_waves, log);
     HIP_TRY(hipEventRecord(ev[2], st));
     HIP_TRY(hipEventSynchronize(ev[2]));
     HIP_TRY(hipEventElapsedTime(ms_step_kernel, ev[0], ev[1]));
@@ -1822,8 +1873,7 @@ int rover_height_scan(rover_sim *sim, float *scan, void *stream)
     if (int rc = ready(sim)) return rc;
     if (!scan) return fail(ROVER_ERR_INVALID, "scan is NULL");
     const RvParams &p = sim->p;
-    hipLaunchKernelGGL(rover_scan_obs_kernel<0>, dim3(p.n), dim3(RV_K2_THREADS), sim->lds_bytes, static_cast<hipStream_t>(stream), p,
-                       sim->state, scan, p.rays, 0, (const float *)nullptr, 0, (float *)nullptr);
+    launch_scan<0>(sim, p.n, static_cast<hipStream_t>(stream), scan, p.rays, 0, nullptr, 0, nullptr);
     HIP_TRY(hipGetLastError());
     return ROVER_OK;
 }
@@ -1838,17 +1888,10 @@ int rover_debug_set_k1_stamps(void *buf)
 int rover_debug_scan(rover_sim *sim, float *scan, void *stamps, void *stream)
 {
     const RvParams &p = sim->p;
-    hipLaunchKernelGGL(rover_scan_obs_kernel<0>, dim3(p.n), dim3(RV_K2_THREADS), sim->lds_bytes, static_cast<hipStream_t>(stream), p,
-                       sim->state, scan, p.rays, 0, (const float *)stamps, 0, (float *)nullptr);
+    launch_scan<0>(sim, p.n, static_cast<hipStream_t>(stream), scan, p.rays, 0, (const float *)stamps, 0, nullptr);
     return ROVER_OK;
 }
 #endif
-
-int rover_debug_set_scan_slot(rover_sim *sim, const int *slot_dev)
-{
-    sim->p.scan_slot = slot_dev;
-    return ROVER_OK;
-}
 
 int rover_physics(rover_sim *sim, const float *steer_target, const float *wheel_target, int32_t substeps, float *force,
                   void *stream)

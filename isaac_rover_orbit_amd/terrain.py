@@ -18,6 +18,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
+Q16_SCALE = 2.0 ** -13     # height quantum (0.122 mm) of terrains that have an exact int16 copy (|h| < 4 m)
 RESOLUTION = 0.05          # terrain_utils.py:108
 GRADIENT_THRESHOLD = 0.3   # terrain_utils.py:109
 SPAWN_SEED = 41            # terrain_utils.py:124
@@ -171,6 +172,11 @@ def gaussian_rocks(shape, n_rocks=400, seed=1234, h_range=(0.25, 0.6), aspect_ra
     return out
 
 
+def quantize_heights(h: np.ndarray, scale: float = Q16_SCALE) -> np.ndarray:
+    """Round heights to integer multiples of ``scale`` (exactly representable in fp32 AND in int16 for |h| < 4 m)."""
+    return (np.rint(np.asarray(h, dtype=np.float64) / scale) * scale).astype(np.float32)
+
+
 @dataclass
 class Terrain:
     """Host copy of the shared, read-only terrain data every env (and every GPU rank) uses."""
@@ -195,6 +201,16 @@ class Terrain:
     @property
     def shape(self):
         return self.height.shape
+
+    def height_q16(self, scale: float = Q16_SCALE):
+        """int16 array q with ``height == q * scale`` EXACTLY, or None when the terrain is not representable that way
+        (arbitrary ingested meshes, |h| >= 4 m).  The ray-caster kernel stages this copy (half the bytes) when it exists."""
+        q = self.height.astype(np.float64) / scale
+        if not np.all(q == np.rint(q)) or np.abs(q).max() > 32767:
+            return None
+        q16 = q.astype(np.int16)
+        assert np.array_equal(q16.astype(np.float32) * np.float32(scale), self.height)
+        return q16
 
     def make_spawns(self, n_spawns: int, seed=SPAWN_SEED, border_offset=SPAWN_BORDER_M) -> np.ndarray:
         """Spawn table of the reference: ``n_spawns = 2 * num_envs`` (terrain_utils.py:123-124)."""
@@ -227,12 +243,15 @@ def make_flat_terrain(shape=(2048, 2048), z=0.0) -> Terrain:
 
 
 def make_procedural_terrain(shape=(2048, 2048), seed=1234, sigma_z=0.15, n_rocks=400, h_range=(0.25, 0.6),
-                            aspect_range=(1.0, 1.4)) -> Terrain:
-    """SURVEY 8d config 2 (and config 4 with sigma_z = 0.4): fBm ground + Gaussian rocks."""
+                            aspect_range=(1.0, 1.4), quantize: bool = True) -> Terrain:
+    """SURVEY 8d config 2 (and config 4 with sigma_z = 0.4): fBm ground + Gaussian rocks.  With ``quantize`` both layers
+    are rounded to 2^-13 m (0.12 mm, far below the 0.05 m cell), which makes the terrain exactly representable in int16."""
     scale = min(shape) / 2048.0
     ground = fbm_heightfield(shape, seed=seed, sigma_z=sigma_z, base_cell=max(int(256 * scale), 8))
     rocks = gaussian_rocks(shape, n_rocks=n_rocks, seed=seed, h_range=h_range, aspect_range=aspect_range,
                            border_m=min(5.0, 0.1 * min(shape) * RESOLUTION))
+    if quantize:
+        ground, rocks = quantize_heights(ground), quantize_heights(rocks)
     return Terrain(ground=ground, obstacle=rocks)
 
 

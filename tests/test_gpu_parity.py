@@ -68,6 +68,35 @@ def test_height_scan_matches_oracle(oracle):
     env.close()
 
 
+def test_int16_and_fp32_terrain_paths_agree(oracle):
+    """The exact int16 copy of a quantised terrain and the fp32 array give bit-identical scans; a terrain that is not
+    representable in int16 silently uses the fp32 path."""
+    from isaac_rover_orbit_amd import terrain as T
+    ter = small_procedural()
+    assert ter.height_q16() is not None
+    env_q = make_env(300, ter)
+    env_f = make_env(300, ter, use_int16_terrain=False)
+    assert env_q._height_q_dev is not None and env_f._height_q_dev is None
+    for e in (env_q, env_f):
+        e.reset()
+    assert torch.equal(env_q.obs_buf["policy"], env_f.obs_buf["policy"])
+    rng = np.random.RandomState(1)
+    for _ in range(5):
+        a = torch.from_numpy(rng.uniform(-1, 1, (300, 2)).astype(np.float32)).cuda()
+        oq, rq, _, _, _ = env_q.step(a)
+        of, rf, _, _, _ = env_f.step(a)
+        assert torch.equal(oq["policy"], of["policy"]) and torch.equal(rq, rf)
+    env_q.close(); env_f.close()
+    raw = T.make_procedural_terrain((1024, 1024), seed=5, n_rocks=60, quantize=False)
+    assert raw.height_q16() is None
+    env = make_env(200, raw)
+    assert env._height_q_dev is None
+    env.reset()
+    ocfg, oter = oracle_side(oracle, env)
+    assert_close(env.height_scan().cpu().numpy(), oracle.height_scan(ocfg, oter, state_np(env)), 0, 0, "fp32 terrain scan")
+    env.close()
+
+
 def test_height_scan_misses_are_minus_inf(oracle):
     """Rays that leave the map report +inf hits -> obs = -inf (ORBIT RayCaster semantics)."""
     ter = flat()
