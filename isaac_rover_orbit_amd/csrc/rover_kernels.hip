@@ -1,15 +1,18 @@
 // rover_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) + C ABI of the AAURoverEnv-v0 hot path.
 //
 // Two launches per env.step():
-//   K1  rover_step_kernel     one env per LANE, SoA state (state[word * N + env] => every load/store is a coalesced
-//                             256-B wave access).  process_action -> Ackermann -> 6 x {implicit-PD steer joints,
-//                             6-wheel contact PGS against the bilinear heightfield, wheel motors, integration} ->
-//                             counters -> terminations -> rewards -> in-lane reset (Philox) -> command update.
+//   K1  rover_step_kernel[_group]  one env per LANE (N >= 65536) or per 8-LANE GROUP (one wheel per lane; default),
+//                             SoA state (state[word * N + env]).  process_action -> Ackermann -> 6 x {implicit-PD
+//                             steer joints, 6-wheel contact solve against the bilinear heightfield, wheel motors,
+//                             integration} -> counters -> terminations -> rewards -> in-lane reset (Philox) ->
+//                             command update; writes the observation head and a 32-byte scan descriptor per env.
 //                             Wave-level butterfly reductions produce the per-wave partials of extras["log"].
-//   K2  rover_scan_obs_kernel one env per 256-thread WORKGROUP: stages the yaw-rotated 3 x 3 m terrain window in LDS
-//                             (<= 92 x 92 fp32), evaluates the 31 x 31 vertical rays by bilinear gather from LDS and
-//                             writes the 965-float observation row with coalesced stores; one extra workgroup
-//                             reduces the log partials in a fixed order (deterministic).
+//   K2  rover_scan_obs_kernel PERSISTENT 512-thread workgroups (as many as the chip holds), each walking envs
+//                             b, b + n_wg, ...: the yaw-rotated 3 x 3 m terrain window of the NEXT env is copied
+//                             global -> LDS asynchronously (global_load_lds_dwordx4, dense int16 or fp32 tile, two
+//                             buffers) while the 31 x 31 vertical rays of the current env are evaluated by bilinear
+//                             gather from LDS and written to the 965-float observation row with coalesced stores;
+//                             one extra workgroup reduces the log partials in a fixed order (deterministic).
 // There is no matrix-shaped work on this path (gather / integrate / scatter) => no MFMA; the bound is HBM/latency.
 //
 // Reference behaviour being replaced (file:line in /root/reference): RoverEnv.step entrypoints/rover_env.py:42-102;
@@ -49,7 +52,12 @@ struct RvParams {
     float q_scale;
     int chunk_cells;
     float *scan_desc;  // [n][8] per-env scan descriptor written by the step kernel: px, py, pz, cos(yaw), sin(yaw),
-                       // i_lo, j_lo, (th | tw4 << 16) of the terrain window (ints as raw bits)
+                       // i_lo, j_lo, (th | interior << 15 | tw4 << 16) of the terrain window (ints as raw bits)
+    // host-precomputed uniforms of the scan kernel (a per-thread IEEE division costs ~10 VALU instructions)
+    float inv_res, x_max, y_max, inv_nx;
+    int cpr_log;  // log2 of the chunk slots per staged row (smallest power of two >= tile_pitch / chunk_cells)
+    int wq, pq;   // 16-byte chunks per heightfield row / per LDS tile row
+    int tile_bufs; // LDS tile buffers of the scan kernel (2 when they fit beside full occupancy, else 1)
 };
 
 // ------------------------------------------------------------------------------------------------ small helpers
@@ -910,6 +918,7 @@ __device__ __forceinline__ void write_obs_head(const RvParams &p, const float *S
 struct ScanWindow {
     float px, py, pz, cy, sy;
     int i_lo, j_lo, th, tw4;
+    int interior;  // every ray is >= 2 cells inside the map and the window is not truncated: no per-ray bounds work
 };
 __device__ __forceinline__ ScanWindow scan_window(const RvParams &p, const float *pos, const float *quat)
 {
@@ -923,7 +932,7 @@ __device__ __forceinline__ ScanWindow scan_window(const RvParams &p, const float
     w.px = pos[0]; w.py = pos[1]; w.pz = pos[2];
     w.cy = a * inv;
     w.sy = b * inv;
-    const float inv_res = 1.0f / p.res;
+    const float inv_res = p.inv_res;
     // window covered by the rotated pattern (+ slack), clamped to the map; the left edge is aligned down to a whole
     // 16-byte chunk so that every row can be staged with 16-byte loads
     const float hx = 0.5f * c.scan_size_x, hy = 0.5f * c.scan_size_y;
@@ -940,6 +949,9 @@ __device__ __forceinline__ ScanWindow scan_window(const RvParams &p, const float
     w.j_lo = j_lo;
     w.th = min(i_hi - i_lo + 1, p.tile_dim);
     w.tw4 = min(min((j_hi - j_lo + cc) >> sh, p.tile_pitch >> sh), (p.W - j_lo + cc - 1) >> sh);   // 16-byte chunks per row
+    const float m = 2.0f * p.res;
+    w.interior = (w.px - ex > p.min_x + m) && (w.px + ex < p.x_max - m) && (w.py - ey > p.min_y + m) &&
+                 (w.py + ey < p.y_max - m) && (i_hi - i_lo + 1 <= p.tile_dim) && (((j_hi - j_lo + cc) >> sh) <= (p.tile_pitch >> sh));
     return w;
 }
 __device__ __forceinline__ void write_scan_desc(const RvParams &p, const float *pos, const float *quat, int e)
@@ -947,7 +959,7 @@ __device__ __forceinline__ void write_scan_desc(const RvParams &p, const float *
     const ScanWindow w = scan_window(p, pos, quat);
     float4 *d = reinterpret_cast<float4 *>(p.scan_desc + (size_t)e * 8);
     d[0] = make_float4(w.px, w.py, w.pz, w.cy);
-    d[1] = make_float4(w.sy, __int_as_float(w.i_lo), __int_as_float(w.j_lo), __int_as_float(w.th | (w.tw4 << 16)));
+    d[1] = make_float4(w.sy, __int_as_float(w.i_lo), __int_as_float(w.j_lo), __int_as_float(w.th | (w.interior << 15) | (w.tw4 << 16)));
 }
 
 __device__ __forceinline__ float wave_sum(float x)
@@ -1383,24 +1395,27 @@ __global__ __launch_bounds__(64) void rover_reset_kernel(RvParams p, float *__re
 }
 
 // ================================================================================================ K2: scan + obs
-// One workgroup per env.  out row = out + env * row_stride; scan values start at column col0.
+// Persistent workgroups, one env at a time.  out row = out + env * row_stride; scan values start at column col0.
 //   MODE 0  pose from the state tensor, scan columns only                                   (rover_height_scan)
 //   MODE 1  pose from the state tensor + observation head                                   (rover_reset)
 //   MODE 2  pose + terrain window from the 32-byte descriptor the step kernel left (one scalar load), the head was
 //           written by the step kernel; the LAST workgroup reduces the log partials          (rover_step)
 #ifndef RV_K2_THREADS
-#define RV_K2_THREADS 512   // 8 waves share one LDS tile: LDS (36.9 KB / workgroup) admits 4 workgroups = 32 waves per CU
+#define RV_K2_THREADS 512   // 8 waves share the LDS tiles; <= 40 KiB of LDS per workgroup admits 4 workgroups = 32 waves per CU
 #endif
 template <int MODE, bool Q16>
-__global__ __launch_bounds__(RV_K2_THREADS) void rover_scan_obs_kernel(RvParams p, const float *__restrict__ state,
+__global__ __launch_bounds__(RV_K2_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void rover_scan_obs_kernel(RvParams p, const float *__restrict__ state,
                                                              float *__restrict__ out, int row_stride, int col0,
                                                              const float *__restrict__ log_partial, int n_waves,
-                                                             float *__restrict__ log_out)
+                                                             float *__restrict__ log_out,
+                                                             const float *__restrict__ scan_desc)
 {
+    // scan_desc (= p.scan_desc) is a separate read-only, non-aliased argument so that the per-env descriptor is fetched
+    // with scalar loads: they do not queue behind the in-flight tile copies on the vector-memory counter
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x;
     const int N = p.n;
-    if (MODE == 2 && (int)blockIdx.x == N) {
+    if (MODE == 2 && blockIdx.x == gridDim.x - 1) {
         // deterministic reduction of the per-wave log partials: GROUPS x 16 words, then a fixed-order sum
         constexpr int GROUPS = RV_K2_THREADS / 16;
         const int word = tid & 15, grp = tid >> 4;
@@ -1430,100 +1445,145 @@ __global__ __launch_bounds__(RV_K2_THREADS) void rover_scan_obs_kernel(RvParams 
         }
         return;
     }
-    const int e = blockIdx.x;
     const rover_config &c = p.cfg;
+    // persistent workgroups: the grid is sized to what the chip holds at once (launching one 8-wave workgroup per env
+    // costs ~10 us of dispatch alone at N = 4096); each workgroup walks envs blockIdx.x, blockIdx.x + n_wg, ...
+    const int n_wg = (int)gridDim.x - (MODE == 2 ? 1 : 0);
+#ifdef RV_K2_EMPTY
+    if (N > 0) return;  // diagnostic build: launch cost of the grid alone
+#endif
 #ifdef RV_K2_STAMP
 #define RV_STAMP(k) do { if (MODE == 0 && tid == 0) { reinterpret_cast<unsigned long long *>(const_cast<float *>(log_partial))[(size_t)e * 8 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
 #define RV_STAMP(k) do { } while (0)
 #endif
-    RV_STAMP(0);
-    ScanWindow w;
-    if (MODE == 2) {
-        const float4 *d = reinterpret_cast<const float4 *>(p.scan_desc + (size_t)e * 8);
-        const float4 d0 = d[0], d1 = d[1];
-        w.px = d0.x; w.py = d0.y; w.pz = d0.z; w.cy = d0.w; w.sy = d1.x;
-        w.i_lo = __float_as_int(d1.y);
-        w.j_lo = __float_as_int(d1.z);
-        const int pk = __float_as_int(d1.w);
-        w.th = pk & 0xFFFF;
-        w.tw4 = pk >> 16;
-    } else {
-        float pos[3], quat[4];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) pos[i] = state[(size_t)(ROVER_POS + i) * N + e];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) quat[i] = state[(size_t)(ROVER_QUAT + i) * N + e];
-        w = scan_window(p, pos, quat);
-    }
-    const float px = w.px, py = w.py, pz = w.pz, cy = w.cy, sy = w.sy;
-    const int i_lo = w.i_lo, j_lo = w.j_lo, th = w.th;
-    int tw4 = w.tw4;
-    if (px == 12345.678f) return;  // keeps the pose loads ahead of the stamp in diagnostic builds (never true)
-    RV_STAMP(1);
-    // LDS carve: [0, 64) ray x offsets, [64, 128) ray y offsets, [128, ...) terrain tile (16-B aligned) of fp32 heights
-    // or, when the terrain has an exact 16-bit copy, of int16 heights (half the bytes to stage)
+    // LDS carve: [0, 64) ray x offsets, [64, 128) ray y offsets, [128, 192) reciprocals 1/t, [192, ...) tile_bufs terrain
+    // tiles (16-B aligned) of fp32 heights or, when the terrain has an exact 16-bit copy, of int16 heights (half the bytes)
     using cell_t = typename std::conditional<Q16, int16_t, float>::type;
     constexpr int CC = Q16 ? 8 : 4;  // cells per 16-byte chunk
-    float *ox_tab = lds, *oy_tab = lds + 64;
-    cell_t *tile = reinterpret_cast<cell_t *>(lds + 128);
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    float *ox_tab = lds, *oy_tab = lds + 64, *inv_tab = lds + 128;
+    cell_t *tile_base = reinterpret_cast<cell_t *>(lds + 192);
+    const size_t tile_cells = (size_t)p.tile_dim * p.tile_pitch;
     const cell_t *hsrc = Q16 ? reinterpret_cast<const cell_t *>(p.height_q) : reinterpret_cast<const cell_t *>(p.height);
     // ORBIT grid_pattern: arange(-size/2, size/2 + 1e-9, res) evaluated in double, x fastest (App. C)
     if (tid < c.scan_nx) ox_tab[tid] = (float)(-0.5 * (double)c.scan_size_x + (double)c.scan_resolution * (double)tid);
     if (tid >= 64 && tid < 64 + c.scan_ny)
         oy_tab[tid - 64] = (float)(-0.5 * (double)c.scan_size_y + (double)c.scan_resolution * (double)(tid - 64));
-    const float inv_res = 1.0f / p.res;
-    const int pitch = p.tile_pitch;  // cells per LDS row, multiple of CC
+    if (tid >= 128 && tid < 192) inv_tab[tid - 128] = 1.0f / (float)max(tid - 128, 1);
+    const float inv_res = p.inv_res;
     const bool vec_ok = ((p.W & (CC - 1)) == 0) && ((reinterpret_cast<uintptr_t>(hsrc) & 15) == 0);
-    if (vec_ok) {
-        // the window is th rows x tw4 16-byte chunks; chunk k of the row-major list goes to thread k % THREADS, so every
-        // lane of a wave moves a useful chunk and consecutive lanes read consecutive 16-B pieces of a row.  Four chunks
-        // per thread are in flight before the first LDS store waits for data (memory-level parallelism).
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        const v4f *src = reinterpret_cast<const v4f *>(hsrc + (size_t)i_lo * p.W + j_lo);
-        v4f *dst = reinterpret_cast<v4f *>(tile);
-        const int wq = p.W / CC, pq = pitch / CC;
-        const int nchunk = th * tw4;
-        const float inv_tw4 = 1.0f / (float)tw4;
-        for (int k0 = tid; k0 < nchunk; k0 += 4 * RV_K2_THREADS) {
-            int rr[4], cc[4];
+    const bool two_bufs = p.tile_bufs == 2;
+    const float x_max = p.x_max, y_max = p.y_max;
+    const float inv_nx = p.inv_nx;
+    const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
+
+    auto get_window = [&](int e) -> ScanWindow {
+        ScanWindow w;
+        if (MODE == 2) {
+            const float4 *d = reinterpret_cast<const float4 *>(scan_desc + (size_t)e * 8);
+            const float4 d0 = d[0], d1 = d[1];
+            w.px = d0.x; w.py = d0.y; w.pz = d0.z; w.cy = d0.w; w.sy = d1.x;
+            w.i_lo = __float_as_int(d1.y);
+            w.j_lo = __float_as_int(d1.z);
+            const int pk = __float_as_int(d1.w);
+            w.th = pk & 0x7FFF;
+            w.interior = (pk >> 15) & 1;
+            w.tw4 = pk >> 16;
+        } else {
+            float pos[3], quat[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = min(k0 + u * RV_K2_THREADS, nchunk - 1);  // clamped: every load is issued, no divergence
-                rr[u] = (int)(((float)k + 0.5f) * inv_tw4);             // k / tw4, exact for k < 2^20
-                cc[u] = k - rr[u] * tw4;
-            }
-            const v4f b0 = src[(size_t)rr[0] * wq + cc[0]], b1 = src[(size_t)rr[1] * wq + cc[1]];
-            const v4f b2 = src[(size_t)rr[2] * wq + cc[2]], b3 = src[(size_t)rr[3] * wq + cc[3]];
-            if (k0 + 0 * RV_K2_THREADS < nchunk) dst[rr[0] * pq + cc[0]] = b0;
-            if (k0 + 1 * RV_K2_THREADS < nchunk) dst[rr[1] * pq + cc[1]] = b1;
-            if (k0 + 2 * RV_K2_THREADS < nchunk) dst[rr[2] * pq + cc[2]] = b2;
-            if (k0 + 3 * RV_K2_THREADS < nchunk) dst[rr[3] * pq + cc[3]] = b3;
+            for (int i = 0; i < 3; ++i) pos[i] = state[(size_t)(ROVER_POS + i) * N + e];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) quat[i] = state[(size_t)(ROVER_QUAT + i) * N + e];
+            w = scan_window(p, pos, quat);
         }
-    } else {
-        const int tw = min(tw4 * CC, p.W - j_lo);
-        for (int r = tid >> 6; r < th; r += RV_K2_THREADS / 64)
-            for (int cc = tid & 63; cc < tw; cc += 64) tile[r * pitch + cc] = hsrc[(size_t)(i_lo + r) * p.W + (j_lo + cc)];
-    }
-    const int tw = min(tw4 * CC, p.W - j_lo);
-    RV_STAMP(2);
+        return w;
+    };
+    // Stage the th x tw4 chunk window of env `w` DENSELY (row pitch = tw4 chunks): chunk k of the row-major list goes to
+    // LDS chunk k, moved by an asynchronous global->LDS copy (global_load_lds_dwordx4: no VGPR staging, no ds_write; the
+    // LDS address is wave base + lane * 16, which the dense list order satisfies).  The copies stay in flight while the
+    // workgroup casts the rays of the previous env; `s_waitcnt vmcnt(0)` + barrier retire them before the tile is read.
+    auto issue_tile = [&](const ScanWindow &w, cell_t *tile) {
+        const int tw4 = w.tw4, th = w.th;
+        if (vec_ok) {
+            const v4f *src = reinterpret_cast<const v4f *>(hsrc + (size_t)w.i_lo * p.W + w.j_lo);
+            v4f *dst = reinterpret_cast<v4f *>(tile);
+            const int nchunk = th * tw4;
+            const float inv_tw4 = inv_tab[tw4];
+            for (int k0 = 0; k0 < nchunk; k0 += RV_K2_THREADS) {
+                const int k = k0 + tid;
+                if (k < nchunk) {
+                    const int r = (int)(((float)k + 0.5f) * inv_tw4);  // k / tw4, exact for k < 2^20
+                    const int cq = k - (int)__umul24(r, tw4);
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(src + (size_t)(__umul24(r, p.wq) + cq)),
+                        (__attribute__((address_space(3))) void *)(dst + (k0 + wave_base)), 16, 0, 0);
+                }
+            }
+        } else {
+            const int pitch = tw4 * CC, tw = min(pitch, p.W - w.j_lo);
+            for (int r = tid >> 6; r < th; r += RV_K2_THREADS / 64)
+                for (int cc = tid & 63; cc < tw; cc += 64)
+                    tile[r * pitch + cc] = hsrc[(size_t)(w.i_lo + r) * p.W + (w.j_lo + cc)];
+        }
+    };
+
+    int e = blockIdx.x;
+    if (e >= N) return;
+    __syncthreads();  // tables
+    ScanWindow w = get_window(e);
+    issue_tile(w, tile_base);
+    // the window of the env after next is fetched one iteration early (scalar loads), so its latency hides under a ray phase
+    ScanWindow wn = (e + n_wg < N) ? get_window(e + n_wg) : w;
+    for (int it = 0;; ++it) {
+    RV_STAMP(0);
+    // with two tile buffers one barrier per env is enough: the buffer filled next was last read two envs ago
+    cell_t *tile = tile_base + (two_bufs ? (size_t)(it & 1) * tile_cells : 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    RV_STAMP(1);
+    const int e_next = e + n_wg;
+    const bool more = e_next < N;
+    if (more && two_bufs) issue_tile(wn, tile_base + (size_t)((it + 1) & 1) * tile_cells);
+    const ScanWindow wnn = (e_next + n_wg < N) ? get_window(e_next + n_wg) : wn;
+    RV_STAMP(2);
+    const float px = w.px, py = w.py, pz = w.pz, cy = w.cy, sy = w.sy;
+    const int i_lo = w.i_lo, j_lo = w.j_lo, th = w.th;
+    const int pitch = w.tw4 * CC;  // cells per staged row
+    const int tw = min(pitch, p.W - j_lo);
     RV_STAMP(3);
 
-    const float x_max = p.min_x + (float)(p.W - 1) * p.res;
-    const float y_max = p.min_y + (float)(p.H - 1) * p.res;
-    const float inv_nx = 1.0f / (float)c.scan_nx;
     float *row = out + (size_t)e * row_stride + col0;
-    // one vertical ray: bilinear height of the staged tile at the yaw-rotated grid point
-    auto ray_obs = [&](int ray) -> float {
+    // bilinear height from four staged cells; for the int16 tile the interpolation runs on the raw integers and is scaled
+    // once at the end: q_scale is a power of two, so this is bit-identical to interpolating the scaled heights
+    auto bilerp = [&](const cell_t *q, float fx, float fy) -> float {
+        const float h00 = (float)q[0], h01 = (float)q[1], h10 = (float)q[pitch], h11 = (float)q[pitch + 1];
+        const float dx0 = h01 - h00, dx1 = h11 - h10;
+        const float hx0 = h00 + fx * dx0;
+        const float hx1 = h10 + fx * dx1;
+        const float hh = hx0 + fy * (hx1 - hx0);
+        return Q16 ? hh * p.q_scale : hh;
+    };
+    // one vertical ray: bilinear height of the staged tile at the yaw-rotated grid point.  FAST (whole-workgroup uniform,
+    // decided once per env by scan_window()): every ray is inside the map and the window, so the bounds tests, clamps and
+    // the window check of the general path are no-ops and are skipped.
+    auto ray_obs = [&](int ray, auto fast_tag) -> float {
+        constexpr bool FAST = decltype(fast_tag)::value;
         const int i = (int)(((float)ray + 0.5f) * inv_nx);   // ray / scan_nx, exact for ray < 2^20
-        const int j = ray - i * c.scan_nx;
+        const int j = ray - (int)__umul24(i, c.scan_nx);
         const float oy = oy_tab[i];
         const float ox = ox_tab[j];
         const float x = px + (cy * ox - sy * oy);
         const float y = py + (sy * ox + cy * oy);
         float hgt;
-        if (x < p.min_x || x > x_max || y < p.min_y || y > y_max) {
+        if (FAST) {
+            const float u = (x - p.min_x) * inv_res;
+            const float v = (y - p.min_y) * inv_res;
+            const int j0 = (int)u, i0 = (int)v;
+            const float fx = u - (float)j0, fy = v - (float)i0;
+            hgt = bilerp(tile + (__umul24(i0 - i_lo, pitch) + (j0 - j_lo)), fx, fy);
+        } else if (x < p.min_x || x > x_max || y < p.min_y || y > y_max) {
             hgt = INFINITY;  // ray leaves the terrain: ORBIT RayCaster reports +inf
         } else {
             float u = (x - p.min_x) * inv_res;
@@ -1541,32 +1601,23 @@ __global__ __launch_bounds__(RV_K2_THREADS) void rover_scan_obs_kernel(RvParams 
             // yields NaN, which the parity tests would catch.
             const bool in_tile = jl >= 0 && il >= 0 && jl + 1 < tw && il + 1 < th;
             const int jc = max(0, min(jl, tw - 2)), ic = max(0, min(il, th - 2));
-            const cell_t *q = tile + ic * pitch + jc;
-            float h00, h01, h10, h11;
-            if (Q16) {  // exact: every height is an integer multiple of q_scale (a power of two) below 2^15 steps
-                h00 = (float)q[0] * p.q_scale; h01 = (float)q[1] * p.q_scale;
-                h10 = (float)q[pitch] * p.q_scale; h11 = (float)q[pitch + 1] * p.q_scale;
-            } else {
-                h00 = q[0]; h01 = q[1]; h10 = q[pitch]; h11 = q[pitch + 1];
-            }
+            hgt = bilerp(tile + ic * pitch + jc, fx, fy);
             if (!in_tile) return __int_as_float(0x7fc00000);
-            const float dx0 = h01 - h00, dx1 = h11 - h10;
-            const float hx0 = h00 + fx * dx0;
-            const float hx1 = h10 + fx * dx1;
-            hgt = hx0 + fy * (hx1 - hx0);
         }
         return pz - hgt - c.scan_height_offset;  // observations.py:45
     };
     // two independent rays per thread first (their LDS reads overlap), then whatever is left for larger patterns
-    {
+    auto all_rays = [&](auto fast_tag) {
         const int r0 = tid, r1 = tid + RV_K2_THREADS;
         const bool v0 = r0 < p.rays, v1 = r1 < p.rays;
-        const float o0 = ray_obs(v0 ? r0 : 0);
-        const float o1 = ray_obs(v1 ? r1 : 0);
+        const float o0 = ray_obs(v0 ? r0 : 0, fast_tag);
+        const float o1 = ray_obs(v1 ? r1 : 0, fast_tag);
         if (v0) row[r0] = o0;
         if (v1) row[r1] = o1;
-    }
-    for (int ray = tid + 2 * RV_K2_THREADS; ray < p.rays; ray += RV_K2_THREADS) row[ray] = ray_obs(ray);
+        for (int ray = tid + 2 * RV_K2_THREADS; ray < p.rays; ray += RV_K2_THREADS) row[ray] = ray_obs(ray, fast_tag);
+    };
+    if (w.interior) all_rays(std::true_type{});
+    else all_rays(std::false_type{});
     RV_STAMP(4);
     if (MODE == 1 && tid == 0) {
         const float cbx = state[(size_t)(ROVER_CMD_B + 0) * N + e];
@@ -1577,6 +1628,15 @@ __global__ __launch_bounds__(RV_K2_THREADS) void rover_scan_obs_kernel(RvParams 
         o[2] = sqrtf(cbx * cbx + cby * cby) * c.obs_scale_distance;
         o[3] = rv_atan2f(cby, cbx) * c.obs_scale_heading;
     }
+    if (!more) break;
+    if (!two_bufs) {
+        __syncthreads();  // every ray of this env has read the single tile
+        issue_tile(wn, tile_base);
+    }
+    w = wn;
+    wn = wnn;
+    e = e_next;
+    }  // env loop
 }
 
 // ================================================================================================ unit kernels
@@ -1645,6 +1705,8 @@ struct rover_sim {
     int n_waves;       // log-partial rows written by the step kernel of the selected mapping
     bool group_mapping; // eight lanes per env
     size_t lds_bytes;
+    int n_cu;          // compute units of the device
+    int scan_wgs;      // persistent scan workgroups: what the device holds at once
 };
 
 static void configure_tile(rover_sim *sim, int chunk_cells);
@@ -1653,12 +1715,13 @@ template <int MODE>
 static void launch_scan(rover_sim *sim, int grid, hipStream_t st, float *out, int row_stride, int col0, const float *log_partial,
                         int n_waves, float *log_out)
 {
+    grid = (sim->p.n < sim->scan_wgs ? sim->p.n : sim->scan_wgs) + (MODE == 2 ? 1 : 0);
     if (sim->p.height_q)
         hipLaunchKernelGGL((rover_scan_obs_kernel<MODE, true>), dim3(grid), dim3(RV_K2_THREADS), sim->lds_bytes, st, sim->p,
-                           sim->state, out, row_stride, col0, log_partial, n_waves, log_out);
+                           sim->state, out, row_stride, col0, log_partial, n_waves, log_out, sim->p.scan_desc);
     else
         hipLaunchKernelGGL((rover_scan_obs_kernel<MODE, false>), dim3(grid), dim3(RV_K2_THREADS), sim->lds_bytes, st, sim->p,
-                           sim->state, out, row_stride, col0, log_partial, n_waves, log_out);
+                           sim->state, out, row_stride, col0, log_partial, n_waves, log_out, sim->p.scan_desc);
 }
 
 extern "C" {
@@ -1712,6 +1775,11 @@ int rover_create(const rover_config *cfg, int32_t num_envs, int32_t env_id_offse
     s->p.rays = cfg->scan_nx * cfg->scan_ny;
     s->p.obs_w = 4 + s->p.rays;
     s->device = device;
+    {
+        int n_cu = 0;
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n_cu <= 0) n_cu = 256;
+        s->n_cu = n_cu;
+    }
     if (cfg->step_mapping < 0 || cfg->step_mapping > 2) { delete s; return fail(ROVER_ERR_INVALID, "step_mapping must be 0, 1 or 2"); }
     // latency mapping (8 lanes per env) while one-env-per-lane would leave most SIMDs without a wave
     s->group_mapping = cfg->step_mapping == 2 || (cfg->step_mapping == 0 && num_envs < 65536);
@@ -1787,7 +1855,22 @@ static void configure_tile(rover_sim *sim, int chunk_cells)
     // + (chunk - 1) cells for the alignment of the left edge, + one chunk of padding
     p.tile_pitch = ((p.tile_dim + 2 * (chunk_cells - 1)) & ~(chunk_cells - 1)) + chunk_cells;
     const size_t cell_bytes = chunk_cells == 8 ? 2 : 4;
-    sim->lds_bytes = 128 * sizeof(float) + (size_t)p.tile_dim * p.tile_pitch * cell_bytes;
+    const size_t tile_bytes = (size_t)p.tile_dim * p.tile_pitch * cell_bytes;
+    // 8-wave workgroups: four per CU fill the 32 wave slots and may use 40 KiB of the 160 KiB LDS each
+    p.tile_bufs = (192 * sizeof(float) + 2 * tile_bytes <= 40 * 1024) ? 2 : 1;
+    sim->lds_bytes = 192 * sizeof(float) + p.tile_bufs * tile_bytes;
+    const int by_lds = (int)((160 * 1024) / (sim->lds_bytes > 0 ? sim->lds_bytes : 1));
+    const int by_waves = 32 / (RV_K2_THREADS / 64);
+    const int per_cu = by_lds < by_waves ? (by_lds < 1 ? 1 : by_lds) : by_waves;
+    sim->scan_wgs = sim->n_cu * per_cu;
+    p.pq = p.tile_pitch / chunk_cells;
+    p.wq = p.W / chunk_cells;
+    p.cpr_log = 0;
+    while ((1 << p.cpr_log) < p.pq) ++p.cpr_log;
+    p.inv_res = 1.0f / p.res;
+    p.inv_nx = 1.0f / (float)p.cfg.scan_nx;
+    p.x_max = p.min_x + (float)(p.W - 1) * p.res;
+    p.y_max = p.min_y + (float)(p.H - 1) * p.res;
     if (sim->lds_bytes < (RV_K2_THREADS + 16) * sizeof(float)) sim->lds_bytes = (RV_K2_THREADS + 16) * sizeof(float);
 }
 

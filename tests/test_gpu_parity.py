@@ -97,6 +97,25 @@ def test_int16_and_fp32_terrain_paths_agree(oracle):
     env.close()
 
 
+@pytest.mark.parametrize("quantize", [True, False])
+def test_height_scan_odd_width_and_ragged_persistent_grid(oracle, quantize):
+    """A map whose width is not a multiple of the 16-byte chunk takes the scalar staging path; 2500 envs make the
+    persistent scan workgroups walk a ragged number of envs each (1024 workgroups: two or three envs)."""
+    from isaac_rover_orbit_amd import terrain as T
+    ter = T.make_procedural_terrain((1001, 1203), seed=9, n_rocks=80, quantize=quantize)
+    env = make_env(2500, ter)
+    env.reset()
+    ocfg, oter = oracle_side(oracle, env)
+    rng = np.random.RandomState(3)
+    for _ in range(2):
+        env.step(torch.from_numpy(rng.uniform(-1, 1, (2500, 2)).astype(np.float32)).cuda())
+    S = state_np(env)
+    ref = oracle.height_scan(ocfg, oter, S)
+    assert_close(env.height_scan().cpu().numpy(), ref, 0, 0, "unit scan")
+    assert_close(env.obs_buf["policy"].cpu().numpy()[:, 4:], ref, 0, 0, "scan columns written by step()")
+    env.close()
+
+
 def test_height_scan_misses_are_minus_inf(oracle):
     """Rays that leave the map report +inf hits -> obs = -inf (ORBIT RayCaster semantics)."""
     ter = flat()

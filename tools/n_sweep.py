@@ -9,8 +9,11 @@ from isaac_rover_orbit_amd.cfg import RoverEnvCfg
 from isaac_rover_orbit_amd.envs import RoverEnv
 ter = T.make_procedural_terrain((2048, 2048))
 out = []
-for n, mapping in [(1024, "group"), (4096, "group"), (4096, "lane"), (16384, "group"), (32768, "group"), (32768, "lane"),
-                   (65536, "group"), (65536, "lane"), (131072, "group"), (131072, "lane")]:
+CASES = [(1024, "group"), (4096, "group"), (4096, "lane"), (16384, "group"), (32768, "group"), (32768, "lane"),
+         (65536, "group"), (65536, "lane"), (131072, "group"), (131072, "lane")]
+if len(sys.argv) > 1:   # e.g. 1024:group 2048:group
+    CASES = [(int(a.split(":")[0]), a.split(":")[1]) for a in sys.argv[1:]]
+for n, mapping in CASES:
     ter.make_spawns(2 * n)
     cfg = RoverEnvCfg(); cfg.scene.num_envs = n; cfg.terrain.kind = "custom"; cfg.step_mapping = mapping
     env = RoverEnv(cfg, terrain=ter); env.reset()
