@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Dev tool: profiles/hbm_traffic.json from three rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum
+TCC_MISS_sum) of tools/pmc_run.py.  Usage: pmc_traffic.py <dir_fetch> <dir_write> <dir_tcc> <out.json> [note]"""
+import csv, glob, json, sys, collections
+
+
+def per_kernel(d):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        rows = list(csv.DictReader(open(f)))
+        for r in rows:
+            name = r["Kernel_Name"]
+            key = "rover_scan_obs_kernel" if "rover_scan_obs_kernel<2" in name or "rover_scan_obs_kernelILi2" in name else \
+                  "rover_step_kernel" if "rover_step_kernel" in name else None
+            if key:
+                acc[key][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+    out = {}
+    for k, d2 in acc.items():
+        out[k] = {}
+        for c, v in d2.items():
+            v.sort()
+            v = [x for _, x in v][2:]          # skip the first launches (cold caches)
+            out[k][c] = sum(v) / max(len(v), 1)
+    return out
+
+
+fetch, write, tcc = per_kernel(sys.argv[1]), per_kernel(sys.argv[2]), per_kernel(sys.argv[3])
+res = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum (three separate passes) -- "
+               "python3 tools/pmc_run.py 4096 20; per-launch means over launches 3..20, N=4096, 1x MI355X. FETCH_SIZE/WRITE_SIZE "
+               "are KiB at the L2's memory side (Infinity-Cache hits included). MI355X_MICROARCH.md: on gfx950 FETCH_SIZE "
+               "reports 1/2 of the bytes of a wide coalesced (16 B/lane) read stream -> doubled for rover_scan_obs_kernel (its "
+               "tile staging is 16 B/lane global_load_lds); the step kernel's 4-byte gathers are an uncalibrated width -> raw value.",
+       "round": 1, "_kernels": sys.argv[5] if len(sys.argv) > 5 else ""}
+for k, corr in (("rover_scan_obs_kernel", 2.0), ("rover_step_kernel", 1.0)):
+    f, w = fetch[k]["FETCH_SIZE"], write[k]["WRITE_SIZE"]
+    h, m = tcc[k].get("TCC_HIT_sum", 0.0), tcc[k].get("TCC_MISS_sum", 0.0)
+    res[k] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "fetch_correction": corr,
+              "bytes_per_launch": int((f * corr + w) * 1024), "l2_hit_rate": h / max(h + m, 1.0)}
+json.dump(res, open(sys.argv[4], "w"), indent=1)
+print(json.dumps(res, indent=1))
