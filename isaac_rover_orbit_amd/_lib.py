@@ -22,6 +22,7 @@ EXPORTS = [
     "rover_default_config", "rover_create", "rover_destroy", "rover_set_terrain", "rover_set_terrain_q16", "rover_workspace_bytes", "rover_bind",
     "rover_reset", "rover_step", "rover_profile_step", "rover_ackermann", "rover_height_scan", "rover_physics", "rover_model_constants",
     "rover_state_words", "rover_config_bytes", "rover_last_error", "rover_version",
+    "rover_terrain_rasterize", "rover_terrain_rock_mask", "rover_terrain_scratch_bytes",   # include/rover_terrain.h
 ]
 
 
@@ -96,6 +97,10 @@ def load():
     lib.rover_height_scan.argtypes = [vp, vp, vp]
     lib.rover_physics.argtypes = [vp, vp, vp, i32, vp, vp]
     lib.rover_model_constants.argtypes = [vp, i32]
+    lib.rover_terrain_rasterize.argtypes = [vp, vp, i32, vp, i32, i32, vp]
+    lib.rover_terrain_rock_mask.argtypes = [vp, i32, i32, C.c_double, vp, vp, vp, vp]
+    lib.rover_terrain_scratch_bytes.argtypes = [i32, i32]
+    lib.rover_terrain_scratch_bytes.restype = C.c_size_t
     lib.rover_last_error.restype = C.c_char_p
     lib.rover_version.restype = C.c_char_p
     for name in EXPORTS:

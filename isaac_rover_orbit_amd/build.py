@@ -10,11 +10,14 @@ import subprocess
 import sys
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-SOURCES = [os.path.join(_PKG, "csrc", "rover_kernels.hip")]
-HEADERS = [os.path.join(_PKG, "csrc", "rover_model.hpp"), os.path.join(os.path.dirname(_PKG), "include", "rover_hip.h")]
+SOURCES = [os.path.join(_PKG, "csrc", "rover_kernels.hip"), os.path.join(_PKG, "csrc", "terrain_kernels.hip")]
+HEADERS = [os.path.join(_PKG, "csrc", "rover_model.hpp"), os.path.join(_PKG, "csrc", "rover_internal.hpp"),
+           os.path.join(os.path.dirname(_PKG), "include", "rover_hip.h"),
+           os.path.join(os.path.dirname(_PKG), "include", "rover_terrain.h")]
+OBJ_DIR = os.path.join(os.path.dirname(_PKG), "build", "obj")
 OUTPUT = os.path.join(_PKG, "librover_hip.so")
 # fp32 parity with the CPU oracle: no contraction, no fast-math (correctly rounded div / sqrt are hipcc defaults)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 
 
 def hipcc_path() -> str:
@@ -32,11 +35,24 @@ def needs_build() -> bool:
 
 
 def build_extension(force: bool = False, verbose: bool = False) -> str:
-    if force or needs_build():
-        cmd = [hipcc_path(), *FLAGS, "-o", OUTPUT, *SOURCES]
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
+    """One object per source (rebuilt only when that source or a header changed), then one link."""
+    if not (force or needs_build()):
+        return OUTPUT
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc, objs = hipcc_path(), []
+    t_hdr = max(os.path.getmtime(h) for h in HEADERS)
+    for src in SOURCES:
+        obj = os.path.join(OBJ_DIR, os.path.splitext(os.path.basename(src))[0] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), t_hdr):
+            cmd = [hipcc, *FLAGS, "-c", "-o", obj, src]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUTPUT, *objs]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
     return OUTPUT
 
 

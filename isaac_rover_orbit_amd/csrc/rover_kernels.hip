@@ -31,6 +31,7 @@
 
 #include "../../include/rover_hip.h"
 #include "rover_model.hpp"
+#include "rover_internal.hpp"
 
 namespace {
 
@@ -1692,6 +1693,8 @@ int fail(int code, const char *fmt, const char *detail = "")
     } while (0)
 
 }  // namespace
+
+int rover_internal_fail(int code, const char *fmt, const char *detail) { return fail(code, fmt, detail); }
 
 // ==================================================================================================== C ABI
 struct rover_sim {

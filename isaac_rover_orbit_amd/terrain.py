@@ -11,6 +11,8 @@ shipped, so the data is synthesised here with the same three-layer contract:
 * ``height``    -- ground + obstacle, the surface the wheels touch and the ray-caster sees (``terrain_merged.usd``)
 
 Everything in this module is numpy / scipy and runs once at start-up; the per-step consumers are the HIP kernels.
+``backend="hip"`` hands the two heavy producers (mesh rasterisation, rock masks) to the device kernels of
+``terrain_hip`` instead (bit-identical results).
 """
 from __future__ import annotations
 
@@ -26,11 +28,11 @@ SPAWN_BORDER_M = 20.0      # terrain_utils.py:334
 
 
 # ----------------------------------------------------------------------------------------------- mesh -> heightmap
-def mesh_to_heightmap(vertices: np.ndarray, faces: np.ndarray, resolution: float = RESOLUTION):
-    """``HeightmapManager.mesh_to_heightmap`` (terrain_utils.py:23-57).
+def mesh_bounding_boxes(vertices: np.ndarray, faces: np.ndarray, resolution: float = RESOLUTION):
+    """Grid extent and per-triangle cell bounding boxes of ``mesh_to_heightmap`` (terrain_utils.py:26-49), shared by the
+    host loop below and the device rasteriser (``terrain_hip.mesh_to_heightmap``).
 
-    1 m border trimmed, cell value = max vertex z over every triangle whose *bounding box* covers the cell
-    (no true rasterisation), cells never covered stay at -99.  Returns ``(heightmap[y, x], min_x, min_y, max_x, max_y)``.
+    Returns ``(shape, (min_x, min_y, max_x, max_y), bbox (F, 4) int32 {min_i, max_i, min_j, max_j}, zmax (F,) fp32)``.
     """
     vertices = np.asarray(vertices)
     border = 1.0
@@ -39,18 +41,32 @@ def mesh_to_heightmap(vertices: np.ndarray, faces: np.ndarray, resolution: float
     grid_x = (max_x - min_x) / resolution
     grid_y = (max_y - min_y) / resolution
     # NB the reference allocates (int(grid_x + 1), int(grid_y + 1)) but indexes it [j (y), i (x)] (:35, :55)
-    hm = np.ones((int(grid_x + 1), int(grid_y + 1)), dtype=np.float32) * -99
+    shape = (int(grid_x + 1), int(grid_y + 1))
     cell_x = (max_x - min_x) / grid_x
     cell_y = (max_y - min_y) / grid_y
     tri = vertices[np.asarray(faces).astype(np.int64)]                      # (F, 3, 3)
     lo, hi, zmax = tri.min(axis=1), tri.max(axis=1), tri[:, :, 2].max(axis=1)
     # python int() truncates toward zero, like the reference
     min_i = np.trunc((lo[:, 0] - min_x) / cell_x).astype(np.int64)
-    max_i = np.minimum(np.trunc((hi[:, 0] - min_x) / cell_x).astype(np.int64), hm.shape[1] - 1)
+    max_i = np.minimum(np.trunc((hi[:, 0] - min_x) / cell_x).astype(np.int64), shape[1] - 1)
     min_j = np.trunc((lo[:, 1] - min_y) / cell_y).astype(np.int64)
-    max_j = np.minimum(np.trunc((hi[:, 1] - min_y) / cell_y).astype(np.int64), hm.shape[0] - 1)
-    for f in range(tri.shape[0]):
-        i0, i1, j0, j1 = min_i[f], max_i[f], min_j[f], max_j[f]
+    max_j = np.minimum(np.trunc((hi[:, 1] - min_y) / cell_y).astype(np.int64), shape[0] - 1)
+    if tri.shape[0] and (min_i.min() < -shape[1] or min_j.min() < -shape[0]):
+        raise IndexError("triangle bounding box outside the heightmap (numpy index would be out of bounds)")
+    bbox = np.stack([min_i, max_i, min_j, max_j], axis=1).astype(np.int32)
+    return shape, (min_x, min_y, max_x, max_y), bbox, zmax.astype(np.float32)
+
+
+def mesh_to_heightmap(vertices: np.ndarray, faces: np.ndarray, resolution: float = RESOLUTION):
+    """``HeightmapManager.mesh_to_heightmap`` (terrain_utils.py:23-57).
+
+    1 m border trimmed, cell value = max vertex z over every triangle whose *bounding box* covers the cell
+    (no true rasterisation), cells never covered stay at -99.  Returns ``(heightmap[y, x], min_x, min_y, max_x, max_y)``.
+    """
+    shape, (min_x, min_y, max_x, max_y), bbox, zmax = mesh_bounding_boxes(vertices, faces, resolution)
+    hm = np.ones(shape, dtype=np.float32) * -99
+    for f in range(bbox.shape[0]):
+        i0, i1, j0, j1 = (int(v) for v in bbox[f])
         if i1 < i0 or j1 < j0:
             continue
         # python's range(min, max + 1) with a negative min wraps through negative indices in the reference
@@ -188,6 +204,7 @@ class Terrain:
     rock_mask: np.ndarray | None = None
     safe_rock_mask: np.ndarray | None = None
     spawn_locations: np.ndarray | None = None
+    backend: str = "numpy"   # who derives the rock masks: "numpy" (host, as the reference) or "hip" (device kernels)
     height: np.ndarray = field(init=False)
 
     def __post_init__(self):
@@ -195,8 +212,15 @@ class Terrain:
         self.obstacle = np.ascontiguousarray(self.obstacle, dtype=np.float32)
         assert self.ground.shape == self.obstacle.shape and self.ground.ndim == 2
         self.height = (self.ground + self.obstacle).astype(np.float32)
+        if self.backend not in ("numpy", "hip"):
+            raise ValueError(f"unknown terrain backend {self.backend!r}")
         if self.rock_mask is None or self.safe_rock_mask is None:
-            self.rock_mask, self.safe_rock_mask = find_rocks_in_heightmap(self.height, GRADIENT_THRESHOLD)
+            if self.backend == "hip":   # explicit choice, no fallback: raises without the HIP library / a GPU
+                from . import terrain_hip
+                rock, safe = terrain_hip.find_rocks_in_heightmap(self.height, GRADIENT_THRESHOLD)
+                self.rock_mask, self.safe_rock_mask = rock.cpu().numpy(), safe.cpu().numpy()
+            else:
+                self.rock_mask, self.safe_rock_mask = find_rocks_in_heightmap(self.height, GRADIENT_THRESHOLD)
 
     @property
     def shape(self):
@@ -243,7 +267,7 @@ def make_flat_terrain(shape=(2048, 2048), z=0.0) -> Terrain:
 
 
 def make_procedural_terrain(shape=(2048, 2048), seed=1234, sigma_z=0.15, n_rocks=400, h_range=(0.25, 0.6),
-                            aspect_range=(1.0, 1.4), quantize: bool = True) -> Terrain:
+                            aspect_range=(1.0, 1.4), quantize: bool = True, backend: str = "numpy") -> Terrain:
     """SURVEY 8d config 2 (and config 4 with sigma_z = 0.4): fBm ground + Gaussian rocks.  With ``quantize`` both layers
     are rounded to 2^-13 m (0.12 mm, far below the 0.05 m cell), which makes the terrain exactly representable in int16."""
     scale = min(shape) / 2048.0
@@ -252,20 +276,28 @@ def make_procedural_terrain(shape=(2048, 2048), seed=1234, sigma_z=0.15, n_rocks
                            border_m=min(5.0, 0.1 * min(shape) * RESOLUTION))
     if quantize:
         ground, rocks = quantize_heights(ground), quantize_heights(rocks)
-    return Terrain(ground=ground, obstacle=rocks)
+    return Terrain(ground=ground, obstacle=rocks, backend=backend)
 
 
-def terrain_from_mesh(vertices, faces, ground_vertices=None, ground_faces=None) -> Terrain:
+def terrain_from_mesh(vertices, faces, ground_vertices=None, ground_faces=None, backend: str = "numpy") -> Terrain:
     """Ingest triangle meshes the way ``TerrainManager.__init__`` does (terrain_utils.py:92-127): the merged
     (hidden) mesh gives the heightmap; an optional ground-only mesh of the same extent (``terrain_only.usd``) gives
     the ground layer, and the obstacle layer is their positive difference.  Without it the terrain has no obstacles.
     """
-    hm, min_x, min_y, _, _ = mesh_to_heightmap(vertices, faces)
+    if backend == "hip":
+        from . import terrain_hip
+
+        def to_hm(v, f):
+            h, x0, y0, x1, y1 = terrain_hip.mesh_to_heightmap(v, f)
+            return h.cpu().numpy(), x0, y0, x1, y1
+    else:
+        to_hm = mesh_to_heightmap
+    hm, min_x, min_y, _, _ = to_hm(vertices, faces)
     if ground_vertices is None:
-        return Terrain(ground=hm, obstacle=np.zeros_like(hm), min_x=float(min_x), min_y=float(min_y))
-    gm, gx, gy, _, _ = mesh_to_heightmap(ground_vertices, ground_faces)
+        return Terrain(ground=hm, obstacle=np.zeros_like(hm), min_x=float(min_x), min_y=float(min_y), backend=backend)
+    gm, gx, gy, _, _ = to_hm(ground_vertices, ground_faces)
     if gm.shape != hm.shape or abs(gx - min_x) > 1e-6 or abs(gy - min_y) > 1e-6:
         raise ValueError("ground mesh and merged mesh must cover the same extent")
     obstacle = np.maximum(hm - gm, 0.0).astype(np.float32)
     obstacle[obstacle < 1e-3] = 0.0
-    return Terrain(ground=hm - obstacle, obstacle=obstacle, min_x=float(min_x), min_y=float(min_y))
+    return Terrain(ground=hm - obstacle, obstacle=obstacle, min_x=float(min_x), min_y=float(min_y), backend=backend)

@@ -1,4 +1,4 @@
-"""The C-ABI library loads on a CPU-only host and exports every symbol include/rover_hip.h declares; model constants
+"""The C-ABI library loads on a CPU-only host and exports every symbol include/*.h declares; model constants
 agree between the HIP library, the oracle and the fixture derived from the reference asset.  No compute calls."""
 import ctypes as C
 import json
@@ -12,9 +12,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "rover_hip.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(rover_[a-z0-9_]+)\s*\(", src)))
+    names = set()
+    for hdr in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        if hdr.endswith(".h"):
+            src = open(os.path.join(ROOT, "include", hdr)).read()
+            src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+            names |= set(re.findall(r"\b(rover_[a-z0-9_]+)\s*\(", src))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():
@@ -24,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     names = declared_symbols()
     assert len(names) >= 15
     for n in names:
-        assert hasattr(lib, n), f"{n} declared in include/rover_hip.h but not exported"
+        assert hasattr(lib, n), f"{n} declared in include/*.h but not exported"
     assert sorted(_lib.EXPORTS) == names, "python binding and header disagree on the entry points"
     assert lib.rover_config_bytes() == C.sizeof(_lib.RoverConfig)
     assert lib.rover_state_words() == 72
