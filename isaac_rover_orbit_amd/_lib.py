@@ -23,7 +23,24 @@ EXPORTS = [
     "rover_reset", "rover_step", "rover_profile_step", "rover_ackermann", "rover_height_scan", "rover_physics", "rover_model_constants",
     "rover_state_words", "rover_config_bytes", "rover_last_error", "rover_version",
     "rover_terrain_rasterize", "rover_terrain_rock_mask", "rover_terrain_scratch_bytes",   # include/rover_terrain.h
+    "rover_policy_default_desc", "rover_policy_packed_floats", "rover_policy_pack", "rover_policy_forward",  # rover_policy.h
 ]
+POLICY_MAX_LAYERS = 8
+ACT_NONE, ACT_LEAKY_RELU, ACT_TANH = 0, 1, 2
+
+
+class PolicyLayer(C.Structure):
+    """Mirror of ``struct rover_policy_layer``."""
+    _fields_ = [("K", C.c_int32), ("N", C.c_int32), ("act", C.c_int32), ("split_k", C.c_int32),
+                ("w_off", C.c_uint32), ("b_off", C.c_uint32)]
+
+
+class PolicyDesc(C.Structure):
+    """Mirror of ``struct rover_policy_desc``."""
+    _fields_ = [("obs_dim", C.c_int32), ("prop_dim", C.c_int32), ("enc_offset", C.c_int32), ("enc_dim", C.c_int32),
+                ("n_enc", C.c_int32), ("n_mlp", C.c_int32), ("leaky_slope", C.c_float),
+                ("layers", PolicyLayer * POLICY_MAX_LAYERS)]
+
 
 
 class RoverHipError(RuntimeError):
@@ -101,6 +118,11 @@ def load():
     lib.rover_terrain_rock_mask.argtypes = [vp, i32, i32, C.c_double, vp, vp, vp, vp]
     lib.rover_terrain_scratch_bytes.argtypes = [i32, i32]
     lib.rover_terrain_scratch_bytes.restype = C.c_size_t
+    lib.rover_policy_default_desc.argtypes = [C.POINTER(PolicyDesc), i32, i32]
+    lib.rover_policy_packed_floats.argtypes = [C.POINTER(PolicyDesc)]
+    lib.rover_policy_packed_floats.restype = C.c_size_t
+    lib.rover_policy_pack.argtypes = [C.POINTER(PolicyDesc), C.POINTER(vp), C.POINTER(vp), vp]
+    lib.rover_policy_forward.argtypes = [C.POINTER(PolicyDesc), vp, i32, vp, i32, vp, vp]
     lib.rover_last_error.restype = C.c_char_p
     lib.rover_version.restype = C.c_char_p
     for name in EXPORTS:

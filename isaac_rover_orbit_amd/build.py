@@ -10,10 +10,11 @@ import subprocess
 import sys
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-SOURCES = [os.path.join(_PKG, "csrc", "rover_kernels.hip"), os.path.join(_PKG, "csrc", "terrain_kernels.hip")]
+SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("rover_kernels.hip", "terrain_kernels.hip", "policy_kernels.hip")]
 HEADERS = [os.path.join(_PKG, "csrc", "rover_model.hpp"), os.path.join(_PKG, "csrc", "rover_internal.hpp"),
            os.path.join(os.path.dirname(_PKG), "include", "rover_hip.h"),
-           os.path.join(os.path.dirname(_PKG), "include", "rover_terrain.h")]
+           os.path.join(os.path.dirname(_PKG), "include", "rover_terrain.h"),
+           os.path.join(os.path.dirname(_PKG), "include", "rover_policy.h")]
 OBJ_DIR = os.path.join(os.path.dirname(_PKG), "build", "obj")
 OUTPUT = os.path.join(_PKG, "librover_hip.so")
 # fp32 parity with the CPU oracle: no contraction, no fast-math (correctly rounded div / sqrt are hipcc defaults)

@@ -1,0 +1,452 @@
+// policy_kernels.hip -- fused policy / value network forward pass on the f32-input MFMA (gfx950 / CDNA4, wave64).
+//
+// Reference being replaced (inference only): rover_envs/envs/navigation/learning/skrl/models.py HeightmapEncoder :24-36,
+// GaussianNeuralNetwork.compute :89-103, DeterministicNeuralNetwork.compute :151-163; architecture from
+// rover_envs/learning/train/get_models.py:36-62.  See include/rover_policy.h for the contract.
+//
+// One 512-thread workgroup = 16 observation rows.  The rows (16 x 965 fp32 = 61.8 KB, one contiguous block) are copied to
+// LDS once; every layer is a [16 x K] x [K x N] product on v_mfma_f32_16x16x4_f32 with the A fragments read from LDS and
+// the B fragments streamed from a packed, fragment-ordered weight buffer (one coalesced 16-byte load per lane feeds
+// four MFMAs); activations never leave LDS; the last layer writes the (n, N_last) result.  The f32 MFMA is bit-for-bit
+// a k-ordered fmaf chain (MI355X guide, "FP32-input MFMA"), so the result is reproducible on a CPU:
+//   out[n] = act(chain_k fmaf(in[k], W[n][k], acc) + bias[n]),   acc0 = 0, k ascending
+// with the chain cut into 8 contiguous k ranges (one per wave) combined as ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7))
+// for `split_k` layers (the 961-wide first layer: every wave streams an eighth of its 307 KB of weights; the last
+// 128 -> 2 layer).  tanh / exp are explicit
+// fp32 sequences (rv_tanhf / rv_expf), the same text as in oracle/policy_oracle.c.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <type_traits>
+
+#include "../../include/rover_hip.h"
+#include "../../include/rover_policy.h"
+#include "rover_internal.hpp"
+
+namespace {
+
+constexpr int POL_THREADS = 512;  // 8 waves: two per SIMD, so that one wave's LDS / global latencies hide under the other's MFMAs
+constexpr int POL_WAVES = POL_THREADS / 64;
+constexpr int POL_ROWS = 16;      // observation rows per workgroup = M of the MFMA tile
+constexpr int POL_MAXT = 6;       // accumulator tiles a wave carries at once in a split-K layer
+constexpr int POL_PF = 3;         // k groups of B fragments in flight per wave in a split-K layer (x tiles x 16 B per lane)
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Cephes expf / tanhf as explicit fp32 sequences (no contraction): identical text in oracle/policy_oracle.c
+__device__ __forceinline__ float rv_expf(float x)
+{
+    if (x > 88.0f) return INFINITY;
+    if (x < -88.0f) return 0.0f;
+    const float z = floorf(1.44269504088896341f * x + 0.5f);
+    x = x - z * 0.693359375f;
+    x = x - z * -2.12194440e-4f;
+    const float zz = x * x;
+    float p = 1.9875691500e-4f;
+    p = p * x + 1.3981999507e-3f;
+    p = p * x + 8.3334519073e-3f;
+    p = p * x + 4.1665795894e-2f;
+    p = p * x + 1.6666665459e-1f;
+    p = p * x + 5.0000001201e-1f;
+    p = p * zz + x + 1.0f;
+    return ldexpf(p, (int)z);
+}
+__device__ __forceinline__ float rv_tanhf(float x)
+{
+    const float z = fabsf(x);
+    if (z > 44.0f) return x > 0.0f ? 1.0f : -1.0f;
+    if (z >= 0.625f) {
+        const float s = rv_expf(z + z);
+        const float r = 1.0f - 2.0f / (s + 1.0f);
+        return x < 0.0f ? -r : r;
+    }
+    if (x == 0.0f) return x;
+    const float s = x * x;
+    float p = -5.70498872745e-3f;
+    p = p * s + 2.06390887954e-2f;
+    p = p * s - 5.37397155531e-2f;
+    p = p * s + 1.33314422036e-1f;
+    p = p * s - 3.33332819422e-1f;
+    return p * s * x + x;
+}
+__device__ __forceinline__ float activate(float v, int act, float slope)
+{
+    if (act == ROVER_ACT_LEAKY_RELU) return v > 0.0f ? v : v * slope;
+    if (act == ROVER_ACT_TANH) return rv_tanhf(v);
+    return v;
+}
+
+#ifdef POL_STAMP
+__device__ unsigned long long *g_pol_stamps = nullptr;
+#endif
+
+struct PolLaunch {
+    int n_copies;     // replicas of the packed buffer; workgroup b reads replica b % n_copies
+    unsigned copy_floats;  // floats per replica
+    int tile_floats;  // LDS floats of the observation tile (16 * obs_dim, padded to 4)
+    int part_floats;  // LDS floats of the raw-accumulator buffer
+    int act_pitch;    // floats per row of an activation buffer
+};
+
+// acc[i] += A[16 x k-range] x B[k-range x 16] for NT column tiles at once: k groups [g0, g1) of 16 inputs, B fragments of
+// tile i at Wt + i * tile_stride (+ g * 64 per group, lane already added).  The B fragments of the next PF groups are
+// kept in flight in a register queue (one wave per SIMD: nothing else hides the L2 latency); the loop body is
+// branch-free (a group that holds k >= K, which can only be the last one, is peeled off) so that the compiler's
+// s_waitcnt stays a counted vmcnt(N); the MFMAs of consecutive tiles are independent (the 16x16x4 f32 MFMA issues every
+// 32 cycles but has 40 cycles of dependent latency).
+template <int NT>
+__device__ __forceinline__ void mfma_one_group(v4f (&acc)[NT], const float (&a)[4], const v4f (&b)[NT])
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+#ifdef POL_ABL_NOMFMA   // diagnostic build: weight streaming + LDS time only
+            acc[i][j] += a[j] * b[i][j];
+#else
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[i][j], acc[i], 0, 0, 0);
+#endif
+        }
+}
+template <int NT, int PF>
+__device__ __forceinline__ void mfma_groups(v4f (&acc)[NT], const float *arow_ptr, int akq, int K, const v4f *Wt,
+                                            size_t tile_stride, int g0, int g1, int G)
+{
+#ifdef POL_ABL_NOLOAD   // diagnostic build: every B fragment comes from group 0 (L1 hits): MFMA + LDS time only
+#define POL_G(x) 0
+#else
+#define POL_G(x) (x)
+#endif
+    if (g0 >= g1) return;
+    const bool ragged = (K & 15) != 0 && g1 == G;   // the last group of the layer reads past K: peeled off below
+    const int g_main = ragged ? g1 - 1 : g1;
+    const int n_full = ((g_main - g0) / PF) * PF, rem = (g_main - g0) - n_full;
+    v4f bq[PF][NT];
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+#pragma unroll
+        for (int i = 0; i < NT; ++i) bq[u][i] = Wt[i * tile_stride + (size_t)POL_G(min(g0 + u, G - 1)) * 64];
+    const float *ap = arow_ptr + 16 * g0 + akq;
+    for (int gb = g0; gb < g0 + n_full; gb += PF) {   // PF groups per trip, slot u of the queue <-> group gb + u
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            float a[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = ap[16 * u + 4 * j];
+            mfma_one_group<NT>(acc, a, bq[u]);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) bq[u][i] = Wt[i * tile_stride + (size_t)POL_G(min(gb + u + PF, G - 1)) * 64];
+            __builtin_amdgcn_sched_barrier(0);   // keep the refill here: PF - 1 groups of MFMAs cover its latency
+        }
+        ap += 16 * PF;
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {   // fewer than PF groups left; their fragments are already in slots 0 .. rem - 1
+        if (u < rem) {
+            float a[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = ap[16 * u + 4 * j];
+            mfma_one_group<NT>(acc, a, bq[u]);
+        } else if (u == rem && ragged) {
+            float a[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 16 * g_main + 4 * j + akq;
+                const float v = arow_ptr[min(k, K - 1)];
+                a[j] = k < K ? v : 0.0f;
+            }
+            mfma_one_group<NT>(acc, a, bq[u]);
+        }
+    }
+}
+
+// Packed weights of one layer: for column tile t (16 outputs), k group g (16 inputs = 4 MFMA k-steps), lane l:
+// a float4 {W[n][k0], W[n][k0 + 4], W[n][k0 + 8], W[n][k0 + 12]} with n = 16 t + (l & 15), k0 = 16 g + (l >> 4);
+// zero outside (N, K).  Index ((t * G + g) * 64 + l) * 4.
+__global__ __launch_bounds__(POL_THREADS) void rover_policy_kernel(rover_policy_desc d, PolLaunch L,
+                                                                   const float *__restrict__ packed,
+                                                                   const float *__restrict__ obs, int n,
+                                                                   float *__restrict__ out)
+{
+    extern __shared__ __align__(16) float lds[];
+    // every workgroup streams the same 640 KB of weights in lock step; replicas spread those reads over L2 channels
+    packed += (size_t)(blockIdx.x % (unsigned)L.n_copies) * L.copy_floats;
+#ifdef POL_STAMP   // diagnostic build: s_memtime per phase of workgroup 0..; `out` row space is not used for stamps, a global is
+#define PSTAMP(k) do { if (threadIdx.x == 0 && g_pol_stamps) g_pol_stamps[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PSTAMP(k) do { } while (0)
+#endif
+    PSTAMP(0);
+    float *tile = lds;
+    float *part = tile + L.tile_floats;                       // raw accumulators: [4][16][16 * MAXT + 4] or [16][16 T + 4]
+    float *buf0 = part + L.part_floats;                       // [16][act_pitch]
+    float *buf1 = buf0 + POL_ROWS * L.act_pitch;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar loop bounds, counted waits
+    const int row0 = blockIdx.x * POL_ROWS;
+    const int rows = min(POL_ROWS, n - row0);
+    const int obs_dim = d.obs_dim;
+
+    // ---- observation rows -> LDS (one contiguous block; 16-byte loads when the block is aligned and full)
+    {
+        const float *src = obs + (size_t)row0 * obs_dim;
+        const int total = rows * obs_dim, total_pad = POL_ROWS * obs_dim;
+        if (rows == POL_ROWS && (total & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+            const v4f *s4 = reinterpret_cast<const v4f *>(src);
+            v4f *t4 = reinterpret_cast<v4f *>(tile);
+            const int n4 = total / 4;
+            for (int i0 = tid; i0 < n4; i0 += 8 * POL_THREADS) {   // eight 16-byte loads in flight per lane
+                v4f r[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) r[u] = __builtin_nontemporal_load(s4 + min(i0 + u * POL_THREADS, n4 - 1));  // read once: keep the weights in L2
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (i0 + u * POL_THREADS < n4) t4[i0 + u * POL_THREADS] = r[u];
+            }
+        } else {
+            for (int i = tid; i < total_pad; i += POL_THREADS) tile[i] = i < total ? src[i] : 0.0f;
+        }
+    }
+    __syncthreads();
+    PSTAMP(1);
+
+    const int n_layers = d.n_enc + d.n_mlp;
+    const float *in = tile + (d.n_enc > 0 ? d.enc_offset : 0);  // A operand of the current layer
+    int in_pitch = obs_dim;
+    float *cur = buf0, *nxt = buf1;
+    const int arow = lane & 15, akq = lane >> 4;  // A fragment: row, k within a k-step; C fragment: col = arow, rows 4 akq + j
+
+    for (int li = 0; li < n_layers; ++li) {
+        const rover_policy_layer lay = d.layers[li];
+        const int K = lay.K, N = lay.N, G = ceil_div(K, 16), T = ceil_div(N, 16);
+        const v4f *W4 = reinterpret_cast<const v4f *>(packed + lay.w_off);
+        const float *bias = packed + lay.b_off;
+        const bool last = li == n_layers - 1;
+        // where this layer's activations go: the last encoder layer writes behind the proprioceptive columns of the MLP input
+        const int col0 = (d.n_enc > 0 && li == d.n_enc - 1) ? d.prop_dim : 0;
+        float *dst = last ? out + (size_t)row0 * N : cur + col0;
+        const int dst_pitch = last ? N : L.act_pitch;
+        const float *arow_ptr = in + arow * in_pitch;
+
+        if (lay.split_k) {
+            const int gw = ceil_div(G, POL_WAVES), g0 = min(wave * gw, G), g1 = min(g0 + gw, G);
+            const int ppitch = 16 * POL_MAXT + 4;
+            for (int t0 = 0; t0 < T; t0 += POL_MAXT) {
+                const int nt = min(POL_MAXT, T - t0);
+                const v4f *Wt = W4 + (size_t)t0 * G * 64 + lane;
+                if (t0 > 0) __syncthreads();  // the previous pass's partials have been combined
+                auto pass = [&](auto nt_tag) {
+                    constexpr int NT = decltype(nt_tag)::value;
+                    v4f acc[NT];
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) acc[i] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+                    mfma_groups<NT, POL_PF>(acc, arow_ptr, akq, K, Wt, (size_t)G * 64, g0, g1, G);
+                    float *pw = part + (wave * POL_ROWS + 4 * akq) * ppitch + arow;
+#pragma unroll
+                    for (int i = 0; i < NT; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) pw[j * ppitch + 16 * i] = acc[i][j];
+                };
+                switch (nt) {
+                    case 1: pass(std::integral_constant<int, 1>{}); break;
+                    case 2: pass(std::integral_constant<int, 2>{}); break;
+                    case 3: pass(std::integral_constant<int, 3>{}); break;
+                    case 4: pass(std::integral_constant<int, 4>{}); break;
+                    case 5: pass(std::integral_constant<int, 5>{}); break;
+                    default: pass(std::integral_constant<int, 6>{}); break;
+                }
+                // combine: thread -> (row, column) with the column fastest; 16 * nt columns
+                const int ncols = 16 * nt;
+                const float inv = 1.0f / (float)ncols;
+                __syncthreads();
+                for (int e = tid; e < POL_ROWS * ncols; e += POL_THREADS) {
+                    const int r = (int)(((float)e + 0.5f) * inv), c = e - r * ncols, col = 16 * t0 + c;   // e / ncols, exact here
+                    float q[POL_WAVES];
+#pragma unroll
+                    for (int w = 0; w < POL_WAVES; ++w) q[w] = part[(w * POL_ROWS + r) * ppitch + c];
+                    const float sum = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+                    if (r < rows && col < N) dst[r * dst_pitch + col] = activate(sum + bias[col], lay.act, d.leaky_slope);
+                }
+            }
+        } else {
+            // column tiles wave, wave + 8, wave + 16, ... belong to this wave; up to four of them are carried at once
+            for (int t0 = wave; t0 < T; t0 += 4 * POL_WAVES) {
+                const int nt = min(4, ceil_div(T - t0, POL_WAVES));
+                const v4f *Wt = W4 + (size_t)t0 * G * 64 + lane;
+                auto pass = [&](auto nt_tag) {
+                    constexpr int NT = decltype(nt_tag)::value;
+                    v4f acc[NT];
+                    float bv[NT];   // this lane's bias per tile, fetched before the k loop (its latency hides under it)
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) {
+                        acc[i] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+                        bv[i] = bias[min(16 * (t0 + POL_WAVES * i) + arow, N - 1)];
+                    }
+                    mfma_groups<NT, (NT >= 3 ? 3 : 6)>(acc, arow_ptr, akq, K, Wt, (size_t)POL_WAVES * G * 64, 0, G, G);
+                    float *pd = dst + 4 * akq * dst_pitch + 16 * t0 + arow;
+                    auto epi = [&](auto act_tag) {   // one specialised copy per activation: no per-element branching
+                        constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+                        for (int i = 0; i < NT; ++i)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (4 * akq + j < rows && 16 * (t0 + POL_WAVES * i) + arow < N)
+                                    pd[j * dst_pitch + 16 * POL_WAVES * i] = activate(acc[i][j] + bv[i], ACT, d.leaky_slope);
+                    };
+                    if (lay.act == ROVER_ACT_LEAKY_RELU) epi(std::integral_constant<int, ROVER_ACT_LEAKY_RELU>{});
+                    else if (lay.act == ROVER_ACT_TANH) epi(std::integral_constant<int, ROVER_ACT_TANH>{});
+                    else epi(std::integral_constant<int, ROVER_ACT_NONE>{});
+                };
+                switch (nt) {
+                    case 1: pass(std::integral_constant<int, 1>{}); break;
+                    case 2: pass(std::integral_constant<int, 2>{}); break;
+                    case 3: pass(std::integral_constant<int, 3>{}); break;
+                    default: pass(std::integral_constant<int, 4>{}); break;
+                }
+            }
+        }
+        PSTAMP(2 + li);
+        if (last) break;
+        // proprioceptive columns in front of the encoder output (models.py:93-96: cat([states[:, :4], encoder_output]))
+        if (d.n_enc > 0 && li == d.n_enc - 1)
+            for (int e = tid; e < POL_ROWS * d.prop_dim; e += POL_THREADS) {
+                const int r = e / d.prop_dim, c = e - r * d.prop_dim;
+                cur[r * L.act_pitch + c] = tile[r * obs_dim + c];
+            }
+        __syncthreads();
+        in = cur;
+        in_pitch = L.act_pitch;
+        float *t = cur; cur = nxt; nxt = t;
+    }
+}
+
+int check_desc(const rover_policy_desc *d)
+{
+    if (!d) return rover_internal_fail(ROVER_ERR_INVALID, "desc is NULL");
+    const int nl = d->n_enc + d->n_mlp;
+    if (d->n_enc < 0 || d->n_mlp < 1 || nl > ROVER_POLICY_MAX_LAYERS) return rover_internal_fail(ROVER_ERR_INVALID, "bad layer counts");
+    if (d->obs_dim < 1 || d->prop_dim < 0 || d->prop_dim > d->obs_dim) return rover_internal_fail(ROVER_ERR_INVALID, "bad obs_dim / prop_dim");
+    int width = d->prop_dim;
+    if (d->n_enc > 0) {
+        if (d->enc_dim < 1 || d->enc_offset < 0 || d->enc_offset + d->enc_dim > d->obs_dim)
+            return rover_internal_fail(ROVER_ERR_INVALID, "encoder slice outside the observation row");
+        int k = d->enc_dim;
+        for (int i = 0; i < d->n_enc; ++i) {
+            if (d->layers[i].K != k || d->layers[i].N < 1) return rover_internal_fail(ROVER_ERR_INVALID, "encoder layer shapes do not chain");
+            k = d->layers[i].N;
+        }
+        width += k;
+    }
+    for (int i = d->n_enc; i < nl; ++i) {
+        if (d->layers[i].K != width || d->layers[i].N < 1) return rover_internal_fail(ROVER_ERR_INVALID, "MLP layer shapes do not chain");
+        width = d->layers[i].N;
+    }
+    for (int i = 0; i < nl; ++i)
+        if (d->layers[i].act < 0 || d->layers[i].act > 2) return rover_internal_fail(ROVER_ERR_INVALID, "unknown activation");
+    return ROVER_OK;
+}
+
+size_t layer_weight_floats(const rover_policy_layer &l) { return (size_t)ceil_div(l.N, 16) * ceil_div(l.K, 16) * 64 * 4; }
+size_t layer_bias_floats(const rover_policy_layer &l) { return ((size_t)l.N + 3) & ~(size_t)3; }
+
+}  // namespace
+
+extern "C" {
+
+int rover_policy_default_desc(rover_policy_desc *d, int32_t out_dim, int32_t final_tanh)
+{
+    if (!d || out_dim < 1) return rover_internal_fail(ROVER_ERR_INVALID, "bad argument");
+    memset(d, 0, sizeof(*d));
+    d->obs_dim = 965; d->prop_dim = 4; d->enc_offset = 3; d->enc_dim = 961;   // models.py:94-95
+    d->n_enc = 2; d->n_mlp = 4; d->leaky_slope = 0.01f;
+    const int K[6] = {961, 80, 64, 256, 160, 128}, N[6] = {80, 60, 256, 160, 128, out_dim};   // get_models.py:43-49
+    for (int i = 0; i < 6; ++i) {
+        d->layers[i].K = K[i]; d->layers[i].N = N[i];
+        d->layers[i].act = ROVER_ACT_LEAKY_RELU;
+        d->layers[i].split_k = 0;
+    }
+    d->layers[0].split_k = 1;   // 307 KB of weights: a quarter per wave
+    d->layers[5].split_k = 1;   // one column tile only
+    d->layers[5].act = final_tanh ? ROVER_ACT_TANH : ROVER_ACT_NONE;
+    return ROVER_OK;
+}
+
+size_t rover_policy_packed_floats(const rover_policy_desc *d)
+{
+    if (!d || d->n_enc + d->n_mlp > ROVER_POLICY_MAX_LAYERS || d->n_enc < 0 || d->n_mlp < 0) return 0;
+    size_t n = 0;
+    for (int i = 0; i < d->n_enc + d->n_mlp; ++i) n += layer_weight_floats(d->layers[i]) + layer_bias_floats(d->layers[i]);
+    return n;
+}
+
+int rover_policy_pack(rover_policy_desc *d, const float *const *weights, const float *const *biases, float *packed)
+{
+    if (int rc = check_desc(d)) return rc;
+    if (!weights || !biases || !packed) return rover_internal_fail(ROVER_ERR_INVALID, "NULL argument");
+    size_t off = 0;
+    for (int li = 0; li < d->n_enc + d->n_mlp; ++li) {
+        rover_policy_layer &l = d->layers[li];
+        if (!weights[li] || !biases[li]) return rover_internal_fail(ROVER_ERR_INVALID, "layer weight / bias is NULL");
+        const int G = ceil_div(l.K, 16), T = ceil_div(l.N, 16);
+        l.w_off = (uint32_t)off;
+        float *w = packed + off;
+        for (int t = 0; t < T; ++t)
+            for (int g = 0; g < G; ++g)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j) {
+                        const int nn = 16 * t + (lane & 15), k = 16 * g + 4 * j + (lane >> 4);
+                        w[(((size_t)t * G + g) * 64 + lane) * 4 + j] = (nn < l.N && k < l.K) ? weights[li][(size_t)nn * l.K + k] : 0.0f;
+                    }
+        off += layer_weight_floats(l);
+        l.b_off = (uint32_t)off;
+        for (size_t i = 0; i < layer_bias_floats(l); ++i) packed[off + i] = i < (size_t)l.N ? biases[li][i] : 0.0f;
+        off += layer_bias_floats(l);
+    }
+    return ROVER_OK;
+}
+
+int rover_policy_forward(const rover_policy_desc *d, const float *packed, int32_t n_copies, const float *obs, int32_t n,
+                         float *out, void *stream)
+{
+    if (int rc = check_desc(d)) return rc;
+    if (!packed || !obs || !out || n < 1 || n_copies < 1) return rover_internal_fail(ROVER_ERR_INVALID, "bad argument");
+    if (reinterpret_cast<uintptr_t>(packed) & 15) return rover_internal_fail(ROVER_ERR_INVALID, "packed weights must be 16-byte aligned");
+    PolLaunch L;
+    L.n_copies = n_copies;
+    L.copy_floats = (unsigned)rover_policy_packed_floats(d);
+    L.tile_floats = (POL_ROWS * d->obs_dim + 3) & ~3;
+    int width = d->prop_dim, part_floats = 0;
+    const int nl = d->n_enc + d->n_mlp;
+    for (int i = 0; i < nl; ++i) {
+        const int T = ceil_div(d->layers[i].N, 16);
+        const int pf = d->layers[i].split_k ? POL_WAVES * POL_ROWS * (16 * POL_MAXT + 4) : 0;
+        part_floats = part_floats > pf ? part_floats : pf;
+        const int w = 16 * T + ((d->n_enc > 0 && i == d->n_enc - 1) ? d->prop_dim : 0);
+        width = width > w ? width : w;
+    }
+    L.part_floats = (part_floats + 3) & ~3;
+    L.act_pitch = ((width + 3) & ~3) + 4;
+    const size_t lds = sizeof(float) * ((size_t)L.tile_floats + L.part_floats + 2 * POL_ROWS * L.act_pitch);
+    if (lds > 160 * 1024) return rover_internal_fail(ROVER_ERR_UNSUPPORTED, "network too wide for the 160 KiB LDS");
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rover_policy_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return rover_internal_fail(ROVER_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(rover_policy_kernel, dim3(ceil_div(n, POL_ROWS)), dim3(POL_THREADS), lds, static_cast<hipStream_t>(stream),
+                       *d, L, packed, obs, n, out);
+    e = hipGetLastError();
+    if (e != hipSuccess) return rover_internal_fail(ROVER_ERR_HIP, "rover_policy_kernel launch: %s", hipGetErrorString(e));
+    return ROVER_OK;
+}
+
+#ifdef POL_STAMP
+int rover_debug_set_policy_stamps(void *buf)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_pol_stamps), &buf, sizeof(buf)) == hipSuccess ? ROVER_OK : ROVER_ERR_HIP;
+}
+#endif
+
+}  // extern "C"

@@ -50,3 +50,42 @@ def assert_close(a, b, atol, rtol, what=""):
     if not (err <= tol).all():
         i = int(np.argmax(err - tol))
         raise AssertionError(f"{what}: max |err| {err.max():.3e} (worst excess at flat idx {i}: {a[fin][i]} vs {b[fin][i]})")
+
+
+# ---------------------------------------------------------------------------------------------- policy networks
+def random_policy_weights(seed=0, out_dim=2, scale=1.0):
+    """Random-init weights of the reference architecture (get_models.py:36-62), torch Linear default init ranges."""
+    rng = np.random.RandomState(seed)
+    K, N = [961, 80, 64, 256, 160, 128], [80, 60, 256, 160, 128, out_dim]
+    ws = [(rng.uniform(-1, 1, (n, k)) / np.sqrt(k) * scale).astype(np.float32) for k, n in zip(K, N)]
+    bs = [(rng.uniform(-1, 1, (n,)) / np.sqrt(k) * scale).astype(np.float32) for k, n in zip(K, N)]
+    return ws, bs
+
+
+def torch_policy_reference(ws, bs, obs, final_tanh=True, device="cpu"):
+    """Plain torch fp32 restatement of GaussianNeuralNetwork.compute / DeterministicNeuralNetwork.compute
+    (rover_envs/envs/navigation/learning/skrl/models.py:89-103, 151-163)."""
+    import torch
+    act = torch.nn.functional.leaky_relu
+    W = [torch.as_tensor(w, device=device) for w in ws]
+    B = [torch.as_tensor(b, device=device) for b in bs]
+    s = torch.as_tensor(obs, device=device)
+    e = s[:, 3:-1]
+    e = act(torch.nn.functional.linear(e, W[0], B[0]))
+    e = act(torch.nn.functional.linear(e, W[1], B[1]))
+    x = torch.cat([s[:, 0:4], e], 1)
+    for i in (2, 3, 4):
+        x = act(torch.nn.functional.linear(x, W[i], B[i]))
+    x = torch.nn.functional.linear(x, W[5], B[5])
+    return (torch.tanh(x) if final_tanh else x).cpu().numpy()
+
+
+def synthetic_obs(n, seed=0):
+    """Observation rows shaped like the env's: actions in [-1, 1], distance / heading terms, height scan around -0.27."""
+    rng = np.random.RandomState(seed)
+    obs = np.empty((n, 965), dtype=np.float32)
+    obs[:, 0:2] = rng.uniform(-1, 1, (n, 2))
+    obs[:, 2] = rng.uniform(0, 1.2, n)
+    obs[:, 3] = rng.uniform(-1, 1, n)
+    obs[:, 4:] = -0.27 + 0.15 * rng.standard_normal((n, 961))
+    return obs

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Dev tool (GPU box): per-phase s_memtime timeline of the policy kernel (diagnostic build POLSTAMP)."""
+import ctypes as C, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import random_policy_weights, synthetic_obs
+from isaac_rover_orbit_amd import _lib
+_lib.LIB_PATH = os.path.join(ROOT, "build", "abl", "librover_ablPOLSTAMP%s.so" % (sys.argv[1] if len(sys.argv) > 1 else ""))
+from isaac_rover_orbit_amd.policy import RoverNet
+n = 4096
+ws, bs = random_policy_weights(seed=0, scale=3.0)
+net = RoverNet(ws, bs)
+obs = torch.from_numpy(synthetic_obs(n)).cuda()
+stamps = torch.zeros(n // 16, 16, dtype=torch.int64, device="cuda")
+fn = net._lib.rover_debug_set_policy_stamps; fn.argtypes = [C.c_void_p]
+assert fn(C.c_void_p(stamps.data_ptr())) == 0
+for _ in range(5): net(obs)
+torch.cuda.synchronize()
+s = stamps.cpu().numpy().astype(np.float64)
+names = ["obs tile in LDS", "L1 961->80", "L2 80->60", "L3 64->256", "L4 256->160", "L5 160->128", "L6 128->2"]
+for k in range(1, 8):
+    d = s[:, k] - s[:, k - 1]
+    print(f"{names[k-1]:18s} +{np.median(d):8.0f} cycles (p90 {np.percentile(d, 90):8.0f})")
+print("total", np.median(s[:, 7] - s[:, 0]), "start spread", s[:, 0].max() - s[:, 0].min())
