@@ -543,6 +543,43 @@ __device__ __forceinline__ void wheel_rows(const StepConsts &k, Contact &ct, con
     db = fmaf(ct.js_b, ds, fmaf(ct.jt_b, dt, ct.jn_b * dn)) * b_winv;
 }
 
+// The same three rows on packed fp32 (v_pk_fma_f32 / v_pk_mul_f32: two fp32 operations per lane per instruction): every
+// linear quantity is paired with its angular twin -- nj[i] = {n[i], jn_a[i]}, vw[i] = {v[i], w[i]}, minv[i] = {1/m,
+// 1/I[i]} -- so the row velocities and the velocity contributions take half the instructions of wheel_rows().  Each
+// component goes through exactly the operations of wheel_rows() (one rounding per multiply / add / fma), so the result
+// is bit-identical; only the group mapping uses it (a lone wave per SIMD is bound by instruction issue).
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct ContactPairs {
+    f2 nj[3], tj[3], sj[3], minv[3];
+};
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ void wheel_rows_packed(const StepConsts &k, Contact &ct, const ContactPairs &cp, const f2 *vw,
+                                                  float bdj, float b_winv, float mu, float wheel_w, f2 *dvw, float &db)
+{
+    const f2 an = fma2(cp.nj[2], vw[2], fma2(cp.nj[1], vw[1], cp.nj[0] * vw[0]));
+    const f2 at = fma2(cp.tj[2], vw[2], fma2(cp.tj[1], vw[1], cp.tj[0] * vw[0]));
+    const f2 as = fma2(cp.sj[2], vw[2], fma2(cp.sj[1], vw[1], cp.sj[0] * vw[0]));
+    const float un = fmaf(ct.jn_b, bdj, an.x + an.y);
+    const float ut = fmaf(ct.jt_b, bdj, at.x + at.y) - RV_WHEEL_CONTACT_RADIUS * wheel_w;
+    const float us = fmaf(ct.js_b, bdj, as.x + as.y);
+    float ln = fmaf(ct.bias - un, ct.mn, ct.ln);
+    if (ln < 0.0f) ln = 0.0f;
+    const float dn = ln - ct.ln;
+    ct.ln = ln;
+    const float lim = mu * ln;
+    const float lmax = lim < k.lt_motor ? lim : k.lt_motor;
+    const float lt = clampf(fmaf(-fmaf(ct.a_nt, dn, ut), ct.mt, ct.lt), -lmax, lmax);
+    const float dt = lt - ct.lt;
+    ct.lt = lt;
+    const float ls = clampf(fmaf(-fmaf(ct.a_ts, dt, fmaf(ct.a_ns, dn, us)), ct.ms, ct.ls), -lim, lim);
+    const float ds = ls - ct.ls;
+    ct.ls = ls;
+    const f2 dn2 = {dn, dn}, dt2 = {dt, dt}, ds2 = {ds, ds};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dvw[i] = fma2(cp.sj[i], ds2, fma2(cp.tj[i], dt2, cp.nj[i] * dn2)) * cp.minv[i];
+    db = fmaf(ct.js_b, ds, fmaf(ct.jt_b, dt, ct.jn_b * dn)) * b_winv;
+}
+
 // chassis integration shared by both mappings: velocity cap, symplectic Euler, quaternion update
 __device__ __forceinline__ void chassis_integrate(float h, const float R[3][3], float *v, float *wb, float *com_w,
                                                   float *pos, float *quat, float *linvel, float *angvel)
@@ -796,15 +833,29 @@ __device__ __forceinline__ void physics_substep_group(const RvParams &p, const S
     }
     bd += db + dpp_xor1(db);
     const float wheel_w = g.wheel_active ? g.wqd : 0.0f;
-    for (int it = 0; it < p.cfg.solver_iterations; ++it) {
-        wheel_rows(K, ct, v, w, bd, g.b_winv, mu, wheel_w, dv, dw, db);
-        group_sum8x6_pair(dv[0], dv[1], dv[2], dw[0], dw[1], dw[2], db);
+    {
+        ContactPairs cp;
+        f2 vw[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            v[i] += dv[i];
-            w[i] += dw[i];
+            cp.nj[i] = (f2){ct.n[i], ct.jn_a[i]};
+            cp.tj[i] = (f2){ct.t[i], ct.jt_a[i]};
+            cp.sj[i] = (f2){ct.s[i], ct.js_a[i]};
+            cp.minv[i] = (f2){K.inv_m, K.inv_I[i]};
+            vw[i] = (f2){v[i], w[i]};
         }
-        bd += db;
+        for (int it = 0; it < p.cfg.solver_iterations; ++it) {
+            f2 dvw[3];
+            wheel_rows_packed(K, ct, cp, vw, bd, g.b_winv, mu, wheel_w, dvw, db);
+            float a0 = dvw[0].x, a1 = dvw[1].x, a2 = dvw[2].x, a3 = dvw[0].y, a4 = dvw[1].y, a5 = dvw[2].y;
+            group_sum8x6_pair(a0, a1, a2, a3, a4, a5, db);
+            vw[0] += (f2){a0, a3};
+            vw[1] += (f2){a1, a4};
+            vw[2] += (f2){a2, a5};
+            bd += db;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { v[i] = vw[i].x; w[i] = vw[i].y; }
     }
     K1_STAMP(4 + 3 * sidx);
     wheel_motor(K, g.wheel_t, ct.lt, g.wq, g.wqd);
