@@ -93,3 +93,40 @@ def test_bad_arguments_are_reported():
     from isaac_rover_orbit_amd._lib import RoverHipError
     with pytest.raises(RoverHipError, match="chain"):
         RoverNet(ws[:2] + [ws[2][:, :60]] + ws[3:], bs)   # MLP input narrower than prop + encoder output: wrong obs split
+
+
+def _generic_case(po, shapes, n_enc, final_act, obs_dim, prop_dim, n, seed, force_split=None):
+    """Random network of arbitrary shape through RoverNet and through the oracle with the same descriptor."""
+    from isaac_rover_orbit_amd.policy import RoverNet
+    rng = np.random.RandomState(seed)
+    ws = [(rng.uniform(-1, 1, s) / np.sqrt(s[1]) * 2.0).astype(np.float32) for s in shapes]
+    bs = [(rng.uniform(-1, 1, (s[0],)) * 0.1).astype(np.float32) for s in shapes]
+    net = RoverNet(ws, bs, n_enc=n_enc, final_act=final_act, obs_dim=obs_dim, prop_dim=prop_dim)
+    if force_split is not None:
+        for i, f in enumerate(force_split):
+            net.desc.layers[i].split_k = f
+    obs = rng.standard_normal((n, obs_dim)).astype(np.float32)
+    got = net(torch.from_numpy(obs).cuda()).cpu().numpy()
+    ref = po.forward(po.desc_from(net.desc), ws, bs, obs)
+    assert np.array_equal(got, ref), f"max |diff| {np.abs(got - ref).max()}"
+    return got
+
+
+def test_generic_architectures(po):
+    """The kernel is not specialised to 961-80-60 / 256-160-128: odd widths, no encoder, K not a multiple of 16, more than
+    six column tiles in a split-K layer (several passes), a tile-parallel layer with more than 32 tiles."""
+    # MLP only (no encoder): obs 10 -> 33 -> 7, linear head
+    _generic_case(po, [(33, 10), (7, 33)], 0, "none", 10, 10, 37, seed=1)
+    # encoder over obs[:, 5:-1] of a 70-wide row (64 inputs), prop 6; widths that are not multiples of 16
+    _generic_case(po, [(20, 64), (9, 20), (50, 15), (3, 50)], 2, "tanh", 70, 6, 100, seed=2)
+    # split-K layer with 13 column tiles (three passes of <= 6) and a 600-wide K; then a 24-tile tile-parallel layer
+    _generic_case(po, [(200, 600), (384, 204), (5, 384)], 1, "none", 604, 4, 48, seed=3, force_split=[1, 0, 1])
+    # a network that does not fit the LDS is refused with an error code, not a crash
+    from isaac_rover_orbit_amd._lib import RoverHipError
+    with pytest.raises(RoverHipError, match="LDS"):
+        _generic_case(po, [(200, 600), (1024, 204), (5, 1024)], 1, "none", 604, 4, 16, seed=3)
+    # every layer forced to split-K, and every layer forced to a single chain
+    shapes = [(80, 961), (60, 80), (256, 64), (160, 256), (128, 160), (2, 128)]
+    a = _generic_case(po, shapes, 2, "tanh", 965, 4, 33, seed=4, force_split=[1] * 6)
+    b = _generic_case(po, shapes, 2, "tanh", 965, 4, 33, seed=4, force_split=[0] * 6)
+    assert np.abs(a - b).max() < 1e-5 and not np.array_equal(a, b)   # same network, different (documented) summation cuts
