@@ -391,6 +391,14 @@ class RoverEnv(RLTaskEnv):
                    "rover_physics")
         return force.view(_lib.NUM_BODIES, 3, self.num_envs).permute(2, 0, 1)
 
+    @property
+    def episode_log_vector(self) -> torch.Tensor:
+        """The raw 16-float device vector behind ``extras["log"]``: [0:7] mean episodic reward sums per term, [7:11]
+        number of envs that ended this step by (time_out, is_success, far_from_target, collision), [11:13] mean metrics,
+        [13] number of envs that were reset in this step.  Entries other than [13] keep their last value while no env
+        resets (ORBIT only refreshes ``extras["log"]`` on resets)."""
+        return self._log
+
     # ---- state access (env state is never checkpointed in the reference; here it is just a tensor) -------------
     def get_state(self) -> torch.Tensor:
         """(num_envs, 72) copy of the per-env state words (AoS, same word order as include/rover_hip.h)."""
