@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--iterations", type=int, default=100)
     ap.add_argument("--rollouts", type=int, default=60)
     ap.add_argument("--out", default=None, help="write the per-iteration statistics as JSON lines")
+    ap.add_argument("--save", default=None, help="write a skrl-style checkpoint {'policy': state_dict, 'value': state_dict}")
     args = ap.parse_args()
     torch.manual_seed(42)
     dev = torch.device("cuda")
@@ -139,6 +140,8 @@ def main():
         print(json.dumps(st), flush=True)
         if out:
             out.write(json.dumps(st) + "\n"); out.flush()
+    if args.save:
+        torch.save({"policy": policy.state_dict(), "value": value.state_dict()}, args.save)
     env.close()
 
 
