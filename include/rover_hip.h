@@ -100,8 +100,9 @@ int rover_set_terrain(rover_sim *sim, const float *height, const float *obstacle
                       int32_t W, float resolution, float min_x, float min_y, const float *spawns, int32_t n_spawns);
 
 /* Optional: an EXACT 16-bit copy of `height` for the ray-caster kernel -- height[i] == height_q[i] * q_scale for every
- * cell (q_scale a power of two; the caller guarantees it, isaac_rover_orbit_amd/terrain.py quantises generated terrain
- * to 2^-13 m and checks ingested terrain).  Halves the bytes the scan kernel stages per env; results are bit-identical
+ * cell, q_scale a positive power of two (checked; anything else is ROVER_ERR_INVALID).  The caller guarantees the
+ * equality: isaac_rover_orbit_amd/terrain.py quantises generated terrain to 2^-13 m and looks for an exact quantum
+ * (2^-13 ... 2^-8 m) for ingested terrain.  Halves the bytes the scan kernel stages per env; results are bit-identical
  * to the fp32 array.  NULL switches back to fp32.  No reference counterpart (the reference ray-casts a mesh with Warp). */
 int rover_set_terrain_q16(rover_sim *sim, const int16_t *height_q, float q_scale);
 

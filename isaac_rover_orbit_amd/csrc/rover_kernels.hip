@@ -1881,7 +1881,9 @@ int rover_set_terrain_q16(rover_sim *sim, const int16_t *height_q, float q_scale
         configure_tile(sim, 4);
         return ROVER_OK;
     }
-    if (!(q_scale > 0.0f)) return fail(ROVER_ERR_INVALID, "q_scale must be > 0");
+    int q_exp = 0;
+    if (!(q_scale > 0.0f) || frexpf(q_scale, &q_exp) != 0.5f)   // the kernel scales once, after interpolating the raw integers
+        return fail(ROVER_ERR_INVALID, "q_scale must be a positive power of two");
     sim->p.height_q = height_q;
     sim->p.q_scale = q_scale;
     configure_tile(sim, 8);

@@ -259,9 +259,8 @@ class RoverEnv(RLTaskEnv):
             self._height_q_dev = None
             q16 = terrain.height_q16() if getattr(self.cfg, "use_int16_terrain", True) else None
             if q16 is not None:     # exact 16-bit copy for the ray-caster kernel (half the staged bytes, same results)
-                from ..terrain import Q16_SCALE
-                self._height_q_dev = torch.from_numpy(q16).to(dev)
-                _lib.check(self._lib.rover_set_terrain_q16(h, _ptr(self._height_q_dev), float(Q16_SCALE)), "rover_set_terrain_q16")
+                self._height_q_dev = torch.from_numpy(q16[0]).to(dev)
+                _lib.check(self._lib.rover_set_terrain_q16(h, _ptr(self._height_q_dev), q16[1]), "rover_set_terrain_q16")
             n = self.num_envs
             self.state = torch.zeros(_lib.STATE_WORDS, n, dtype=torch.float32, device=dev)
             self.state[_lib.QUAT] = 1.0

@@ -20,7 +20,8 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-Q16_SCALE = 2.0 ** -13     # height quantum (0.122 mm) of terrains that have an exact int16 copy (|h| < 4 m)
+Q16_SCALE = 2.0 ** -13     # height quantum (0.122 mm) of the procedural terrains: exact int16 copy for |h| < 4 m
+Q16_SCALES = tuple(2.0 ** -e for e in (13, 12, 11, 10, 9, 8))   # quanta tried for an exact int16 copy (+-4 m ... +-128 m)
 RESOLUTION = 0.05          # terrain_utils.py:108
 GRADIENT_THRESHOLD = 0.3   # terrain_utils.py:109
 SPAWN_SEED = 41            # terrain_utils.py:124
@@ -226,15 +227,19 @@ class Terrain:
     def shape(self):
         return self.height.shape
 
-    def height_q16(self, scale: float = Q16_SCALE):
-        """int16 array q with ``height == q * scale`` EXACTLY, or None when the terrain is not representable that way
-        (arbitrary ingested meshes, |h| >= 4 m).  The ray-caster kernel stages this copy (half the bytes) when it exists."""
-        q = self.height.astype(np.float64) / scale
-        if not np.all(q == np.rint(q)) or np.abs(q).max() > 32767:
-            return None
-        q16 = q.astype(np.int16)
-        assert np.array_equal(q16.astype(np.float32) * np.float32(scale), self.height)
-        return q16
+    def height_q16(self, scales=None):
+        """``(q, scale)`` with an int16 array q such that ``height == q * scale`` EXACTLY for a power-of-two ``scale``
+        (2^-13 m ... 2^-8 m, i.e. a range of +-4 m ... +-128 m), or None when the terrain is not representable that way
+        (arbitrary ingested meshes that were not snapped with ``quantize_heights``).  The ray-caster kernel stages this copy
+        (half the bytes) when it exists; results are bit-identical either way."""
+        h64 = self.height.astype(np.float64)
+        for scale in (scales or Q16_SCALES):
+            q = h64 / scale
+            if np.abs(q).max() <= 32767 and np.all(q == np.rint(q)):
+                q16 = q.astype(np.int16)
+                assert np.array_equal(q16.astype(np.float32) * np.float32(scale), self.height)
+                return q16, float(scale)
+        return None
 
     def make_spawns(self, n_spawns: int, seed=SPAWN_SEED, border_offset=SPAWN_BORDER_M) -> np.ndarray:
         """Spawn table of the reference: ``n_spawns = 2 * num_envs`` (terrain_utils.py:123-124)."""
@@ -279,10 +284,13 @@ def make_procedural_terrain(shape=(2048, 2048), seed=1234, sigma_z=0.15, n_rocks
     return Terrain(ground=ground, obstacle=rocks, backend=backend)
 
 
-def terrain_from_mesh(vertices, faces, ground_vertices=None, ground_faces=None, backend: str = "numpy") -> Terrain:
+def terrain_from_mesh(vertices, faces, ground_vertices=None, ground_faces=None, backend: str = "numpy",
+                      quantize: float | None = None) -> Terrain:
     """Ingest triangle meshes the way ``TerrainManager.__init__`` does (terrain_utils.py:92-127): the merged
     (hidden) mesh gives the heightmap; an optional ground-only mesh of the same extent (``terrain_only.usd``) gives
     the ground layer, and the obstacle layer is their positive difference.  Without it the terrain has no obstacles.
+    ``quantize`` (a power of two, e.g. ``2 ** -12``) snaps the heights to that quantum -- a deviation of at most half a
+    quantum from the mesh -- which gives the terrain an exact int16 copy for the ray-caster kernel.
     """
     if backend == "hip":
         from . import terrain_hip
@@ -293,9 +301,13 @@ def terrain_from_mesh(vertices, faces, ground_vertices=None, ground_faces=None, 
     else:
         to_hm = mesh_to_heightmap
     hm, min_x, min_y, _, _ = to_hm(vertices, faces)
+    if quantize is not None:
+        hm = quantize_heights(hm, quantize)
     if ground_vertices is None:
         return Terrain(ground=hm, obstacle=np.zeros_like(hm), min_x=float(min_x), min_y=float(min_y), backend=backend)
     gm, gx, gy, _, _ = to_hm(ground_vertices, ground_faces)
+    if quantize is not None:
+        gm = quantize_heights(gm, quantize)
     if gm.shape != hm.shape or abs(gx - min_x) > 1e-6 or abs(gy - min_y) > 1e-6:
         raise ValueError("ground mesh and merged mesh must cover the same extent")
     obstacle = np.maximum(hm - gm, 0.0).astype(np.float32)

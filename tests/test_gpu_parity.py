@@ -73,7 +73,7 @@ def test_int16_and_fp32_terrain_paths_agree(oracle):
     representable in int16 silently uses the fp32 path."""
     from isaac_rover_orbit_amd import terrain as T
     ter = small_procedural()
-    assert ter.height_q16() is not None
+    assert ter.height_q16() is not None and ter.height_q16()[1] == 2.0 ** -13
     env_q = make_env(300, ter)
     env_f = make_env(300, ter, use_int16_terrain=False)
     assert env_q._height_q_dev is not None and env_f._height_q_dev is None
@@ -94,6 +94,18 @@ def test_int16_and_fp32_terrain_paths_agree(oracle):
     env.reset()
     ocfg, oter = oracle_side(oracle, env)
     assert_close(env.height_scan().cpu().numpy(), oracle.height_scan(ocfg, oter, state_np(env)), 0, 0, "fp32 terrain scan")
+    env.close()
+    # tall terrain (+-11 m): not representable at 2^-13 m, exact at a coarser power of two -> still the int16 path
+    tall = T.Terrain(ground=T.quantize_heights(raw.ground * 30.0, 2.0 ** -11), obstacle=T.quantize_heights(raw.obstacle, 2.0 ** -11))
+    q = tall.height_q16()
+    assert np.abs(tall.height).max() > 4.0 and q is not None and q[1] == 2.0 ** -11
+    env = make_env(200, tall)
+    assert env._height_q_dev is not None
+    env.reset()
+    ocfg, oter = oracle_side(oracle, env)
+    assert_close(env.height_scan().cpu().numpy(), oracle.height_scan(ocfg, oter, state_np(env)), 0, 0, "int16 scan, 2^-11 m quantum")
+    assert env._lib.rover_set_terrain_q16(env._h, env._height_q_dev.data_ptr(), 0.003) != 0    # not a power of two
+    assert b"power of two" in env._lib.rover_last_error()
     env.close()
 
 

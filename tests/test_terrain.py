@@ -1,4 +1,6 @@
 """Init-time terrain producers against the reference's outputs (tests/golden/heightmap.npz)."""
+import os
+
 import numpy as np
 
 from isaac_rover_orbit_amd import terrain as T
@@ -74,3 +76,21 @@ def test_terrain_from_mesh_roundtrip(golden_dir):
     h = np.load(f"{golden_dir}/heightmap.npz")
     t = T.terrain_from_mesh(h["wavy_vertices"], h["wavy_faces"])
     assert np.array_equal(t.height, h["wavy_heightmap"]) and (t.obstacle == 0).all()
+
+
+def test_exact_int16_copy_and_mesh_quantisation():
+    """height_q16 finds the finest power-of-two quantum that represents the terrain exactly (or none); terrain_from_mesh
+    can snap an ingested mesh to such a quantum (deviation <= half a quantum)."""
+    from isaac_rover_orbit_amd import terrain as T
+    ter = T.make_procedural_terrain((256, 256), seed=3, n_rocks=4)
+    q, scale = ter.height_q16()
+    assert scale == 2.0 ** -13 and q.dtype == np.int16 and np.array_equal(q.astype(np.float32) * np.float32(scale), ter.height)
+    assert T.make_procedural_terrain((256, 256), seed=3, n_rocks=4, quantize=False).height_q16() is None
+    tall = T.Terrain(ground=T.quantize_heights(ter.ground * 40.0, 2.0 ** -10), obstacle=np.zeros_like(ter.ground),
+                     rock_mask=np.zeros(ter.shape, np.uint8), safe_rock_mask=np.zeros(ter.shape, np.uint8))
+    assert np.abs(tall.height).max() > 16.0 and tall.height_q16()[1] == 2.0 ** -10
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "heightmap.npz"))
+    raw = T.terrain_from_mesh(g["wavy_vertices"], g["wavy_faces"])
+    snap = T.terrain_from_mesh(g["wavy_vertices"], g["wavy_faces"], quantize=2.0 ** -12)
+    cov = raw.height > -99
+    assert np.abs(snap.height[cov] - raw.height[cov]).max() <= 2.0 ** -13 and snap.height_q16() is not None
