@@ -127,6 +127,8 @@ def random_rover_spawns(rock_mask: np.ndarray, heightmap: np.ndarray, n_spawns: 
     max_xy = int(min(height, width) - min_xy)
     assert max_xy < width and max_xy < height
     assert max_xy > min_xy, "terrain smaller than twice the spawn border"
+    if np.all(rock_mask[min_xy:max_xy, min_xy:max_xy] != 0):   # the reference would spin forever in the loop below
+        raise ValueError("no rock-free cell inside the spawn border: cannot build a spawn table")
     out = np.zeros((n_spawns, 3), dtype=np.float32)
     for i in range(n_spawns):
         while True:

@@ -96,7 +96,9 @@ def test_int16_and_fp32_terrain_paths_agree(oracle):
     assert_close(env.height_scan().cpu().numpy(), oracle.height_scan(ocfg, oter, state_np(env)), 0, 0, "fp32 terrain scan")
     env.close()
     # tall terrain (+-11 m): not representable at 2^-13 m, exact at a coarser power of two -> still the int16 path
-    tall = T.Terrain(ground=T.quantize_heights(raw.ground * 30.0, 2.0 ** -11), obstacle=T.quantize_heights(raw.obstacle, 2.0 ** -11))
+    zero = np.zeros(raw.shape, np.uint8)   # masks given explicitly: at 30x relief the gradient test would flag every cell as rock
+    tall = T.Terrain(ground=T.quantize_heights(raw.ground * 30.0, 2.0 ** -11), obstacle=T.quantize_heights(raw.obstacle, 2.0 ** -11),
+                     rock_mask=zero, safe_rock_mask=zero.copy())
     q = tall.height_q16()
     assert np.abs(tall.height).max() > 4.0 and q is not None and q[1] == 2.0 ** -11
     env = make_env(200, tall)
