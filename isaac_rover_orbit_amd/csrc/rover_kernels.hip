@@ -216,7 +216,7 @@ template <bool WANT_OBST>
 __device__ __forceinline__ void terrain_sample(const RvParams &p, float x, float y, float &h, float &gx, float &gy,
                                                float &obst)
 {
-    const float inv_res = 1.0f / p.res;
+    const float inv_res = p.inv_res;   // = 1.0f / p.res, computed once on the host (same IEEE division)
     float u = (x - p.min_x) * inv_res;
     float v = (y - p.min_y) * inv_res;
     u = clampf(u, 0.0f, (float)(p.W - 1));
@@ -227,7 +227,11 @@ __device__ __forceinline__ void terrain_sample(const RvParams &p, float x, float
     const float fx = u - (float)j0, fy = v - (float)i0;
     const size_t base = (size_t)i0 * p.W + j0;
     const float *q = p.height + base;
+#ifdef RV_K1_NOTERRAIN   // diagnostic build: no terrain gathers (how much memory latency do the wheels expose?)
+    const float h00 = fx * 0.01f, h01 = fy * 0.01f, h10 = 0.0f, h11 = 0.0f;
+#else
     const float h00 = q[0], h01 = q[1], h10 = q[p.W], h11 = q[p.W + 1];
+#endif
     const float dx0 = h01 - h00, dx1 = h11 - h10, dy0 = h10 - h00, dy1 = h11 - h01;
     const float hx0 = h00 + fx * dx0;
     const float hx1 = h10 + fx * dx1;
