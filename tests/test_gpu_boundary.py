@@ -47,3 +47,56 @@ def test_gym_make_and_trainer_shaped_loop():
     zero = torch.zeros(env.action_space.shape, device=env.unwrapped.device)        # 01_zero_agent.py:44-52
     env.step(zero)
     env.close()
+
+
+def test_c_abi_from_plain_cpp_matches_python_binding(tmp_path):
+    """examples/c_api_demo.cpp (no Python, no torch: hipMalloc + the C ABI) against RoverEnv on the same configuration:
+    same mean reward, same bits in the last observation."""
+    import os
+    import shutil
+    import subprocess
+    import zlib  # noqa: F401
+    import numpy as np
+    import torch
+    from isaac_rover_orbit_amd import terrain as T
+    from isaac_rover_orbit_amd.cfg import RoverEnvCfg
+    from isaac_rover_orbit_amd.envs import RoverEnv
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available on this box")
+    exe = str(tmp_path / "c_api_demo")
+    libdir = os.path.join(root, "isaac_rover_orbit_amd")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "c_api_demo.cpp"), "-o", exe, "-L" + libdir, "-lrover_hip",
+                           "-Wl,-rpath," + libdir], timeout=600)
+    n, steps = 192, 40
+    out = subprocess.run([exe, str(n), str(steps)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    fields = out.stdout.strip().split("|")
+    c_mean = float(fields[2].split()[-1])
+    c_sum = fields[3].split()[-1]
+
+    H = W = 1024
+    i = np.arange(2 * n, dtype=np.float32)
+    spawns = np.stack([np.float32(21.0) + np.float32(9.0) * i / np.float32(2 * n),
+                       np.float32(30.0) - np.float32(9.0) * i / np.float32(2 * n), np.zeros(2 * n, np.float32)], 1).astype(np.float32)
+    zero = np.zeros((H, W), np.uint8)
+    ter = T.Terrain(ground=np.zeros((H, W), np.float32), obstacle=np.zeros((H, W), np.float32), rock_mask=zero,
+                    safe_rock_mask=zero.copy(), spawn_locations=spawns)
+    cfg = RoverEnvCfg(); cfg.scene.num_envs = n; cfg.terrain.kind = "custom"; cfg.record_contact_forces = False
+    cfg.use_int16_terrain = False
+    env = RoverEnv(cfg, terrain=ter)
+    env.reset()
+    act = torch.tensor([0.8, 0.1], device="cuda").repeat(n, 1)
+    tot = 0.0
+    for _ in range(steps):
+        obs, rew, *_ = env.step(act)
+        tot += float(rew.cpu().numpy().astype(np.float64).sum())
+    raw = obs["policy"].cpu().numpy().astype(np.float32).tobytes()
+    h = 2166136261
+    for b in raw:
+        h = ((h ^ b) * 16777619) & 0xFFFFFFFF
+    assert f"{h:08x}" == c_sum, (f"{h:08x}", c_sum)
+    assert abs(tot / (n * steps) - c_mean) <= 1e-9 * max(1.0, abs(c_mean))
+    env.close()
