@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Dev tool: build the diagnostic variants of librover_hip.so that the GPU-box measurement scripts load from build/abl/
+(they travel to the GPU box with the snapshot):
+
+    STAMP     -DRV_K2_STAMP   s_memtime phase stamps in the scan kernel        (tools/k2_stamps.py)
+    K1STAMP   -DRV_K1_STAMP   s_memtime phase stamps in the group step kernel  (tools/k1_stamps.py)
+    POLSTAMP  -DPOL_STAMP     s_memtime phase stamps in the policy kernel      (tools/policy_stamps.py)
+
+    python tools/build_diag.py [STAMP K1STAMP POLSTAMP]
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from isaac_rover_orbit_amd import build as b  # noqa: E402
+
+VARIANTS = {"STAMP": ("rover_kernels.hip", "-DRV_K2_STAMP"), "K1STAMP": ("rover_kernels.hip", "-DRV_K1_STAMP"),
+            "POLSTAMP": ("policy_kernels.hip", "-DPOL_STAMP")}
+
+
+def main():
+    b.build_extension()                      # the regular objects are reused for the untouched translation units
+    out_dir = os.path.join(ROOT, "build", "abl")
+    os.makedirs(out_dir, exist_ok=True)
+    hipcc = b.hipcc_path()
+    for tag in (sys.argv[1:] or list(VARIANTS)):
+        src_name, define = VARIANTS[tag]
+        obj = os.path.join(out_dir, f"{tag}.o")
+        subprocess.check_call([hipcc, *b.FLAGS, define, "-c", "-o", obj, os.path.join(ROOT, "isaac_rover_orbit_amd", "csrc", src_name)])
+        objs = [obj if os.path.basename(s) == src_name else os.path.join(b.OBJ_DIR, os.path.splitext(os.path.basename(s))[0] + ".o")
+                for s in b.SOURCES]
+        lib = os.path.join(out_dir, f"librover_abl{tag}.so")
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])
+        print(lib)
+
+
+if __name__ == "__main__":
+    main()

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import random_policy_weights, synthetic_obs
 from isaac_rover_orbit_amd import _lib
-_lib.LIB_PATH = os.path.join(ROOT, "build", "abl", "librover_ablPOLSTAMP%s.so" % (sys.argv[1] if len(sys.argv) > 1 else ""))
+_lib.LIB_PATH = os.path.join(ROOT, "build", "abl", "librover_ablPOLSTAMP.so")   # python tools/build_diag.py POLSTAMP
 from isaac_rover_orbit_amd.policy import RoverNet
 n = 4096
 ws, bs = random_policy_weights(seed=0, scale=3.0)
