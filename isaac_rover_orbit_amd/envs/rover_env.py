@@ -406,6 +406,25 @@ class RoverEnv(RLTaskEnv):
     def set_state(self, state_aos: torch.Tensor):
         self.state.copy_(state_aos.to(self.device, torch.float32).t())
 
+    # ---- checkpoint / resume: the state words ARE the environment (the RNG is a counter-based Philox keyed by the seed,
+    # the global env id and the per-env reset counter, which is a state word), so resuming is exact
+    def state_dict(self) -> dict:
+        """Everything needed to continue bit-for-bit: state words, the last observation, the episodic log vector."""
+        return {"state": self.get_state().cpu(), "obs": self.obs_buf["policy"].detach().cpu().clone(),
+                "log": self._log.detach().cpu().clone(), "num_envs": self.num_envs,
+                "common_step_counter": int(self.common_step_counter)}
+
+    def load_state_dict(self, sd: dict):
+        """Restore a ``state_dict()`` of an env of the same size and configuration; returns the observation dict."""
+        if int(sd["num_envs"]) != self.num_envs or tuple(sd["state"].shape) != (self.num_envs, _lib.STATE_WORDS):
+            raise ValueError("checkpoint was taken from an env of a different size")
+        self.set_state(sd["state"])
+        self._log.copy_(sd["log"].to(self._log.device))
+        self._obs[self._cur].copy_(sd["obs"].to(self.device))
+        self.common_step_counter = int(sd.get("common_step_counter", 0))
+        self.obs_buf = self._obs_dicts[self._cur]
+        return self.obs_buf
+
     def render(self):
         return None
 

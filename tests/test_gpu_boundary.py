@@ -55,7 +55,6 @@ def test_c_abi_from_plain_cpp_matches_python_binding(tmp_path):
     import os
     import shutil
     import subprocess
-    import zlib  # noqa: F401
     import numpy as np
     import torch
     from isaac_rover_orbit_amd import terrain as T

@@ -438,3 +438,31 @@ def test_full_size_properties():
         assert float(env._log[13]) == float(done.sum())
     assert total_resets > 0
     env.close()
+
+
+def test_checkpoint_resume_is_exact():
+    """state_dict() / load_state_dict(): a second env restored from a mid-rollout checkpoint continues bit for bit
+    (counter-based RNG: the reset counters are state words)."""
+    ter = small_procedural()
+    env_a = make_env(300, ter)
+    env_a.reset()
+    rng = np.random.RandomState(4)
+    acts = [torch.from_numpy(rng.uniform(-1, 1, (300, 2)).astype(np.float32)).cuda() for _ in range(60)]
+    S = state_np(env_a)
+    S[:40, 51] = np.array([748], dtype=np.int32).view(np.float32)      # some envs about to time out -> resets after the restore
+    env_a.set_state(torch.from_numpy(S))
+    for a in acts[:20]:
+        env_a.step(a)
+    sd = env_a.state_dict()
+    env_b = make_env(300, ter)
+    obs_b = env_b.load_state_dict(sd)
+    assert torch.equal(obs_b["policy"], env_a.obs_buf["policy"])
+    resets = 0
+    for a in acts[20:]:
+        oa, ra, ta, ua, _ = env_a.step(a)
+        ob, rb, tb, ub, _ = env_b.step(a)
+        assert torch.equal(oa["policy"], ob["policy"]) and torch.equal(ra, rb) and torch.equal(ta, tb) and torch.equal(ua, ub)
+        resets += int((ta | ua).sum())
+    assert resets > 0 and torch.equal(env_a.get_state(), env_b.get_state())
+    assert torch.equal(env_a.episode_log_vector, env_b.episode_log_vector)
+    env_a.close(); env_b.close()
