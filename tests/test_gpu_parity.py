@@ -466,3 +466,40 @@ def test_checkpoint_resume_is_exact():
     assert resets > 0 and torch.equal(env_a.get_state(), env_b.get_state())
     assert torch.equal(env_a.episode_log_vector, env_b.episode_log_vector)
     env_a.close(); env_b.close()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_random_configurations_match_oracle(oracle, seed):
+    """Config fuzz: ray pattern (3 x 3 ... 45 x 37 rays, 0.05-0.25 m spacing: one to three rays per thread, windows from
+    a few cells to the LDS limit), decimation, solver iterations, friction, reset mode, thresholds, episode length and both
+    step-kernel mappings -- 12 closed-loop steps, bit-exact against the oracle."""
+    from isaac_rover_orbit_amd.cfg import RoverEnvCfg
+    from isaac_rover_orbit_amd.envs import RoverEnv
+    rng = np.random.RandomState(100 + seed)
+    ter = small_procedural()
+    n = int(rng.choice([37, 200, 333]))
+    ter.make_spawns(2 * n)
+    cfg = RoverEnvCfg()
+    cfg.scene.num_envs = n
+    cfg.terrain.kind = "custom"
+    res = float(rng.choice([0.05, 0.1, 0.2, 0.25]))
+    nx, ny = int(rng.randint(3, 46)), int(rng.randint(3, 38))
+    while (nx - 1) * res > 4.4 or (ny - 1) * res > 4.4:           # keep the tile inside the 64 KiB LDS limit
+        nx, ny = max(3, nx - 3), max(3, ny - 3)
+    cfg.height_scanner.resolution, cfg.height_scanner.size = res, (round((nx - 1) * res, 6), round((ny - 1) * res, 6))
+    cfg.decimation = int(rng.randint(1, 9))
+    cfg.solver_iterations = int(rng.randint(1, 21))
+    cfg.friction = float(rng.uniform(0.3, 1.0))
+    cfg.reset_velocities = str(rng.choice(["reference", "zero"]))
+    cfg.step_mapping = str(rng.choice(["lane", "group"]))
+    cfg.episode_length_s = float(rng.choice([0.8, 2.0, 150.0]))      # short episodes force time-outs inside the rollout
+    thr = float(rng.uniform(0.1, 3.0))
+    cfg.terminations["is_success"].params["threshold"] = thr
+    cfg.rewards["reached_target"].params["threshold"] = thr
+    cfg.use_int16_terrain = bool(rng.randint(0, 2))
+    env = RoverEnv(cfg, terrain=ter)
+    assert env.num_rays == nx * ny, (env.num_rays, nx, ny, res)
+    actions = rng.uniform(-1, 1, (12, n, 2)).astype(np.float32)
+    flips = rollout_compare(oracle, env, 12, actions, 0.0, 0.0, resync=False)
+    assert flips == 0
+    env.close()
