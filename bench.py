@@ -191,7 +191,7 @@ def main():
             ro.step(ocfg, oter, S, acts[0])
             ro.step(ocfg, oter, S, acts[1])
             per = (time.perf_counter() - t0) / 2
-            m = int(max(4, min(400, args.cpu_seconds / max(per, 1e-6))))
+            m = int(max(4, min(4000, args.cpu_seconds / max(per, 1e-6))))   # ~15 s of CPU work by default
             t0 = time.perf_counter()
             for k in range(m):
                 ro.step(ocfg, oter, S, acts[k % 64])
