@@ -187,14 +187,13 @@ def main():
             S = ro.new_state(n)
             ro.reset_all(ocfg, oter, S)
             acts = actions[:64].cpu().numpy()
-            t0 = time.perf_counter()
-            ro.step(ocfg, oter, S, acts[0])
+            ro.step(ocfg, oter, S, acts[0])            # warm-up (thread pool, page faults)
             ro.step(ocfg, oter, S, acts[1])
-            per = (time.perf_counter() - t0) / 2
-            m = int(max(4, min(4000, args.cpu_seconds / max(per, 1e-6))))   # ~15 s of CPU work by default
             t0 = time.perf_counter()
-            for k in range(m):
-                ro.step(ocfg, oter, S, acts[k % 64])
+            m = 0
+            while m < 4000 and (m < 4 or time.perf_counter() - t0 < args.cpu_seconds):   # bounded sample: ~cpu_seconds of CPU work
+                ro.step(ocfg, oter, S, acts[m % 64])
+                m += 1
             dt = time.perf_counter() - t0
             out["cpu_baseline"] = {"value": n * m / dt, "unit": "env-steps/s", "cores": int(ro.lib().rvo_num_threads()),
                                    "kind": "port",
