@@ -133,7 +133,7 @@ def main():
                 "whole_step_frac": (scan_b + dyn_b) * value / world / 1e9 / HBM_PEAK_GBS, "kernels": kernels}
 
     out = {
-        "metric": "env-steps/sec AAURoverEnv-v0 @ num_envs=4096", "value": value, "unit": "env-steps/s",
+        "metric": "env-steps/sec AAURoverEnv-v0 @ num_envs=4096; 1/2/4/8 MI355X", "value": value, "unit": "env-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "AAURoverEnv-v0 num_envs=%d per GPU, procedural heightfield 2048x2048 @0.05 m "
