@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-forces", action="store_true", help="do not materialise contact_sensor.force_matrix_w")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 4),
+                    help="BASELINE.json config: 2 = headline (31x31 rays @0.1 m, sigma_z 0.15 m); "
+                         "4 = dense scanner stress (32x32 rays @0.05 m, sigma_z 0.4 m)")
     args = ap.parse_args()
 
     import numpy as np
@@ -70,7 +73,9 @@ def main():
     shard = rd.weak_shard(n, rank, world)
 
     # ---- workload: SURVEY 8d config 2 (procedural 2048^2 heightfield @ 0.05 m, fBm sigma_z 0.15 m seed 1234, ~400 rocks)
-    ter = T.make_procedural_terrain((2048, 2048), seed=1234, sigma_z=0.15, n_rocks=400)
+    #      or config 4 (same map generator at sigma_z 0.4 m, 32 x 32 rays at 0.05 m spacing)
+    sigma_z = 0.15 if args.config == 2 else 0.4
+    ter = T.make_procedural_terrain((2048, 2048), seed=1234, sigma_z=sigma_z, n_rocks=400)
     ter.make_spawns(2 * shard.global_num_envs, seed=41)
     cfg = RoverEnvCfg()
     cfg.scene.num_envs = n
@@ -79,6 +84,8 @@ def main():
     cfg.env_id_offset = shard.env_id_offset
     cfg.global_num_envs = shard.global_num_envs
     cfg.record_contact_forces = not args.no_forces
+    if args.config == 4:
+        cfg.height_scanner.resolution, cfg.height_scanner.size = 0.05, (1.55, 1.55)
     env = RoverEnv(cfg, terrain=ter)
 
     total = args.steps + args.warmup
@@ -106,29 +113,39 @@ def main():
         elapsed = float(t.item())
     value = shard.global_num_envs * args.steps / elapsed
 
-    # ---- roofline leg: HIP-event duration of each kernel (on the stream the kernels are launched on)
+    # ---- roofline leg: HIP-event duration of each kernel (on the stream the kernels are launched on).  An event pair
+    #      with nothing between them measures the fixed cost an interval carries (event processing + the dispatch gap);
+    #      it is subtracted so that the kernel durations agree with the rocprofv3 trace and sum to <= ms_per_step.
     ms1 = ms2 = 0.0
     ps = max(args.profile_steps, 1)
     for k in range(ps):
         a, b = env.profile_step(actions[k % n_act])
         ms1 += a
         ms2 += b
-    ms1, ms2 = ms1 / ps, ms2 / ps
+    ms1_raw, ms2_raw = ms1 / ps, ms2 / ps
+    ev_ms = env.profile_event_overhead(200)
+    ms1, ms2 = max(ms1_raw - ev_ms, 1e-6), max(ms2_raw - ev_ms, 1e-6)
     scan_b, dyn_b = algorithmic_bytes(env.num_rays)
     kernels = {
-        "rover_step_kernel": {"ms": ms1, "algorithmic_bytes": dyn_b * n, "GB/s": dyn_b * n / (ms1 * 1e-3) / 1e9},
-        "rover_scan_obs_kernel": {"ms": ms2, "algorithmic_bytes": scan_b * n, "GB/s": scan_b * n / (ms2 * 1e-3) / 1e9},
+        "rover_step_kernel": {"ms": ms1, "ms_raw_events": ms1_raw, "algorithmic_bytes": dyn_b * n,
+                              "GB/s": dyn_b * n / (ms1 * 1e-3) / 1e9},
+        "rover_scan_obs_kernel": {"ms": ms2, "ms_raw_events": ms2_raw, "algorithmic_bytes": scan_b * n,
+                                  "GB/s": scan_b * n / (ms2 * 1e-3) / 1e9},
     }
     dom = max(kernels, key=lambda k: kernels[k]["ms"])
     traffic = None
+    traffic_build = None
     tr_path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tr_path):
+    if args.config == 2 and n == 4096 and os.path.exists(tr_path):
         try:
-            traffic = json.load(open(tr_path)).get(dom, {}).get("bytes_per_launch")
+            tr = json.load(open(tr_path))
+            traffic = tr.get(dom, {}).get("bytes_per_launch")
+            traffic_build = tr.get("_build")
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": kernels[dom]["GB/s"] / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": kernels[dom]["GB/s"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_build": traffic_build,
+                "event_pair_overhead_ms": ev_ms,
                 "whole_step_GB/s": (scan_b + dyn_b) * value / world / 1e9,
                 "whole_step_frac": (scan_b + dyn_b) * value / world / 1e9 / HBM_PEAK_GBS, "kernels": kernels}
 
@@ -137,7 +154,11 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "AAURoverEnv-v0 num_envs=%d per GPU, procedural heightfield 2048x2048 @0.05 m "
-                               "(fBm sigma_z 0.15 m seed 1234 + 400 rocks), random U(-1,1) actions, in-step resets" % n,
+                               "(fBm sigma_z %.2f m seed 1234 + 400 rocks), %dx%d rays @%.2f m, random U(-1,1) actions, "
+                               "in-step resets (BASELINE config %d)"
+                               % (n, sigma_z, env.cfg.height_scanner.grid[0], env.cfg.height_scanner.grid[1],
+                                  env.cfg.height_scanner.resolution, args.config),
+                   "baseline_config": args.config,
                    "num_envs_per_gpu": n, "global_num_envs": shard.global_num_envs, "rays": env.num_rays,
                    "decimation": cfg.decimation, "sim_dt": cfg.sim.dt, "solver_iterations": cfg.solver_iterations,
                    "contact_forces_materialised": cfg.record_contact_forces, "parallelism": f"env-shard x{world}"},
@@ -145,6 +166,9 @@ def main():
     }
 
     # ---- RCCL rollout gather (BASELINE config 3): one 60-step rollout shard of observations, not in `value`
+    if world > 1 and not nccl:
+        out["rollout_gather"] = None
+        out["rollout_gather_skipped"] = f"backend is {dist.get_backend()}, not nccl (RCCL): CPU rehearsal"
     if world > 1 and nccl:
         try:
             T_roll = 60
@@ -169,7 +193,8 @@ def main():
         except Exception as e:  # the extra leg must never take the headline number down
             out["rollout_gather"] = {"failed": repr(e)}
 
-    # ---- CPU baseline: the oracle (a port, test infrastructure) on a bounded sample of the same workload
+    # ---- CPU baseline: the oracle (a port, test infrastructure) on a bounded sample of the same workload.  Its action
+    #      rows are its own (host RNG), independent of --steps / --warmup.
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             from oracle import rover_oracle as ro
@@ -184,23 +209,32 @@ def main():
                     setattr(ocfg, name, v)
             oter = ro.TerrainData(ter.height, ter.obstacle, ter.safe_rock_mask, ter.resolution, ter.min_x, ter.min_y,
                                   ter.spawn_locations)
-            S = ro.new_state(n)
-            ro.reset_all(ocfg, oter, S)
-            acts = actions[:64].cpu().numpy()
-            ro.step(ocfg, oter, S, acts[0])            # warm-up (thread pool, page faults)
-            ro.step(ocfg, oter, S, acts[1])
-            t0 = time.perf_counter()
-            m = 0
-            while m < 4000 and (m < 4 or time.perf_counter() - t0 < args.cpu_seconds):   # bounded sample: ~cpu_seconds of CPU work
-                ro.step(ocfg, oter, S, acts[m % 64])
-                m += 1
-            dt = time.perf_counter() - t0
-            out["cpu_baseline"] = {"value": n * m / dt, "unit": "env-steps/s", "cores": int(ro.lib().rvo_num_threads()),
-                                   "kind": "port",
-                                   "sample": f"{m} steps of the same N={n} workload on the C oracle (OpenMP), {dt:.1f} s",
-                                   "host_cpus": os.cpu_count()}
+            acts = np.random.RandomState(1234).uniform(-1.0, 1.0, (64, n, 2)).astype(np.float32)
+
+            def cpu_leg(threads, n_sub, seconds, max_steps):
+                ro.set_num_threads(threads)
+                S = ro.new_state(n_sub)
+                ro.reset_all(ocfg, oter, S)
+                ro.step(ocfg, oter, S, acts[0][:n_sub])            # warm-up (thread pool, page faults)
+                ro.step(ocfg, oter, S, acts[1][:n_sub])
+                t0 = time.perf_counter()
+                m = 0
+                while m < max_steps and (m < 4 or time.perf_counter() - t0 < seconds):
+                    ro.step(ocfg, oter, S, acts[m % len(acts)][:n_sub])
+                    m += 1
+                return m, time.perf_counter() - t0
+
+            host = os.cpu_count() or 1
+            n_thr = int(ro.max_threads())
+            n1 = min(n, 512)                                   # single thread: the first 512 envs of the workload
+            m1, dt1 = cpu_leg(1, n1, args.cpu_seconds / 3.0, 400)
+            mN, dtN = cpu_leg(n_thr, n, args.cpu_seconds * 2.0 / 3.0, 4000)
+            out["cpu_baseline"] = {"value": n * mN / dtN, "unit": "env-steps/s", "cores": n_thr, "kind": "port",
+                                   "sample": f"{mN} steps of the same N={n} workload on the C oracle (OpenMP, {n_thr} threads), "
+                                             f"{dtN:.1f} s; single thread: {m1} steps of its first {n1} envs, {dt1:.1f} s",
+                                   "single_thread_value": n1 * m1 / dt1, "host_cpus": host}
         except Exception as e:  # the baseline must never take the bench down
-            out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+            out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
 
     env.close()
     if rank == 0:

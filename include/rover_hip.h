@@ -116,6 +116,20 @@ int rover_bind(rover_sim *sim, float *state, void *workspace, size_t workspace_b
  * the first observation.  obs: (num_envs, 4 + scan_nx * scan_ny) fp32 row-major. */
 int rover_reset(rover_sim *sim, float *obs, void *stream);
 
+/* RLTaskEnv._reset_idx(env_ids) with the reference's recorded torch draws INJECTED in place of the Philox draws (same
+ * code path as the in-step reset): the envs whose `mask` byte is non-zero (NULL = every env) take spawn table row
+ * spawn_row[e] (randomizations.py:22 `randperm(len(table))[:k]`), yaw = yaw_u[e] * 2 pi (:30), the target angles
+ * theta_u[e * max_target_tries + j] * 2 pi of rejection round j (terrain_importer.py:143-169) and heading command
+ * heading_u[e] * (hi - lo) + lo (:93-95); then _update_command and the observation rows of ALL envs.  This is the parity
+ * protocol for reset outcomes (torch's RNG stream cannot be reproduced; tests/golden/reset.npz holds the draws).
+ * All arrays are device pointers with one entry (row) per env. */
+int rover_reset_with_draws(rover_sim *sim, const uint8_t *mask, const int32_t *spawn_row, const float *yaw_u,
+                           const float *theta_u, const float *heading_u, float *obs, void *stream);
+
+/* Replaces env.seed(seed) / reset(seed=...) (gymnasium contract): new key of the counter-based RNG used by the resets
+ * that follow.  Host only, takes effect with the next launch. */
+int rover_set_seed(rover_sim *sim, uint32_t seed_lo, uint32_t seed_hi);
+
 /* Replaces RoverEnv.step (rover_env.py:42-102), including the in-step reset of finished envs (_reset_idx :27-39,
  * reset_root_state_rover randomizations.py:12-39, TerrainBasedPositionCommand._resample_command
  * terrain_importer.py:74-95) and the command / observation managers.
@@ -140,14 +154,26 @@ int rover_profile_step(rover_sim *sim, const float *action, float *obs, float *r
                        uint8_t *truncated, float *force, float *log, void *stream, float *ms_step_kernel,
                        float *ms_scan_kernel);
 
+/* Average elapsed time (ms) of an event pair with nothing recorded between the two events: the fixed cost each interval of
+ * rover_profile_step carries; bench.py subtracts it.  Synchronises -- measurement only. */
+int rover_profile_event_overhead(rover_sim *sim, void *stream, int32_t reps, float *ms);
+
 /* Unit entry points used by the parity tests (same kernels' device functions, one env per lane):
  *   rover_ackermann      -- AckermannAction2.process_actions + ackermann (ackermann_actions.py:226-322)
  *                           steer (n,4) [FL,RL,RR,FR], wheel (n,6) [ML,FL,RL,RR,MR,FR] as the reference stacks them
  *   rover_height_scan    -- RayCaster + height_scan_rover (rover_env_cfg.py:78-86, observations.py:35-45) for the
  *                           bound state; scan (num_envs, rays)
  *   rover_physics        -- `substeps` x (write_data_to_sim, sim.step, scene.update) (rover_env.py:64-72) on the bound
- *                           state with explicit joint targets in MODEL order (steer FL,FR,RL,RR; wheels FL,FR,CL,CR,RL,RR) */
+ *                           state with explicit joint targets in MODEL order (steer FL,FR,RL,RR; wheels FL,FR,CL,CR,RL,RR)
+ *   rover_mdp_terms      -- the term functions of the step kernel's tail on caller-supplied rows (device pointers):
+ *                           3 observation / 7 reward / 3 termination terms + mdp.time_out (observations.py:15-32,
+ *                           rewards.py:14-137, terminations.py:14-64); cmd_b (n,3), action / prev_action (n,2),
+ *                           ep_len (n,) int32, force (n,13,3) -> obs_distance, obs_angle (n,), rew (n,7) unweighted,
+ *                           term (n,4) u8 [time_out, is_success, far_from_target, collision] */
 int rover_ackermann(rover_sim *sim, int32_t n, const float *raw, float *processed, float *steer, float *wheel, void *stream);
+int rover_mdp_terms(rover_sim *sim, int32_t n, const float *cmd_b, const float *action, const float *prev_action,
+                    const int32_t *ep_len, const float *force, float *obs_distance, float *obs_angle, float *rew,
+                    uint8_t *term, void *stream);
 int rover_height_scan(rover_sim *sim, float *scan, void *stream);
 int rover_physics(rover_sim *sim, const float *steer_target, const float *wheel_target, int32_t substeps, float *force,
                   void *stream);

@@ -20,7 +20,8 @@ CMD_B, HEADING_CMD_B, EP_SUM, METRIC_POS, METRIC_HEAD, LAMBDA_N, RESET_COUNT = 5
 
 EXPORTS = [
     "rover_default_config", "rover_create", "rover_destroy", "rover_set_terrain", "rover_set_terrain_q16", "rover_workspace_bytes", "rover_bind",
-    "rover_reset", "rover_step", "rover_profile_step", "rover_ackermann", "rover_height_scan", "rover_physics", "rover_model_constants",
+    "rover_reset", "rover_reset_with_draws", "rover_set_seed", "rover_step", "rover_profile_step",
+    "rover_profile_event_overhead", "rover_mdp_terms", "rover_ackermann", "rover_height_scan", "rover_physics", "rover_model_constants",
     "rover_state_words", "rover_config_bytes", "rover_last_error", "rover_version",
     "rover_terrain_rasterize", "rover_terrain_rock_mask", "rover_terrain_scratch_bytes",   # include/rover_terrain.h
     "rover_policy_default_desc", "rover_policy_packed_floats", "rover_policy_pack", "rover_policy_forward",  # rover_policy.h
@@ -108,6 +109,10 @@ def load():
     lib.rover_workspace_bytes.restype = C.c_size_t
     lib.rover_bind.argtypes = [vp, vp, vp, C.c_size_t]
     lib.rover_reset.argtypes = [vp, vp, vp]
+    lib.rover_reset_with_draws.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.rover_set_seed.argtypes = [vp, C.c_uint32, C.c_uint32]
+    lib.rover_profile_event_overhead.argtypes = [vp, vp, i32, C.POINTER(C.c_float)]
+    lib.rover_mdp_terms.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.rover_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.rover_profile_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.rover_ackermann.argtypes = [vp, i32, vp, vp, vp, vp, vp]

@@ -874,28 +874,40 @@ __device__ __forceinline__ void physics_substep_group(const RvParams &p, const S
 }
 
 // ------------------------------------------------------------------------------------------------ (a7, a8) reset
+// Injected draws (rover_reset_with_draws): the uniforms the reference drew from torch's generator (recorded in
+// tests/golden/reset.npz) take the place of the Philox draws -- same code path otherwise.
+struct ResetDraws {
+    int32_t spawn_row;     // randomizations.py:22   randperm(len(table))[:k]
+    float yaw_u;           // :30                    rand(k)
+    const float *theta_u;  // terrain_importer.py:169 rand(len(env_ids)) of every rejection round, in order
+    float heading_u;       // :93-95                 uniform_(lo, hi) = u * (hi - lo) + lo
+};
+
 // target on the 9 m circle with rejection on the safe rock mask (terrain_importer.py:134-175), heading ~ U(lo, hi)
-__device__ __forceinline__ void resample_command(const RvParams &p, float *S, uint32_t gid, uint32_t count, float heading_u)
+__device__ __forceinline__ void resample_command(const RvParams &p, float *S, uint32_t gid, uint32_t count, float heading_u,
+                                                 const float *inj_theta = nullptr)
 {
     const rover_config &c = p.cfg;
     float tx = 0.0f, ty = 0.0f;
     int tries = 0;
     bool done = false;
-    for (uint32_t blk = 1; !done; ++blk) {
-        uint32_t r[4];
-        philox4x32(gid, count, blk, 0u, c.seed_lo, c.seed_hi, r);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (!done) {
-                const float theta = u01(r[i]) * 2.0f * RV_PI_F;
-                tx = rv_cosf(theta) * c.target_distance + S[ROVER_ENV_ORIGIN + 0];
-                ty = rv_sinf(theta) * c.target_distance + S[ROVER_ENV_ORIGIN + 1];
-                int cx, cy;
-                quirk_cell(p, tx, ty, cx, cy);
-                ++tries;
-                if (p.safe_mask[(size_t)cy * p.W + cx] != 1 || tries >= c.max_target_tries) done = true;
-            }
+    uint32_t r[4] = {0u, 0u, 0u, 0u};
+    while (!done) {
+        float u;
+        if (inj_theta) {
+            u = inj_theta[tries];
+        } else {
+            if ((tries & 3) == 0) philox4x32(gid, count, 1u + (uint32_t)(tries >> 2), 0u, c.seed_lo, c.seed_hi, r);
+            const int w = tries & 3;
+            u = u01(w == 0 ? r[0] : (w == 1 ? r[1] : (w == 2 ? r[2] : r[3])));
         }
+        const float theta = u * 2.0f * RV_PI_F;
+        tx = rv_cosf(theta) * c.target_distance + S[ROVER_ENV_ORIGIN + 0];
+        ty = rv_sinf(theta) * c.target_distance + S[ROVER_ENV_ORIGIN + 1];
+        int cx, cy;
+        quirk_cell(p, tx, ty, cx, cy);
+        ++tries;
+        if (p.safe_mask[(size_t)cy * p.W + cx] != 1 || tries >= c.max_target_tries) done = true;
     }
     int cx, cy;
     quirk_cell(p, tx, ty, cx, cy);
@@ -907,16 +919,16 @@ __device__ __forceinline__ void resample_command(const RvParams &p, float *S, ui
 }
 
 // reset_root_state_rover (randomizations.py:12-39) + ORBIT manager resets (RLTaskEnv._reset_idx)
-__device__ __forceinline__ void reset_one(const RvParams &p, float *S, uint32_t gid)
+__device__ __forceinline__ void reset_one(const RvParams &p, float *S, uint32_t gid, const ResetDraws *inj = nullptr)
 {
     const rover_config &c = p.cfg;
     const uint32_t count = __float_as_uint(S[ROVER_RESET_COUNT]);
     uint32_t r[4];
     philox4x32(gid, count, 0u, 0u, c.seed_lo, c.seed_hi, r);
-    const uint32_t row = r[0] % (uint32_t)p.n_spawns;
+    const uint32_t row = inj ? (uint32_t)inj->spawn_row : r[0] % (uint32_t)p.n_spawns;
     const float px = p.spawns[3 * row + 0], py = p.spawns[3 * row + 1];
     const float pz = p.spawns[3 * row + 2] + c.reset_z_offset;
-    const float angle = u01(r[1]) * 2.0f * RV_PI_F;
+    const float angle = (inj ? inj->yaw_u : u01(r[1])) * 2.0f * RV_PI_F;
     S[ROVER_POS + 0] = px; S[ROVER_POS + 1] = py; S[ROVER_POS + 2] = pz;
     S[ROVER_QUAT + 0] = rv_cosf(angle / 2.0f); S[ROVER_QUAT + 1] = 0.0f; S[ROVER_QUAT + 2] = 0.0f;
     S[ROVER_QUAT + 3] = rv_sinf(angle / 2.0f);
@@ -933,7 +945,7 @@ __device__ __forceinline__ void reset_one(const RvParams &p, float *S, uint32_t 
     for (int i = 0; i < ROVER_NUM_REW; ++i) S[ROVER_EP_SUM + i] = 0.0f;
     S[ROVER_METRIC_POS] = 0.0f;
     S[ROVER_METRIC_HEAD] = 0.0f;
-    resample_command(p, S, gid, count, u01(r[2]));
+    resample_command(p, S, gid, count, inj ? inj->heading_u : u01(r[2]), inj ? inj->theta_u : nullptr);
     S[ROVER_EP_LEN] = __int_as_float(0);
     S[ROVER_RESET_COUNT] = __uint_as_float(count + 1u);
 }
@@ -1434,16 +1446,29 @@ __global__ __launch_bounds__(64) void rover_physics_kernel_group(RvParams p, flo
     }
 }
 
-// reset of every env (env.reset()): reset_one + _update_command, no physics
-__global__ __launch_bounds__(64) void rover_reset_kernel(RvParams p, float *__restrict__ state)
+// reset of every env (env.reset()): reset_one + _update_command, no physics.  With `mask` / draws (rover_reset_with_draws):
+// RLTaskEnv._reset_idx of the masked envs with the supplied uniforms in place of the Philox draws.
+__global__ __launch_bounds__(64) void rover_reset_kernel(RvParams p, float *__restrict__ state, const uint8_t *mask,
+                                                         const int32_t *spawn_row, const float *yaw_u, const float *theta_u,
+                                                         const float *heading_u)
 {
     const int e = blockIdx.x * 64 + threadIdx.x;
     if (e >= p.n) return;
+    if (mask && !mask[e]) return;
     const int N = p.n;
     float S[ROVER_STATE_WORDS];
 #pragma unroll
     for (int i = 0; i < ROVER_STATE_WORDS; ++i) S[i] = state[(size_t)i * N + e];
-    reset_one(p, S, (uint32_t)(p.env_id_offset + e));
+    if (spawn_row) {
+        ResetDraws d;
+        d.spawn_row = spawn_row[e];
+        d.yaw_u = yaw_u[e];
+        d.theta_u = theta_u + (size_t)e * p.cfg.max_target_tries;
+        d.heading_u = heading_u[e];
+        reset_one(p, S, (uint32_t)(p.env_id_offset + e), &d);
+    } else {
+        reset_one(p, S, (uint32_t)(p.env_id_offset + e));
+    }
     update_command_one(S + ROVER_POS, S + ROVER_QUAT, S + ROVER_TARGET_W, S[ROVER_HEADING_CMD_W], S + ROVER_CMD_B,
                        S + ROVER_HEADING_CMD_B);
 #pragma unroll
@@ -1707,6 +1732,27 @@ __global__ void rover_ackermann_kernel(rover_config c, int n, const float *raw, 
     for (int k = 0; k < 6; ++k) wheel[6 * i + k] = wh[k];
 }
 
+// the observation-head / reward / termination term functions of the step kernel's tail, one row per thread
+__global__ void rover_mdp_terms_kernel(rover_config c, int n, const float *cmd_b, const float *action, const float *prev_action,
+                                       const int32_t *ep_len, const float *force, float *obs_distance, float *obs_angle,
+                                       float *rew, uint8_t *term)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float F[ROVER_NUM_BODIES * 3];
+    for (int k = 0; k < ROVER_NUM_BODIES * 3; ++k) F[k] = force[(size_t)i * (ROVER_NUM_BODIES * 3) + k];
+    const float cb[3] = {cmd_b[3 * i], cmd_b[3 * i + 1], cmd_b[3 * i + 2]};
+    const float a[2] = {action[2 * i], action[2 * i + 1]}, pa[2] = {prev_action[2 * i], prev_action[2 * i + 1]};
+    float r[ROVER_NUM_REW];
+    bool t[ROVER_NUM_TERM];
+    mdp_terms_one(c, cb, a, pa, ep_len[i], F, r, t);
+    for (int k = 0; k < ROVER_NUM_REW; ++k) rew[(size_t)i * ROVER_NUM_REW + k] = r[k];
+    for (int k = 0; k < ROVER_NUM_TERM; ++k) term[(size_t)i * ROVER_NUM_TERM + k] = t[k] ? 1 : 0;
+    // the two observation terms as write_obs_head evaluates them, before their scales (observations.py:15-32)
+    obs_distance[i] = sqrtf(cb[0] * cb[0] + cb[1] * cb[1]);
+    obs_angle[i] = rv_atan2f(cb[1], cb[0]);
+}
+
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void rover_physics_kernel(RvParams p, float *__restrict__ state, const float *steer_t,
                                                            const float *wheel_t, int substeps, float *force)
 {
@@ -1746,6 +1792,20 @@ int fail(int code, const char *fmt, const char *detail = "")
         hipError_t _e = (expr);                                                                                        \
         if (_e != hipSuccess) return fail(ROVER_ERR_HIP, #expr ": %s", hipGetErrorString(_e));                        \
     } while (0)
+
+// Every entry point that launches work runs on the handle's device, whatever the calling thread's current device is.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
 
 }  // namespace
 
@@ -1946,11 +2006,36 @@ int rover_reset(rover_sim *sim, float *obs, void *stream)
 {
     if (int rc = ready(sim)) return rc;
     if (!obs) return fail(ROVER_ERR_INVALID, "obs is NULL");
+    DeviceGuard guard(sim->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const RvParams &p = sim->p;
-    hipLaunchKernelGGL(rover_reset_kernel, dim3((p.n + 63) / 64), dim3(64), 0, st, p, sim->state);
+    hipLaunchKernelGGL(rover_reset_kernel, dim3((p.n + 63) / 64), dim3(64), 0, st, p, sim->state, nullptr, nullptr, nullptr,
+                       nullptr, nullptr);
     launch_scan<1>(sim, p.n, st, obs, p.obs_w, 4, nullptr, 0, nullptr);
     HIP_TRY(hipGetLastError());
+    return ROVER_OK;
+}
+
+int rover_reset_with_draws(rover_sim *sim, const uint8_t *mask, const int32_t *spawn_row, const float *yaw_u,
+                           const float *theta_u, const float *heading_u, float *obs, void *stream)
+{
+    if (int rc = ready(sim)) return rc;
+    if (!spawn_row || !yaw_u || !theta_u || !heading_u || !obs) return fail(ROVER_ERR_INVALID, "NULL buffer");
+    DeviceGuard guard(sim->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const RvParams &p = sim->p;
+    hipLaunchKernelGGL(rover_reset_kernel, dim3((p.n + 63) / 64), dim3(64), 0, st, p, sim->state, mask, spawn_row, yaw_u,
+                       theta_u, heading_u);
+    launch_scan<1>(sim, p.n, st, obs, p.obs_w, 4, nullptr, 0, nullptr);
+    HIP_TRY(hipGetLastError());
+    return ROVER_OK;
+}
+
+int rover_set_seed(rover_sim *sim, uint32_t seed_lo, uint32_t seed_hi)
+{
+    if (!sim) return fail(ROVER_ERR_INVALID, "sim is NULL");
+    sim->p.cfg.seed_lo = seed_lo;
+    sim->p.cfg.seed_hi = seed_hi;
     return ROVER_OK;
 }
 
@@ -1959,6 +2044,7 @@ int rover_step(rover_sim *sim, const float *action, float *obs, float *reward, u
 {
     if (int rc = ready(sim)) return rc;
     if (!action || !obs || !reward || !terminated || !truncated || !log) return fail(ROVER_ERR_INVALID, "NULL buffer");
+    DeviceGuard guard(sim->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const RvParams &p = sim->p;
     if (sim->group_mapping)
@@ -1980,6 +2066,7 @@ int rover_profile_step(rover_sim *sim, const float *action, float *obs, float *r
     if (int rc = ready(sim)) return rc;
     if (!action || !obs || !reward || !terminated || !truncated || !log || !ms_step_kernel || !ms_scan_kernel)
         return fail(ROVER_ERR_INVALID, "NULL buffer");
+    DeviceGuard guard(sim->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const RvParams &p = sim->p;
     hipEvent_t ev[3];
@@ -2002,9 +2089,49 @@ int rover_profile_step(rover_sim *sim, const float *action, float *obs, float *r
     return ROVER_OK;
 }
 
+int rover_profile_event_overhead(rover_sim *sim, void *stream, int32_t reps, float *ms)
+{
+    // Elapsed time of an event pair with NOTHING between the two records, averaged over `reps`: the fixed cost every
+    // interval of rover_profile_step carries.  Synchronises (measurement only).
+    if (!sim || !ms || reps <= 0) return fail(ROVER_ERR_INVALID, "bad argument");
+    DeviceGuard guard(sim->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipEvent_t ev[3];
+    for (int i = 0; i < 3; ++i) HIP_TRY(hipEventCreate(&ev[i]));
+    double acc = 0.0;
+    for (int r = 0; r < reps; ++r) {
+        // three records like rover_profile_step; the middle interval pair is what a kernel-less step would report
+        HIP_TRY(hipEventRecord(ev[0], st));
+        HIP_TRY(hipEventRecord(ev[1], st));
+        HIP_TRY(hipEventRecord(ev[2], st));
+        HIP_TRY(hipEventSynchronize(ev[2]));
+        float a = 0.0f, b = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&a, ev[0], ev[1]));
+        HIP_TRY(hipEventElapsedTime(&b, ev[1], ev[2]));
+        acc += 0.5 * ((double)a + (double)b);
+    }
+    for (int i = 0; i < 3; ++i) HIP_TRY(hipEventDestroy(ev[i]));
+    *ms = (float)(acc / reps);
+    return ROVER_OK;
+}
+
+int rover_mdp_terms(rover_sim *sim, int32_t n, const float *cmd_b, const float *action, const float *prev_action,
+                    const int32_t *ep_len, const float *force, float *obs_distance, float *obs_angle, float *rew,
+                    uint8_t *term, void *stream)
+{
+    if (!sim || n <= 0 || !cmd_b || !action || !prev_action || !ep_len || !force || !obs_distance || !obs_angle || !rew || !term)
+        return fail(ROVER_ERR_INVALID, "bad argument");
+    DeviceGuard guard(sim->device);
+    hipLaunchKernelGGL(rover_mdp_terms_kernel, dim3((n + 127) / 128), dim3(128), 0, static_cast<hipStream_t>(stream), sim->p.cfg,
+                       n, cmd_b, action, prev_action, ep_len, force, obs_distance, obs_angle, rew, term);
+    HIP_TRY(hipGetLastError());
+    return ROVER_OK;
+}
+
 int rover_ackermann(rover_sim *sim, int32_t n, const float *raw, float *processed, float *steer, float *wheel, void *stream)
 {
     if (!sim || !raw || !processed || !steer || !wheel || n <= 0) return fail(ROVER_ERR_INVALID, "bad argument");
+    DeviceGuard guard(sim->device);
     hipLaunchKernelGGL(rover_ackermann_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
                        sim->p.cfg, n, raw, processed, steer, wheel);
     HIP_TRY(hipGetLastError());
@@ -2015,6 +2142,7 @@ int rover_height_scan(rover_sim *sim, float *scan, void *stream)
 {
     if (int rc = ready(sim)) return rc;
     if (!scan) return fail(ROVER_ERR_INVALID, "scan is NULL");
+    DeviceGuard guard(sim->device);
     const RvParams &p = sim->p;
     launch_scan<0>(sim, p.n, static_cast<hipStream_t>(stream), scan, p.rays, 0, nullptr, 0, nullptr);
     HIP_TRY(hipGetLastError());
@@ -2041,6 +2169,7 @@ int rover_physics(rover_sim *sim, const float *steer_target, const float *wheel_
 {
     if (int rc = ready(sim)) return rc;
     if (!steer_target || !wheel_target || substeps < 0) return fail(ROVER_ERR_INVALID, "bad argument");
+    DeviceGuard guard(sim->device);
     if (sim->group_mapping)
         hipLaunchKernelGGL(rover_physics_kernel_group, dim3((sim->p.n + 7) / 8), dim3(64), 0, static_cast<hipStream_t>(stream),
                            sim->p, sim->state, steer_target, wheel_target, substeps, force);

@@ -309,22 +309,53 @@ class RoverEnv(RLTaskEnv):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def seed(self, seed: int = -1) -> int:
-        self.cfg.seed = int(seed)
-        return seed
+        """gymnasium / ORBIT ``env.seed``: re-keys the counter-based RNG of every reset that follows (``rover_set_seed``).
+        A negative seed keeps the current key (ORBIT draws a random one there; determinism is preferred here)."""
+        seed = int(seed)
+        if seed >= 0:
+            self.cfg.seed = seed
+            lo, hi = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+            self._native_cfg.seed_lo, self._native_cfg.seed_hi = lo, hi
+            _lib.check(self._lib.rover_set_seed(self._h, lo, hi), "rover_set_seed")
+        return int(self.cfg.seed)
 
     def reset(self, seed: int | None = None, options=None):
-        """ORBIT ``RLTaskEnv.reset``: reset every env, return the first observation."""
+        """ORBIT ``RLTaskEnv.reset``: (re-seed,) reset every env, return the first observation."""
+        if seed is not None:
+            self.seed(seed)
         obs = self._obs[self._cur]
         _lib.check(self._lib.rover_reset(self._h, _ptr(obs), self._stream()), "rover_reset")
         self.obs_buf = {"policy": obs}
         return self.obs_buf, self.extras
 
-    def step(self, action: torch.Tensor):
-        """``RoverEnv.step`` (rover_env.py:42-102): two asynchronous kernel launches, no host sync."""
+    def reset_with_draws(self, mask, spawn_row, yaw_u, theta_u, heading_u):
+        """``_reset_idx`` of the masked envs with the reference's recorded torch draws injected in place of the Philox
+        draws (``rover_reset_with_draws``; parity protocol for reset outcomes, tests/golden/reset.npz)."""
+        dev, n = self.device, self.num_envs
+        mask_d = None if mask is None else torch.as_tensor(np.ascontiguousarray(mask, dtype=np.uint8), device=dev)
+        row_d = torch.as_tensor(np.ascontiguousarray(spawn_row, dtype=np.int32), device=dev)
+        yaw_d = torch.as_tensor(np.ascontiguousarray(yaw_u, dtype=np.float32), device=dev)
+        th_d = torch.as_tensor(np.ascontiguousarray(theta_u, dtype=np.float32), device=dev)
+        hd_d = torch.as_tensor(np.ascontiguousarray(heading_u, dtype=np.float32), device=dev)
+        if row_d.shape != (n,) or yaw_d.shape != (n,) or hd_d.shape != (n,) or th_d.shape != (n, self._native_cfg.max_target_tries):
+            raise ValueError("draw arrays must have one entry (theta: max_target_tries entries) per env")
+        obs = self._obs[self._cur]
+        _lib.check(self._lib.rover_reset_with_draws(self._h, _ptr(mask_d), _ptr(row_d), _ptr(yaw_d), _ptr(th_d), _ptr(hd_d),
+                                                    _ptr(obs), self._stream()), "rover_reset_with_draws")
+        torch.cuda.current_stream(dev).synchronize()      # the draw tensors are temporaries
+        self.obs_buf = {"policy": obs}
+        return self.obs_buf, self.extras
+
+    def _check_action(self, action: torch.Tensor) -> torch.Tensor:
         if action.dtype != torch.float32 or not action.is_contiguous() or action.device != self.device:
             action = action.to(device=self.device, dtype=torch.float32).contiguous()
         if action.shape != (self.num_envs, 2):
             raise ValueError(f"action must have shape ({self.num_envs}, 2), got {tuple(action.shape)}")
+        return action
+
+    def step(self, action: torch.Tensor):
+        """``RoverEnv.step`` (rover_env.py:42-102): two asynchronous kernel launches, no host sync."""
+        action = self._check_action(action)
         self._cur = (self._cur + 1) % self._nbuf
         k = self._cur
         rc = self._lib.rover_step(self._h, C.c_void_p(action.data_ptr()), self._obs_ptr[k], self._rew_ptr[k],
@@ -340,15 +371,28 @@ class RoverEnv(RLTaskEnv):
         return self.obs_buf, self.reward_buf, self.reset_terminated, self.reset_time_outs, self.extras
 
     def profile_step(self, action: torch.Tensor):
-        """``step`` with HIP-event timing of the two kernels; returns ``(ms_step_kernel, ms_scan_kernel)``.  Syncs."""
+        """``step`` (same validation and bookkeeping) with HIP-event timing of the two kernels; returns
+        ``(ms_step_kernel, ms_scan_kernel)``, event overhead included (see ``profile_event_overhead``).  Syncs."""
+        action = self._check_action(action)
         self._cur = (self._cur + 1) % self._nbuf
         k = self._cur
         a, b = C.c_float(0.0), C.c_float(0.0)
         _lib.check(self._lib.rover_profile_step(self._h, C.c_void_p(action.data_ptr()), self._obs_ptr[k], self._rew_ptr[k],
                                                 self._term_ptr[k], self._trunc_ptr[k], self._force_ptr, self._log_ptr,
                                                 self._stream(), C.byref(a), C.byref(b)), "rover_profile_step")
+        self.common_step_counter += 1
         self.obs_buf = self._obs_dicts[k]
+        self.reward_buf = self._rew[k]
+        self.reset_terminated = self._term_b[k]
+        self.reset_time_outs = self._trunc_b[k]
         return a.value, b.value
+
+    def profile_event_overhead(self, reps: int = 100) -> float:
+        """Milliseconds an empty HIP-event pair reports on the launch stream: subtract from ``profile_step`` figures."""
+        ms = C.c_float(0.0)
+        _lib.check(self._lib.rover_profile_event_overhead(self._h, self._stream(), int(reps), C.byref(ms)),
+                   "rover_profile_event_overhead")
+        return ms.value
 
     def __getattr__(self, name):
         # lazily built pointer caches (kept out of __init__ so that tensors can be swapped in tests)
@@ -376,6 +420,23 @@ class RoverEnv(RLTaskEnv):
         _lib.check(self._lib.rover_ackermann(self._h, n, _ptr(raw), _ptr(processed), _ptr(steer), _ptr(wheel),
                                              self._stream()), "rover_ackermann")
         return processed, steer, wheel
+
+    def mdp_terms(self, cmd_b, action, prev_action, ep_len, force):
+        """The step kernel's term functions on caller rows (``rover_mdp_terms``): returns ``(obs_distance, obs_angle,
+        rew (n, 7) unweighted, term (n, 4) bool [time_out, is_success, far_from_target, collision])``."""
+        dev = self.device
+        cmd_b = torch.as_tensor(cmd_b, dtype=torch.float32, device=dev).contiguous()
+        n = int(cmd_b.shape[0])
+        action = torch.as_tensor(action, dtype=torch.float32, device=dev).contiguous()
+        prev_action = torch.as_tensor(prev_action, dtype=torch.float32, device=dev).contiguous()
+        ep_len = torch.as_tensor(ep_len, device=dev).to(torch.int32).contiguous()
+        force = torch.as_tensor(force, dtype=torch.float32, device=dev).reshape(n, _lib.NUM_BODIES * 3).contiguous()
+        od, oa = torch.empty(n, device=dev), torch.empty(n, device=dev)
+        rew = torch.empty(n, _lib.NUM_REW, device=dev)
+        term = torch.empty(n, _lib.NUM_TERM, dtype=torch.uint8, device=dev)
+        _lib.check(self._lib.rover_mdp_terms(self._h, n, _ptr(cmd_b), _ptr(action), _ptr(prev_action), _ptr(ep_len), _ptr(force),
+                                             _ptr(od), _ptr(oa), _ptr(rew), _ptr(term), self._stream()), "rover_mdp_terms")
+        return od, oa, rew, term.bool()
 
     def height_scan(self) -> torch.Tensor:
         scan = torch.empty(self.num_envs, self.num_rays, device=self.device)

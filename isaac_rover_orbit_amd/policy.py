@@ -83,9 +83,12 @@ class RoverNet:
         n = int(obs.shape[0])
         if out is None:
             out = torch.empty((n, self.out_dim), dtype=torch.float32, device=obs.device)
+        if obs.device != self.packed.device or out.device != obs.device:
+            raise ValueError(f"obs / out must live on the network's device {self.packed.device}")
         stream = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
-        _lib.check(self._lib.rover_policy_forward(C.byref(self.desc), self.packed.data_ptr(), self.n_copies, obs.data_ptr(), n,
-                                                  out.data_ptr(), stream), "rover_policy_forward")
+        with torch.cuda.device(obs.device):     # the entry point launches on the thread's current device
+            _lib.check(self._lib.rover_policy_forward(C.byref(self.desc), self.packed.data_ptr(), self.n_copies, obs.data_ptr(),
+                                                      n, out.data_ptr(), stream), "rover_policy_forward")
         return out
 
     __call__ = forward

@@ -119,10 +119,15 @@ void rvo_physics_step(const rvo_config *cfg, const rvo_terrain *t, int n, float 
 
 /* ---- whole path ---------------------------------------------------------------------------------------- */
 void rvo_reset_all(const rvo_config *cfg, const rvo_terrain *t, int n, int env_id_offset, float *state, float *obs);
+/* _reset_idx with injected draws (theta_u: n x max_target_tries uniforms, consumed in order per env) */
+void rvo_reset_with_draws(const rvo_config *cfg, const rvo_terrain *t, int n, int env_id_offset, float *state,
+                          const uint8_t *mask, const int32_t *spawn_row, const float *yaw_u, const float *theta_u,
+                          const float *heading_u, float *obs);
 void rvo_step(const rvo_config *cfg, const rvo_terrain *t, int n, int env_id_offset, float *state,
               const float *action /* n x 2 */, float *obs /* n x (4 + rays) */, float *reward, uint8_t *terminated,
               uint8_t *truncated, float *force /* n x 13 x 3 */, float *log_out /* RVO_LOG_WORDS */);
 int rvo_num_threads(void);
+void rvo_set_num_threads(int n); /* 0 = OpenMP default */
 
 #ifdef __cplusplus
 }

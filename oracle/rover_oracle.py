@@ -207,6 +207,20 @@ def reset_all(cfg: Config, t: TerrainData, state, env_id_offset=0):
     return obs
 
 
+def reset_with_draws(cfg: Config, t: TerrainData, state, mask, spawn_row, yaw_u, theta_u, heading_u, env_id_offset=0):
+    """``_reset_idx`` of the masked envs with the reference's recorded torch draws injected (tests/golden/reset.npz)."""
+    assert state.dtype == np.float32 and state.flags.c_contiguous
+    n = state.shape[0]
+    mask = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+    spawn_row = np.ascontiguousarray(spawn_row, dtype=np.int32)
+    yaw_u, theta_u, heading_u = _f32(yaw_u), _f32(theta_u), _f32(heading_u)
+    assert theta_u.shape == (n, cfg.max_target_tries)
+    obs = np.zeros((n, 4 + cfg.scan_nx * cfg.scan_ny), np.float32)
+    lib().rvo_reset_with_draws(C.byref(cfg), C.byref(t.c), n, env_id_offset, _p(state), _p(mask), _p(spawn_row), _p(yaw_u),
+                               _p(theta_u), _p(heading_u), _p(obs))
+    return obs
+
+
 def step(cfg: Config, t: TerrainData, state, action, env_id_offset=0, log=None):
     assert state.dtype == np.float32 and state.flags.c_contiguous
     action = _f32(action)
@@ -220,6 +234,17 @@ def step(cfg: Config, t: TerrainData, state, action, env_id_offset=0, log=None):
     lib().rvo_step(C.byref(cfg), C.byref(t.c), n, env_id_offset, _p(state), _p(action), _p(obs), _p(reward),
                    _p(terminated), _p(truncated), _p(force), _p(log))
     return obs, reward, terminated, truncated, force, log
+
+
+def set_num_threads(n: int):
+    """Threads of the OpenMP loops (0 = the OpenMP default = all host cores)."""
+    lib().rvo_set_num_threads(int(n))
+
+
+def max_threads() -> int:
+    """The OpenMP default thread count (what ``set_num_threads(0)`` selects)."""
+    lib().rvo_set_num_threads(0)
+    return int(lib().rvo_num_threads())
 
 
 def int_view(state):

@@ -89,3 +89,40 @@ def synthetic_obs(n, seed=0):
     obs[:, 3] = rng.uniform(-1, 1, n)
     obs[:, 4:] = -0.27 + 0.15 * rng.standard_normal((n, 961))
     return obs
+
+
+# ---------------------------------------------------------------------------------------------- reset fixture
+def reset_fixture_case(g, batch):
+    """Per-env arrays (scattered from the batch's env_ids) of tests/golden/reset.npz: what ``reset_with_draws`` consumes
+    and what the reference produced (tools/gen_golden.py::gen_reset)."""
+    n, mt = int(g["num_envs"]), int(g["max_tries"])
+    pre = f"b{batch}_"
+    ids = g[pre + "env_ids"]
+    mask = np.zeros(n, np.uint8)
+    mask[ids] = 1
+    spawn_row = np.zeros(n, np.int32)
+    spawn_row[ids] = g[pre + "spawn_index"]
+    yaw_u = np.zeros(n, np.float32)
+    yaw_u[ids] = g[pre + "yaw_u"]
+    theta_u = np.full((n, mt), np.nan, np.float32)
+    theta_u[ids] = g[pre + "theta_u"]
+    heading_u = np.zeros(n, np.float32)
+    heading_u[ids] = g[pre + "heading_u"]
+    expect = {"ids": ids, "root_pose": g[pre + "root_pose"], "env_origins": g[pre + "env_origins"],
+              "pos_command_w": g[pre + "pos_command_w"], "heading_command_w": g[pre + "heading_command_w"]}
+    return mask, spawn_row, yaw_u, theta_u, heading_u, expect
+
+
+def check_reset_against_fixture(state_aos, expect, words):
+    """state_aos: (n, 72) state words after the injected reset; ``words`` = module with the word offsets."""
+    ids = expect["ids"]
+    S = state_aos[ids]
+    # spawn row + z_offset: float adds only => exact; yaw -> quaternion uses cos/sin (torch vs rv_*: <= 2 ulp)
+    assert_close(S[:, words.POS:words.POS + 3], expect["root_pose"][:, 0:3], 0, 0, "root position (randomizations.py:22-27)")
+    assert_close(S[:, words.QUAT:words.QUAT + 4], expect["root_pose"][:, 3:7], 2.5e-7, 0, "root quaternion (:30-33)")
+    assert_close(S[:, words.ENV_ORIGIN:words.ENV_ORIGIN + 3], expect["env_origins"], 0, 0, "env_origins (:37)")
+    # target = origin + 9 (cos, sin)(theta): |err| <= 9 * 2 ulp(1) + ulp(30); z = heightmap cell (exact)
+    assert_close(S[:, words.TARGET_W:words.TARGET_W + 2], expect["pos_command_w"][:, 0:2], 4e-6, 0,
+                 "target xy (terrain_importer.py:168-173)")
+    assert_close(S[:, words.TARGET_W + 2], expect["pos_command_w"][:, 2], 0, 0, "target z (get_height_at, terrain_utils.py:62-84)")
+    assert_close(S[:, words.HEADING_CMD_W], expect["heading_command_w"], 2.4e-7, 0, "heading command (:93-95)")

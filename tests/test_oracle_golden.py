@@ -100,3 +100,32 @@ def test_update_command_against_float64(oracle):
     err = np.abs(((hb - e) + np.pi) % (2 * np.pi) - np.pi)
     assert err.max() < 5e-6
     assert (hb <= np.pi + 1e-6).all() and (hb > -np.pi - 1e-6).all()
+
+
+def _reset_fixture_oracle_setup(oracle, g):
+    cfg = oracle.default_config(max_target_tries=int(g["max_tries"]), scan_nx=3, scan_ny=3, scan_size_x=0.2, scan_size_y=0.2)
+    ter = oracle.TerrainData(g["heightmap"], None, g["safe_mask"], float(g["resolution"]), float(g["min_xy"][0]),
+                             float(g["min_xy"][1]), g["spawn_table"])
+    return cfg, ter
+
+
+def test_reset_golden(oracle, golden_dir):
+    """reset_root_state_rover + sample_new_targets + the heading draw, with the reference's recorded torch draws injected
+    (randomizations.py:12-39, terrain_importer.py:74-95, 134-175): the oracle reproduces pose / origin / target / heading."""
+    from helpers import check_reset_against_fixture, reset_fixture_case
+    g = np.load(f"{golden_dir}/reset.npz")
+    cfg, ter = _reset_fixture_oracle_setup(oracle, g)
+    n = int(g["num_envs"])
+    S = oracle.new_state(n)
+    S[:, oracle.ENV_ORIGIN:oracle.ENV_ORIGIN + 2] = 100.0        # rover_env.py:24-25, overwritten by the reset
+    for batch in (0, 1):
+        mask, row, yaw_u, theta_u, heading_u, expect = reset_fixture_case(g, batch)
+        before = S.copy()
+        oracle.reset_with_draws(cfg, ter, S, mask, row, yaw_u, theta_u, heading_u)
+        check_reset_against_fixture(S, expect, oracle)
+        untouched = mask == 0
+        assert (S[untouched] == before[untouched]).all(), "envs outside env_ids must not change"
+        # number of theta draws consumed = the reference's rejection rounds (safe rock mask, terrain_utils.py:202-223)
+        tries = g[f"b{batch}_tries"]
+        assert (np.isfinite(g[f"b{batch}_theta_u"]).sum(1) == tries).all()
+    assert not np.isnan(S).any()

@@ -15,6 +15,12 @@ Outputs (small .npz files, data only -- inputs and the reference's outputs):
                           TerrainManager.check_if_target_is_valid (:202-223),
                           TerrainManager.random_rover_spawns(seed=41) (:330-385)
 
+* ``reset.npz``       -- reset_root_state_rover (randomizations.py:12-39), RoverTerrainImporter.sample_new_targets /
+                          generate_random_targets (terrain_importer.py:134-175) and the heading draw of
+                          TerrainBasedPositionCommand._resample_command (:74-95), with every torch draw RECORDED
+                          (spawn index, yaw uniform, the theta uniforms incl. rejected ones, heading uniform) so that
+                          the outcome can be replayed by injecting the draws (torch's RNG stream itself cannot be)
+
 Functions that live in third-party code absent from the container (ORBIT math utils, PhysX, Warp
 ray-caster, cv2 morphology) cannot be evaluated and are NOT covered here; see DESIGN.md "parity".
 """
@@ -234,7 +240,147 @@ def gen_heightmap():
     print("heightmap:", {k: getattr(v, "shape", ()) for k, v in out.items()})
 
 
+# --------------------------------------------------------------------------------------- reset / command sampling
+class _DrawRecorder:
+    """Wraps torch.rand / torch.randperm / Tensor.uniform_ while the reference's reset code runs: the calls are served
+    by a seeded CPU generator and every returned tensor is logged.  ``uniform_(lo, hi)`` is served as
+    ``rand * (hi - lo) + lo`` (torch's own definition of U(lo, hi)) so that its underlying uniform is known."""
+
+    def __init__(self, seed):
+        self.g = torch.Generator().manual_seed(seed)
+        self.rand_log, self.perm_log, self.uniform_log = [], [], []
+
+    def __enter__(self):
+        self._rand, self._randperm, self._uniform = torch.rand, torch.randperm, torch.Tensor.uniform_
+        rec = self
+
+        def rand(*size, device=None, **kw):
+            out = rec._rand(*size, generator=rec.g)
+            rec.rand_log.append(out.clone())
+            return out
+
+        def randperm(n, device=None, **kw):
+            out = rec._randperm(n, generator=rec.g)
+            rec.perm_log.append(out.clone())
+            return out
+
+        def uniform_(self_t, lo=0.0, hi=1.0):
+            u = rec._rand(self_t.shape, generator=rec.g)
+            rec.uniform_log.append(u.clone())
+            self_t.copy_(u * (hi - lo) + lo)
+            return self_t
+
+        torch.rand, torch.randperm, torch.Tensor.uniform_ = rand, randperm, uniform_
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand, torch.randperm, torch.Tensor.uniform_ = self._rand, self._randperm, self._uniform
+
+
+def gen_reset():
+    import math
+    from rover_envs.envs.navigation.mdp import randomizations as ref_rand
+    from rover_envs.envs.navigation.utils.terrains import terrain_importer as ref_ti
+
+    N, MAX_TRIES = 96, 32
+    # ---- shared terrain data: a 30 m x 25 m heightmap whose look-up offsets are non-zero (exercises B-1), a blobby
+    #      safe-rock mask (~35 % blocked => the rejection loop of sample_new_targets runs several rounds)
+    rng = np.random.RandomState(17)
+    H, W = 500, 600
+    yy, xx = np.mgrid[0:H, 0:W]
+    heightmap = 0.4 * np.sin(xx * 0.021) * np.cos(yy * 0.017) + 0.02 * rng.standard_normal((H, W))
+    heightmap = (np.round(heightmap * 64.0) / 64.0).astype(np.float32)   # 1/64 m steps: keeps the fixture small
+    blobs = np.zeros((H, W), np.float32)
+    for _ in range(260):
+        cx, cy, r = rng.uniform(0, W), rng.uniform(0, H), rng.uniform(6, 30)
+        blobs = np.maximum(blobs, ((xx - cx) ** 2 + (yy - cy) ** 2 < r * r).astype(np.float32))
+    mask = blobs.astype(np.uint8)
+    hm = ref_tu.HeightmapManager.__new__(ref_tu.HeightmapManager)
+    hm.resolution_in_m = 0.05
+    hm.heightmap = heightmap
+    hm.min_x, hm.min_y = 1.25, 2.5
+    hm.heightmap_tensor = torch.from_numpy(heightmap)
+    hm.offset_tensor = torch.tensor([hm.min_x, hm.min_y])
+    tm = ref_tu.TerrainManager.__new__(ref_tu.TerrainManager)
+    tm._heightmap_manager = hm
+    tm.resolution_in_m = 0.05
+    tm.rock_mask_tensor = torch.from_numpy(mask).unsqueeze(-1)
+    # spawn table: 2 N rows inside the map (terrain_utils.py:123-124: n_spawns = 2 * num_envs)
+    spawns = np.stack([rng.uniform(9.5, 20.0, 2 * N), rng.uniform(9.5, 15.0, 2 * N), rng.uniform(-0.3, 0.3, 2 * N)], 1)
+    tm.spawn_locations = torch.from_numpy(spawns.astype(np.float32))
+
+    importer = ref_ti.RoverTerrainImporter.__new__(ref_ti.RoverTerrainImporter)
+    importer._cfg = types.SimpleNamespace(num_envs=N)
+    importer._terrainManager = tm
+    importer.target_distance = 9.0                            # terrain_importer.py:132
+    importer.device = "cpu"
+    importer.env_origins = torch.zeros(N, 3)
+    importer.env_origins[:, 0:2] += 100.0                      # rover_env.py:24-25 (overwritten by the first reset)
+
+    written = {}
+    asset = types.SimpleNamespace(write_root_pose_to_sim=lambda pose, env_ids: written.update(pose=pose.clone(),
+                                                                                               env_ids=env_ids.clone()))
+    robot = types.SimpleNamespace(data=types.SimpleNamespace(default_root_state=torch.zeros(N, 13)))
+    scene = {"robot": asset}
+    env = types.SimpleNamespace(device="cpu", num_envs=N,
+                                scene=types.SimpleNamespace(terrain=importer, __getitem__=None))
+    env.scene = type("Scene", (), {"terrain": importer, "__getitem__": lambda self, k: scene[k]})()
+
+    cmd = ref_ti.TerrainBasedPositionCommand.__new__(ref_ti.TerrainBasedPositionCommand)
+    cmd.terrain, cmd.robot = importer, robot
+    cmd.device, cmd.num_envs = "cpu", N
+    cmd.cfg = types.SimpleNamespace(simple_heading=False, ranges=types.SimpleNamespace(heading=(-math.pi, math.pi)))
+    cmd.pos_command_w = torch.zeros(N, 3)
+    cmd.heading_command_w = torch.zeros(N)
+
+    out = {"heightmap": heightmap, "safe_mask": mask, "min_xy": np.array([hm.min_x, hm.min_y], np.float64),
+           "resolution": np.float64(0.05), "spawn_table": spawns.astype(np.float32), "num_envs": np.int64(N),
+           "max_tries": np.int64(MAX_TRIES), "z_offset": np.float64(0.5), "target_distance": np.float64(9.0),
+           "heading_range": np.array([-math.pi, math.pi], np.float64)}
+    # two batches: the initial reset of every env, then a partial in-step reset of a scattered subset
+    batches = [torch.arange(N), torch.tensor(sorted(rng.choice(N, 23, replace=False).tolist()))]
+    for b, env_ids in enumerate(batches):
+        k = len(env_ids)
+        with _DrawRecorder(1000 + b) as rec:
+            ref_rand.reset_root_state_rover(env, env_ids, types.SimpleNamespace(name="robot"), z_offset=0.5)
+            n_rand_reset = len(rec.rand_log)
+            ids_iter = []
+            orig_check = tm.check_if_target_is_valid
+
+            def spy(e_ids, pos, device="cuda:0", _orig=orig_check, _log=ids_iter):
+                _log.append(e_ids.clone())
+                return _orig(e_ids, pos, device=device)
+
+            tm.check_if_target_is_valid = spy
+            cmd._resample_command(env_ids)
+            tm.check_if_target_is_valid = orig_check
+        assert len(rec.perm_log) == 1 and n_rand_reset == 1 and len(rec.uniform_log) == 1
+        theta_u = np.full((k, MAX_TRIES), np.nan, np.float32)
+        tries = np.zeros(k, np.int64)
+        pos_of = {int(e): i for i, e in enumerate(env_ids.tolist())}
+        for ids, u in zip(ids_iter, rec.rand_log[1:]):
+            for e, val in zip(ids.tolist(), u.tolist()):
+                i = pos_of[int(e)]
+                theta_u[i, tries[i]] = val
+                tries[i] += 1
+        assert tries.max() <= MAX_TRIES and tries.min() >= 1
+        pre = f"b{b}_"
+        out[pre + "env_ids"] = env_ids.numpy().astype(np.int64)
+        out[pre + "spawn_index"] = rec.perm_log[0][:k].numpy().astype(np.int64)          # randomizations.py:22
+        out[pre + "yaw_u"] = rec.rand_log[0].numpy()                                      # :30
+        out[pre + "theta_u"] = theta_u                                                    # terrain_importer.py:169
+        out[pre + "tries"] = tries
+        out[pre + "heading_u"] = rec.uniform_log[0].numpy()                               # :93-95
+        out[pre + "root_pose"] = written["pose"].numpy()                                  # (k, 7) pos + quat (w, x, y, z)
+        out[pre + "env_origins"] = importer.env_origins[env_ids].numpy()                  # randomizations.py:37
+        out[pre + "pos_command_w"] = cmd.pos_command_w[env_ids].numpy()
+        out[pre + "heading_command_w"] = cmd.heading_command_w[env_ids].numpy()
+        print(f"reset batch {b}: {k} envs, target tries max {tries.max()} mean {tries.mean():.2f}")
+    np.savez_compressed(os.path.join(OUT, "reset.npz"), **out)
+
+
 if __name__ == "__main__":
+    gen_reset()
     gen_ackermann()
     gen_mdp_terms()
     gen_heightmap()
