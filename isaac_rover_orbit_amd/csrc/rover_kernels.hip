@@ -1,7 +1,7 @@
 // rover_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) + C ABI of the AAURoverEnv-v0 hot path.
 //
 // Two launches per env.step():
-//   K1  rover_step_kernel[_group]  one env per LANE (N >= 65536) or per 8-LANE GROUP (one wheel per lane; default),
+//   K1  rover_step_kernel[_group]  one env per LANE (large N) or per 16-LANE GROUP (wheel slot x channel role per lane; default),
 //                             SoA state (state[word * N + env]).  process_action -> Ackermann -> 6 x {implicit-PD
 //                             steer joints, 6-wheel contact solve against the bilinear heightfield, wheel motors,
 //                             integration} -> counters -> terminations -> rewards -> in-lane reset (Philox) ->
@@ -35,8 +35,38 @@
 
 namespace {
 
+// quantities that depend only on the physics time step (hoisted reciprocals: one division each, then products); evaluated
+// ONCE on the host (same IEEE fp32 operations, -ffp-contract=off) and handed to the kernels in the parameter block
+struct StepConsts {
+    float h, inv_h, inv_m, inv_I[3];
+    float steer_hkp, steer_den_inv, steer_i_over_h, steer_dv_max;
+    float wheel_den_inv, wheel_h_over_i, lt_motor;
+    float bogie_keep[3], b_winv[3];
+};
+__host__ __device__ inline void make_step_consts(float h, StepConsts &k)
+{
+    constexpr float INERTIA_B[3] = RV_INERTIA_B_INIT;
+    constexpr float BOGIE_INERTIA[3] = RV_BOGIE_INERTIA_INIT;
+    k.h = h;
+    k.inv_h = 1.0f / h;
+    k.inv_m = 1.0f / RV_M_TOTAL;
+    for (int i = 0; i < 3; ++i) k.inv_I[i] = 1.0f / INERTIA_B[i];
+    k.steer_hkp = h * RV_STEER_KP;
+    k.steer_den_inv = 1.0f / (RV_STEER_INERTIA + h * RV_STEER_KD + h * h * RV_STEER_KP);
+    k.steer_i_over_h = RV_STEER_INERTIA / h;
+    k.steer_dv_max = RV_STEER_EFFORT * h / RV_STEER_INERTIA;
+    k.wheel_den_inv = 1.0f / (RV_WHEEL_INERTIA + h * RV_WHEEL_KD + h * h * RV_WHEEL_KP);
+    k.wheel_h_over_i = h / RV_WHEEL_INERTIA;
+    k.lt_motor = RV_WHEEL_EFFORT * h / RV_WHEEL_CONTACT_RADIUS;
+    for (int j = 0; j < 3; ++j) {
+        k.bogie_keep[j] = 1.0f / (1.0f + h * RV_BOGIE_DAMPING / BOGIE_INERTIA[j]);
+        k.b_winv[j] = 1.0f / BOGIE_INERTIA[j];
+    }
+}
+
 struct RvParams {
     rover_config cfg;
+    StepConsts K;
     const float *height;
     const float *obstacle;
     const uint8_t *safe_mask;
@@ -345,9 +375,12 @@ struct Contact {
     float obst;
 };
 
+#ifndef RV_GROUP_MAPPING_BELOW
+#define RV_GROUP_MAPPING_BELOW 32768   // num_envs below which the auto mapping picks 16 lanes per env (tools/n_sweep.py)
+#endif
 #define RV_SPLIT_C 6.0f  // contacts sharing the chassis (mass splitting)
 #define RV_SPLIT_B 2.0f  // contacts sharing one bogie
-#define RV_TREE6(a, b, c, d, e, f) ((((a) + (b)) + ((c) + (d))) + (((e) + (f)) + (0.0f + 0.0f)))
+#define RV_TREE8(a) ((((a)[0] + (a)[1]) + ((a)[2] + (a)[3])) + (((a)[4] + (a)[5]) + ((a)[6] + (a)[7])))
 
 // fused-multiply-add forms of the small vector helpers (physics only; the oracle uses the identical sequences)
 __device__ __forceinline__ float dot3f(const float *a, const float *b) { return fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0])); }
@@ -366,36 +399,6 @@ __device__ __forceinline__ void mat_tvecf(const float R[3][3], const float *v, f
 {
 #pragma unroll
     for (int i = 0; i < 3; ++i) o[i] = fmaf(R[2][i], v[2], fmaf(R[1][i], v[1], R[0][i] * v[0]));
-}
-
-// quantities that depend only on the physics time step (hoisted reciprocals: one division each, then products)
-struct StepConsts {
-    float h, inv_h, inv_m, inv_I[3];
-    float steer_hkp, steer_den_inv, steer_i_over_h, steer_dv_max;
-    float wheel_den_inv, wheel_h_over_i, lt_motor;
-    float bogie_keep[3], b_winv[3];
-};
-__device__ __forceinline__ void make_step_consts(float h, StepConsts &k)
-{
-    constexpr float INERTIA_B[3] = RV_INERTIA_B_INIT;
-    constexpr float BOGIE_INERTIA[3] = RV_BOGIE_INERTIA_INIT;
-    k.h = h;
-    k.inv_h = 1.0f / h;
-    k.inv_m = 1.0f / RV_M_TOTAL;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) k.inv_I[i] = 1.0f / INERTIA_B[i];
-    k.steer_hkp = h * RV_STEER_KP;
-    k.steer_den_inv = 1.0f / (RV_STEER_INERTIA + h * RV_STEER_KD + h * h * RV_STEER_KP);
-    k.steer_i_over_h = RV_STEER_INERTIA / h;
-    k.steer_dv_max = RV_STEER_EFFORT * h / RV_STEER_INERTIA;
-    k.wheel_den_inv = 1.0f / (RV_WHEEL_INERTIA + h * RV_WHEEL_KD + h * h * RV_WHEEL_KP);
-    k.wheel_h_over_i = h / RV_WHEEL_INERTIA;
-    k.lt_motor = RV_WHEEL_EFFORT * h / RV_WHEEL_CONTACT_RADIUS;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        k.bogie_keep[j] = 1.0f / (1.0f + h * RV_BOGIE_DAMPING / BOGIE_INERTIA[j]);
-        k.b_winv[j] = 1.0f / BOGIE_INERTIA[j];
-    }
 }
 
 // implicit-PD steering joint (kp 8000, kd 1000, effort 12, rate 6; aau_rover_simple.py:43-49)
@@ -506,82 +509,66 @@ __device__ __forceinline__ void wheel_geometry(const RvParams &p, const StepCons
     ct.a_ts = RV_SPLIT_C * wdot3x(ct.jt_a, ct.js_a, inv_I) + RV_SPLIT_B * (ct.jt_b * ct.js_b * b_winv);
 }
 
-// warm-start contribution of one wheel
-__device__ __forceinline__ void wheel_warm(const StepConsts &k, const Contact &ct, float b_winv, float *dv, float *dw, float &db)
-{
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { dv[i] = ct.n[i] * (ct.ln * k.inv_m); dw[i] = ct.jn_a[i] * (k.inv_I[i] * ct.ln); }
-    db = ct.jn_b * b_winv * ct.ln;
-}
-
-// the three rows of one wheel against a snapshot (v, w, bogie rate) of the shared velocities: Gauss-Seidel inside the
-// wheel through the split-mass coupling terms, velocity contributions (dv, dw, db) with the TRUE masses.
-// Explicit fused multiply-adds; oracle/rover_oracle.c evaluates the identical sequence.
-__device__ __forceinline__ void wheel_rows(const StepConsts &k, Contact &ct, const float *v, const float *w, float bdj,
-                                           float b_winv, float mu, float wheel_w, float *dv, float *dw, float &db)
-{
-    const float un = fmaf(ct.jn_b, bdj, fmaf(ct.n[2], v[2], fmaf(ct.n[1], v[1], ct.n[0] * v[0])) +
-                                            fmaf(ct.jn_a[2], w[2], fmaf(ct.jn_a[1], w[1], ct.jn_a[0] * w[0])));
-    const float ut = fmaf(ct.jt_b, bdj, fmaf(ct.t[2], v[2], fmaf(ct.t[1], v[1], ct.t[0] * v[0])) +
-                                            fmaf(ct.jt_a[2], w[2], fmaf(ct.jt_a[1], w[1], ct.jt_a[0] * w[0]))) -
-                     RV_WHEEL_CONTACT_RADIUS * wheel_w;  // rim speed prescribed by the (stiff) wheel motor
-    const float us = fmaf(ct.js_b, bdj, fmaf(ct.s[2], v[2], fmaf(ct.s[1], v[1], ct.s[0] * v[0])) +
-                                            fmaf(ct.js_a[2], w[2], fmaf(ct.js_a[1], w[1], ct.js_a[0] * w[0])));
-    float ln = fmaf(ct.bias - un, ct.mn, ct.ln);
-    if (ln < 0.0f) ln = 0.0f;
-    const float dn = ln - ct.ln;
-    ct.ln = ln;
-    const float lim = mu * ln;
-    const float lmax = lim < k.lt_motor ? lim : k.lt_motor;
-    const float lt = clampf(fmaf(-fmaf(ct.a_nt, dn, ut), ct.mt, ct.lt), -lmax, lmax);
-    const float dt = lt - ct.lt;
-    ct.lt = lt;
-    const float ls = clampf(fmaf(-fmaf(ct.a_ts, dt, fmaf(ct.a_ns, dn, us)), ct.ms, ct.ls), -lim, lim);
-    const float ds = ls - ct.ls;
-    ct.ls = ls;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        dv[i] = fmaf(ct.s[i], ds, fmaf(ct.t[i], dt, ct.n[i] * dn)) * k.inv_m;
-        dw[i] = fmaf(ct.js_a[i], ds, fmaf(ct.jt_a[i], dt, ct.jn_a[i] * dn)) * k.inv_I[i];
-    }
-    db = fmaf(ct.js_b, ds, fmaf(ct.jt_b, dt, ct.jn_b * dn)) * b_winv;
-}
-
-// The same three rows on packed fp32 (v_pk_fma_f32 / v_pk_mul_f32: two fp32 operations per lane per instruction): every
-// linear quantity is paired with its angular twin -- nj[i] = {n[i], jn_a[i]}, vw[i] = {v[i], w[i]}, minv[i] = {1/m,
-// 1/I[i]} -- so the row velocities and the velocity contributions take half the instructions of wheel_rows().  Each
-// component goes through exactly the operations of wheel_rows() (one rounding per multiply / add / fma), so the result
-// is bit-identical; only the group mapping uses it (a lone wave per SIMD is bound by instruction issue).
+// ---- solver arithmetic (operation for operation the one of oracle/rover_oracle.c, see the comment there) ---------------
+// The generalised velocity is held as four CHANNEL PAIRS {linear, angular}: c0 = (v.x, w.x), c1 = (v.y, w.y),
+// c2 = (v.z, w.z), c3 = (bogie rate, 0).  A wheel has two ROLES: A owns c0, c1; B owns c2, c3.  Every pair is one register
+// pair worked on by packed fp32 instructions (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32).
 typedef float f2 __attribute__((ext_vector_type(2)));
-struct ContactPairs {
-    f2 nj[3], tj[3], sj[3], minv[3];
-};
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ void wheel_rows_packed(const StepConsts &k, Contact &ct, const ContactPairs &cp, const f2 *vw,
-                                                  float bdj, float b_winv, float mu, float wheel_w, f2 *dvw, float &db)
+struct RoleRows {
+    f2 Jn[2], Jt[2], Js[2];  // Jacobian pairs of the role's two channels
+    f2 Mn[2], Mt[2], Ms[2];  // the same times the inverse mass pair of the channel
+};
+__device__ __forceinline__ float row_partial(const f2 *J, const f2 *V)
 {
-    const f2 an = fma2(cp.nj[2], vw[2], fma2(cp.nj[1], vw[1], cp.nj[0] * vw[0]));
-    const f2 at = fma2(cp.tj[2], vw[2], fma2(cp.tj[1], vw[1], cp.tj[0] * vw[0]));
-    const f2 as = fma2(cp.sj[2], vw[2], fma2(cp.sj[1], vw[1], cp.sj[0] * vw[0]));
-    const float un = fmaf(ct.jn_b, bdj, an.x + an.y);
-    const float ut = fmaf(ct.jt_b, bdj, at.x + at.y) - RV_WHEEL_CONTACT_RADIUS * wheel_w;
-    const float us = fmaf(ct.js_b, bdj, as.x + as.y);
-    float ln = fmaf(ct.bias - un, ct.mn, ct.ln);
-    if (ln < 0.0f) ln = 0.0f;
-    const float dn = ln - ct.ln;
-    ct.ln = ln;
-    const float lim = mu * ln;
-    const float lmax = lim < k.lt_motor ? lim : k.lt_motor;
-    const float lt = clampf(fmaf(-fmaf(ct.a_nt, dn, ut), ct.mt, ct.lt), -lmax, lmax);
-    const float dt = lt - ct.lt;
-    ct.lt = lt;
-    const float ls = clampf(fmaf(-fmaf(ct.a_ts, dt, fmaf(ct.a_ns, dn, us)), ct.ms, ct.ls), -lim, lim);
-    const float ds = ls - ct.ls;
-    ct.ls = ls;
+    const f2 pr = fma2(J[1], V[1], J[0] * V[0]);
+    return pr.x + pr.y;
+}
+__device__ __forceinline__ void role_outputs(const RoleRows &r, float dn, float dt, float ds, f2 *o)
+{
     const f2 dn2 = {dn, dn}, dt2 = {dt, dt}, ds2 = {ds, ds};
 #pragma unroll
-    for (int i = 0; i < 3; ++i) dvw[i] = fma2(cp.sj[i], ds2, fma2(cp.tj[i], dt2, cp.nj[i] * dn2)) * cp.minv[i];
-    db = fmaf(ct.js_b, ds, fmaf(ct.jt_b, dt, ct.jn_b * dn)) * b_winv;
+    for (int k = 0; k < 2; ++k) o[k] = fma2(r.Ms[k], ds2, fma2(r.Mt[k], dt2, r.Mn[k] * dn2));
+}
+// inverse mass pairs of the channels: A = {(1/m, 1/Ixx), (1/m, 1/Iyy)}, B = {(1/m, 1/Izz), (1/I_bogie, 0)}
+// (written out row by row: arrays of pointers into `ct` would keep the struct in memory -- hipcc then promotes it to LDS and
+// fetches the workgroup size from the dispatch packet in host memory, a 15 us stall)
+__device__ __forceinline__ void make_role_row(const float *dir, const float *ja, float jb, bool role_b, const f2 &minv0,
+                                              const f2 &minv1, f2 *J, f2 *M)
+{
+    const float j0x = role_b ? dir[2] : dir[0], j0y = role_b ? ja[2] : ja[0];
+    const float j1x = role_b ? jb : dir[1], j1y = role_b ? 0.0f : ja[1];
+    J[0] = (f2){j0x, j0y};
+    J[1] = (f2){j1x, j1y};
+    M[0] = J[0] * minv0;
+    M[1] = J[1] * minv1;
+}
+__device__ __forceinline__ void make_role(const Contact &ct, bool role_b, const f2 &minv0, const f2 &minv1, RoleRows &r)
+{
+    make_role_row(ct.n, ct.jn_a, ct.jn_b, role_b, minv0, minv1, r.Jn, r.Mn);
+    make_role_row(ct.t, ct.jt_a, ct.jt_b, role_b, minv0, minv1, r.Jt, r.Mt);
+    make_role_row(ct.s, ct.js_a, ct.js_b, role_b, minv0, minv1, r.Js, r.Ms);
+}
+// max / min / symmetric clamp as single instructions (v_max_f32 / v_min_f32 / v_med3_f32: total order with -0 < +0, which
+// the oracle's max_ord / min_ord / med3_sym restate)
+__device__ __forceinline__ float max_zero_ord(float a) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(a)); return r; }
+__device__ __forceinline__ float min_ord_s(float uniform, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "s"(uniform), "v"(b)); return r; }
+__device__ __forceinline__ float med3_sym(float x, float lim) { return __builtin_amdgcn_fmed3f(x, -lim, lim); }
+// Gauss-Seidel over the wheel's own rows through the split-mass coupling terms
+__device__ __forceinline__ void impulse_update(const StepConsts &k, Contact &ct, float mu, float un, float ut, float us,
+                                               float &dn, float &dt, float &ds)
+{
+    const float ln = max_zero_ord(fmaf(ct.bias - un, ct.mn, ct.ln));
+    dn = ln - ct.ln;
+    ct.ln = ln;
+    const float lim = mu * ln;
+    const float lmax = min_ord_s(k.lt_motor, lim);
+    const float lt = med3_sym(fmaf(-fmaf(ct.a_nt, dn, ut), ct.mt, ct.lt), lmax);
+    dt = lt - ct.lt;
+    ct.lt = lt;
+    const float ls = med3_sym(fmaf(-fmaf(ct.a_ts, dt, fmaf(ct.a_ns, dn, us)), ct.ms, ct.ls), lim);
+    ds = ls - ct.ls;
+    ct.ls = ls;
 }
 
 // chassis integration shared by both mappings: velocity cap, symplectic Euler, quaternion update
@@ -625,7 +612,9 @@ __device__ __forceinline__ void bogie_integrate(float h, float bq0, float bdv, f
     qd_out = qd;
 }
 
-// ---- "lane" mapping: one physics substep of one env, S = the env's state words in registers
+// ---- "lane" mapping: one physics substep of one env, S = the env's state words in registers.  Same arithmetic as the
+// group mapping; the prescaled Jacobians M = J * minv are re-formed where they are used (identical roundings) instead of
+// being kept in registers for six wheels.
 template <bool RECORD_FORCE>
 __device__ __forceinline__ void physics_substep(const RvParams &p, const StepConsts &K, float *S, const float *steer_t,
                                                 const float *wheel_t, float *F /* 39, only if RECORD_FORCE */)
@@ -664,7 +653,15 @@ __device__ __forceinline__ void physics_substep(const RvParams &p, const StepCon
     }
     // ---- 3. contact geometry (slot order), warm start
     Contact C[6];
-    float dv[6][3], dw[6][3], db[6];
+    const f2 minvA0 = {K.inv_m, K.inv_I[0]}, minvA1 = {K.inv_m, K.inv_I[1]}, minvB0 = {K.inv_m, K.inv_I[2]};
+    f2 VA[2] = {{v[0], w[0]}, {v[1], w[1]}}, VB0 = {v[2], w[2]};
+    float bdy[3] = {0.0f, 0.0f, 0.0f};
+    float oa[4][8], ob0[2][8], ob1[2][8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        oa[0][q] = oa[1][q] = oa[2][q] = oa[3][q] = 0.0f;
+        ob0[0][q] = ob0[1][q] = ob1[0][q] = ob1[1][q] = 0.0f;
+    }
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
         const int k = SLOT_WHEEL[s], j = s >> 1, si = WHEEL_STEER[k];
@@ -676,30 +673,49 @@ __device__ __forceinline__ void physics_substep(const RvParams &p, const StepCon
         C[s].ln = RV_WARM_START * S[ROVER_LAMBDA_N + k];
         C[s].lt = 0.0f;
         C[s].ls = 0.0f;
-        wheel_warm(K, C[s], K.b_winv[j], dv[s], dw[s], db[s]);
+        const f2 minvB1 = {K.b_winv[j], 0.0f};
+        RoleRows ra, rb;
+        make_role(C[s], false, minvA0, minvA1, ra);
+        make_role(C[s], true, minvB0, minvB1, rb);
+        oa[0][s] = ra.Mn[0].x * C[s].ln; oa[1][s] = ra.Mn[0].y * C[s].ln;
+        oa[2][s] = ra.Mn[1].x * C[s].ln; oa[3][s] = ra.Mn[1].y * C[s].ln;
+        ob0[0][s] = rb.Mn[0].x * C[s].ln; ob0[1][s] = rb.Mn[0].y * C[s].ln;
+        ob1[0][s] = rb.Mn[1].x * C[s].ln; ob1[1][s] = rb.Mn[1].y * C[s].ln;
     }
+    // ---- 4. wheel-parallel projected Jacobi with mass splitting (iteration -1 = the warm-start contributions)
+    for (int it = -1; it < p.cfg.solver_iterations; ++it) {
+        if (it >= 0) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        v[i] += RV_TREE6(dv[0][i], dv[1][i], dv[2][i], dv[3][i], dv[4][i], dv[5][i]);
-        w[i] += RV_TREE6(dw[0][i], dw[1][i], dw[2][i], dw[3][i], dw[4][i], dw[5][i]);
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) bd[j] += db[2 * j] + db[2 * j + 1];
-    // ---- 4. wheel-parallel projected Jacobi with mass splitting
-    for (int it = 0; it < p.cfg.solver_iterations; ++it) {
-#pragma unroll
-        for (int s = 0; s < 6; ++s) {
-            const int k = SLOT_WHEEL[s], j = s >> 1;
-            wheel_rows(K, C[s], v, w, bd[j], K.b_winv[j], mu, S[ROVER_WHEEL_QD + k], dv[s], dw[s], db[s]);
+            for (int s = 0; s < 6; ++s) {
+                const int k = SLOT_WHEEL[s], j = s >> 1;
+                const f2 minvB1 = {K.b_winv[j], 0.0f};
+                RoleRows ra, rb;
+                make_role(C[s], false, minvA0, minvA1, ra);
+                make_role(C[s], true, minvB0, minvB1, rb);
+                const f2 VB[2] = {VB0, {bd[j], bdy[j]}};
+                const float un = row_partial(ra.Jn, VA) + row_partial(rb.Jn, VB);
+                const float ut = (row_partial(ra.Jt, VA) + row_partial(rb.Jt, VB)) - RV_WHEEL_CONTACT_RADIUS * S[ROVER_WHEEL_QD + k];
+                const float us = row_partial(ra.Js, VA) + row_partial(rb.Js, VB);
+                float dn, dt, ds;
+                impulse_update(K, C[s], mu, un, ut, us, dn, dt, ds);
+                f2 o[2];
+                role_outputs(ra, dn, dt, ds, o);
+                oa[0][s] = o[0].x; oa[1][s] = o[0].y; oa[2][s] = o[1].x; oa[3][s] = o[1].y;
+                role_outputs(rb, dn, dt, ds, o);
+                ob0[0][s] = o[0].x; ob0[1][s] = o[0].y; ob1[0][s] = o[1].x; ob1[1][s] = o[1].y;
+            }
         }
+        VA[0].x += RV_TREE8(oa[0]); VA[0].y += RV_TREE8(oa[1]);
+        VA[1].x += RV_TREE8(oa[2]); VA[1].y += RV_TREE8(oa[3]);
+        VB0.x += RV_TREE8(ob0[0]); VB0.y += RV_TREE8(ob0[1]);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            v[i] += RV_TREE6(dv[0][i], dv[1][i], dv[2][i], dv[3][i], dv[4][i], dv[5][i]);
-            w[i] += RV_TREE6(dw[0][i], dw[1][i], dw[2][i], dw[3][i], dw[4][i], dw[5][i]);
+        for (int j = 0; j < 3; ++j) {
+            bd[j] += ob1[0][2 * j] + ob1[0][2 * j + 1];
+            bdy[j] += ob1[1][2 * j] + ob1[1][2 * j + 1];
         }
-#pragma unroll
-        for (int j = 0; j < 3; ++j) bd[j] += db[2 * j] + db[2 * j + 1];
     }
+    v[0] = VA[0].x; v[1] = VA[1].x; v[2] = VB0.x;
+    w[0] = VA[0].y; w[1] = VA[1].y; w[2] = VB0.y;
     // ---- 5. wheel motors, 6. obstacle contact report
     if (RECORD_FORCE) {
 #pragma unroll
@@ -724,34 +740,39 @@ __device__ __forceinline__ void physics_substep(const RvParams &p, const StepCon
     for (int j = 0; j < 3; ++j) bogie_integrate(h, bq[j], bd[j], S[ROVER_BOGIE_Q + j], S[ROVER_BOGIE_QD + j]);
 }
 
-// ---- "group" mapping: eight lanes per env.  Per-lane copy of the chassis + ONE wheel.
+// ---- "group" mapping: SIXTEEN lanes per env = 8 wheel slots [FL, CL, FR, CR, RL, RR, -, -] x 2 roles.  Lane l of a
+// 16-lane row: slot = l & 7, role = l >> 3 (A: lanes 0-7 own the channel pairs (v.x, w.x), (v.y, w.y); B: lanes 8-15 own
+// (v.z, w.z), (bogie rate, 0)).  Chassis state and the wheel's contact frame are replicated in the two lanes of a slot.
 struct GroupLane {
-    // chassis (identical in the 8 lanes of a group)
+    // chassis (identical in the 16 lanes of a group)
     float pos[3], quat[4], linvel[3], angvel[3];
     // this lane's bogie / steer joint / wheel
     float bq, bqd, sq, sqd, wq, wqd, lam;
     float steer_t, wheel_t;
     // constants of this lane's slot
     float wb[3], P[3], ax[3], b_winv, bogie_keep;
-    bool steerable, wheel_active;
+    f2 minv0, minv1;  // inverse mass pairs of the lane's two channels (negated in idle slot 7, see physics_substep_group)
+    bool steerable, wheel_active, role_b;
 };
 
-// cross-lane moves inside an 8-lane group as DPP operands (no LDS traffic): quad_perm [1,0,3,2] / [2,3,0,1] = xor 1 / 2,
-// row_half_mirror = lane i <-> 7 - i inside each group of 8
-__device__ __forceinline__ float dpp_xor1(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true)); }
-__device__ __forceinline__ float dpp_xor2(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true)); }
-__device__ __forceinline__ float dpp_half_mirror(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true)); }
-__device__ __forceinline__ float group_sum8(float x)  // ((s0+s1)+(s2+s3)) + ((s4+s5)+(s6+s7)), same value in all 8 lanes
+// cross-lane moves as DPP operands (no LDS traffic): quad_perm [1,0,3,2] / [2,3,0,1] = xor 1 / 2, row_half_mirror =
+// lane i <-> 7 - i inside each group of 8, row_ror:8 = lane i <-> i ^ 8 inside each row of 16 (the other role of the slot)
+__device__ __forceinline__ float dpp_ror8(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xF, 0xF, true)); }
+// u_r = s_r(own role) + s_r(other role) for the three rows: 3 fused v_add_f32_dpp.  The block starts with the register
+// written longest ago; s_nop 1 covers the VALU-write -> DPP-read hazard (2 wait states) of the first instruction.
+__device__ __forceinline__ void cross_role_sum3(float &a, float &b, float &c)
 {
-    x += dpp_xor1(x);
-    x += dpp_xor2(x);
-    x += dpp_half_mirror(x);  // lanes 0-3 hold the left half-sum, 4-7 the right one; addition commutes
-    return x;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "+v"(a), "+v"(b), "+v"(c));
 }
-// the seven per-iteration sums (dv[3], dw[3] over the 8-lane group, db over the bogie pair) as 3 x 7 fused v_add_f32_dpp:
-// hipcc would otherwise SLP-pack the adds into v_pk_add_f32, which cannot take a DPP operand (2 extra v_mov_dpp each).
-// s_nop 1 covers the VALU-write -> DPP-read hazard (2 wait states) for the first instruction of every level.
-__device__ __forceinline__ void group_sum8x6_pair(float &a0, float &a1, float &a2, float &a3, float &a4, float &a5, float &b)
+// The role's four contribution registers summed over the 8 wheel slots of its half-row, ((s0+s1)+(s2+s3))+((s4+s5)+(s6+s7)),
+// as 3 x 4 fused v_add_f32_dpp.  Register 2 of role B is the BOGIE channel, which is shared by the two wheels of one bogie
+// only: levels 2 and 3 are masked off for lanes 8-15 (bank_mask 0x3) on registers 2 and 3.
+__device__ __forceinline__ void slot_sum4(float &a0, float &a1, float &a2, float &a3)
 {
     asm volatile(
         "s_nop 1\n\t"
@@ -759,23 +780,15 @@ __device__ __forceinline__ void group_sum8x6_pair(float &a0, float &a1, float &a
         "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "s_nop 0\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0x3 bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0x3 bound_ctrl:1\n\t"
         "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %4, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %5, %5, %5 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1"
-        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(b));
+        "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0x3 bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0x3 bound_ctrl:1"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
 }
 
 #ifdef RV_K1_STAMP
@@ -792,6 +805,115 @@ __device__ __forceinline__ void k1_stamp(int slot)
 #else
 #define K1_STAMP(k) do { } while (0)
 #endif
+// the projected-Jacobi iterations of one lane (wheel slot x role): see the arithmetic contract above RoleRows
+__device__ __forceinline__ void solver_iteration_generic(const StepConsts &K, Contact &ct, const RoleRows &rr, f2 *V, float cw,
+                                                         float mu)
+{
+    float un = row_partial(rr.Jn, V), ut = row_partial(rr.Jt, V), us = row_partial(rr.Js, V);
+    cross_role_sum3(un, ut, us);
+    ut -= cw;
+    float dn, dt, ds;
+    impulse_update(K, ct, mu, un, ut, us, dn, dt, ds);
+    f2 o[2];
+    role_outputs(rr, dn, dt, ds, o);
+    float a0 = o[0].x, a1 = o[0].y, a2 = o[1].x, a3 = o[1].y;
+    slot_sum4(a0, a1, a2, a3);
+    V[0] += (f2){a0, a1};
+    V[1] += (f2){a2, a3};
+}
+
+// The same iteration, hand-scheduled (two iterations per loop trip).  What the measurements on gfx950 say for ONE wave per
+// SIMD (tools/ubench/bank_probe.hip): an instruction costs ~4.5 cycles of issue if it is 4 bytes (VOP1/VOP2), ~5.5 if it is
+// 8 bytes (VOP3, packed fp32, DPP), whatever its dependences; s_nop 1 costs ~8; a register written by a packed op stalls a
+// consumer in the next two slots.  So the loop is written for instruction COUNT: no moves (the accumulated impulses
+// ping-pong between two registers over the two unrolled halves), no s_nop (the 2 wait states a DPP read needs after a VALU
+// write are filled with independent work), VOP2 encodings wherever the operation allows, rows interleaved behind the
+// packed ops.  Temporaries that are used both as 32-bit and as (even-aligned) 64-bit operands live in v[238:255].
+#define RV_DPP_FULL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define RV_DPP_LANES_A " row_mask:0xf bank_mask:0x3 bound_ctrl:1\n\t"
+#define RV_SOLVER_HALF(LN_IN, LN_OUT, LT_IN, LT_OUT, LS_IN, LS_OUT, FILLER)                                            \
+    "v_pk_mul_f32 v[240:241], %[jn0], %[v0]\n\t"                                                                      \
+    "v_pk_mul_f32 v[242:243], %[jt0], %[v0]\n\t"                                                                      \
+    "v_pk_mul_f32 v[244:245], %[js0], %[v0]\n\t"                                                                      \
+    "v_pk_fma_f32 v[240:241], %[jn1], %[v1], v[240:241]\n\t"                                                          \
+    "v_pk_fma_f32 v[242:243], %[jt1], %[v1], v[242:243]\n\t"                                                          \
+    "v_pk_fma_f32 v[244:245], %[js1], %[v1], v[244:245]\n\t"                                                          \
+    "v_add_f32 v240, v240, v241\n\t"                                                                                   \
+    "v_add_f32 v242, v242, v243\n\t"                                                                                   \
+    "v_add_f32 v244, v244, v245\n\t"                                                                                   \
+    "v_add_f32_dpp v240, v240, v240 row_ror:8" RV_DPP_FULL                                                             \
+    "v_add_f32_dpp v242, v242, v242 row_ror:8" RV_DPP_FULL                                                             \
+    "v_add_f32_dpp v244, v244, v244 row_ror:8" RV_DPP_FULL                                                             \
+    "v_sub_f32 v241, %[bias], v240\n\t"                    /* bias - un                                             */ \
+    "v_sub_f32 v242, v242, %[cw]\n\t"                      /* ut - rim speed                                        */ \
+    "v_fma_f32 v243, v241, %[mn], " LN_IN "\n\t"                                                                       \
+    "v_max_f32 " LN_OUT ", 0, v243\n\t"                    /* ln                                                    */ \
+    "v_sub_f32 v246, " LN_OUT ", " LN_IN "\n\t"            /* dn                                                    */ \
+    "v_mul_f32 v245, %[mu], " LN_OUT "\n\t"                /* lim = mu * ln                                         */ \
+    "v_pk_mul_f32 v[252:253], %[mn0], v[246:247] op_sel_hi:[1,0]\n\t"                                                  \
+    "v_fmac_f32 v242, %[ant], v246\n\t"                    /* ut + a_nt * dn                                        */ \
+    "v_pk_mul_f32 v[254:255], %[mn1], v[246:247] op_sel_hi:[1,0]\n\t"                                                  \
+    "v_min_f32 v247, %[ltm], v245\n\t"                     /* lmax = min(lim, lt_motor)                             */ \
+    "v_fmac_f32 v244, %[ans], v246\n\t"                    /* us + a_ns * dn                                        */ \
+    "v_fma_f32 v243, -v242, %[mt], " LT_IN "\n\t"                                                                      \
+    "v_med3_f32 " LT_OUT ", v243, -v247, v247\n\t"         /* lt                                                    */ \
+    "v_sub_f32 v248, " LT_OUT ", " LT_IN "\n\t"            /* dt                                                    */ \
+    "v_fmac_f32 v244, %[ats], v248\n\t"                    /* ... + a_ts * dt                                       */ \
+    "v_pk_fma_f32 v[252:253], %[mt0], v[248:249], v[252:253] op_sel_hi:[1,0,1]\n\t"                                    \
+    "v_fma_f32 v243, -v244, %[ms], " LS_IN "\n\t"                                                                      \
+    "v_pk_fma_f32 v[254:255], %[mt1], v[248:249], v[254:255] op_sel_hi:[1,0,1]\n\t"                                    \
+    "v_med3_f32 " LS_OUT ", v243, -v245, v245\n\t"         /* ls                                                    */ \
+    "v_sub_f32 v250, " LS_OUT ", " LS_IN "\n\t"            /* ds                                                    */ \
+    "v_pk_fma_f32 v[252:253], %[ms0], v[250:251], v[252:253] op_sel_hi:[1,0,1]\n\t"                                    \
+    "v_pk_fma_f32 v[254:255], %[ms1], v[250:251], v[254:255] op_sel_hi:[1,0,1]\n\t"                                    \
+    FILLER                                                                                                             \
+    "v_add_f32_dpp v252, v252, v252 quad_perm:[1,0,3,2]" RV_DPP_FULL                                                   \
+    "v_add_f32_dpp v253, v253, v253 quad_perm:[1,0,3,2]" RV_DPP_FULL                                                   \
+    "v_add_f32_dpp v254, v254, v254 quad_perm:[1,0,3,2]" RV_DPP_FULL                                                   \
+    "v_add_f32_dpp v255, v255, v255 quad_perm:[1,0,3,2]" RV_DPP_FULL                                                   \
+    "v_add_f32_dpp v252, v252, v252 quad_perm:[2,3,0,1]" RV_DPP_FULL                                                   \
+    "v_add_f32_dpp v253, v253, v253 quad_perm:[2,3,0,1]" RV_DPP_FULL                                                   \
+    "v_add_f32_dpp v254, v254, v254 quad_perm:[2,3,0,1]" RV_DPP_LANES_A                                                \
+    "v_add_f32_dpp v255, v255, v255 quad_perm:[2,3,0,1]" RV_DPP_LANES_A                                                \
+    "v_add_f32_dpp v252, v252, v252 row_half_mirror" RV_DPP_FULL                                                       \
+    "v_add_f32_dpp v253, v253, v253 row_half_mirror" RV_DPP_FULL                                                       \
+    "v_add_f32_dpp v254, v254, v254 row_half_mirror" RV_DPP_LANES_A                                                    \
+    "v_add_f32_dpp v255, v255, v255 row_half_mirror" RV_DPP_LANES_A                                                    \
+    "v_pk_add_f32 %[v0], %[v0], v[252:253]\n\t"                                                                        \
+    "v_pk_add_f32 %[v1], %[v1], v[254:255]\n\t"
+
+__device__ __forceinline__ void solver_iterations_group(const StepConsts &K, Contact &ct, const RoleRows &rr, f2 *V, float cw,
+                                                        float mu, int iterations)
+{
+#ifndef RV_SOLVER_GENERIC
+    int pairs = iterations >> 1;
+    if (pairs > 0) {
+        f2 v0 = V[0], v1 = V[1];
+        float ln = ct.ln, lt = ct.lt, ls = ct.ls;
+        asm volatile(
+            "1:\n\t"
+            RV_SOLVER_HALF("%[ln]", "v249", "%[lt]", "v251", "%[ls]", "v238", "s_sub_u32 %[cnt], %[cnt], 1\n\t")
+            RV_SOLVER_HALF("v249", "%[ln]", "v251", "%[lt]", "v238", "%[ls]", "s_cmp_lg_u32 %[cnt], 0\n\t")
+            "s_cbranch_scc1 1b\n\t"
+            : [v0] "+v"(v0), [v1] "+v"(v1), [ln] "+v"(ln), [lt] "+v"(lt), [ls] "+v"(ls), [cnt] "+s"(pairs)
+            : [jn0] "v"(rr.Jn[0]), [jn1] "v"(rr.Jn[1]), [jt0] "v"(rr.Jt[0]), [jt1] "v"(rr.Jt[1]), [js0] "v"(rr.Js[0]),
+              [js1] "v"(rr.Js[1]), [mn0] "v"(rr.Mn[0]), [mn1] "v"(rr.Mn[1]), [mt0] "v"(rr.Mt[0]), [mt1] "v"(rr.Mt[1]),
+              [ms0] "v"(rr.Ms[0]), [ms1] "v"(rr.Ms[1]), [bias] "v"(ct.bias), [mn] "v"(ct.mn), [mt] "v"(ct.mt), [ms] "v"(ct.ms),
+              [ant] "v"(ct.a_nt), [ans] "v"(ct.a_ns), [ats] "v"(ct.a_ts), [cw] "v"(cw), [mu] "s"(mu), [ltm] "s"(K.lt_motor)
+            : "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251",
+              "v252", "v253", "v254", "v255", "scc");
+        V[0] = v0;
+        V[1] = v1;
+        ct.ln = ln;
+        ct.lt = lt;
+        ct.ls = ls;
+    }
+    if (iterations & 1) solver_iteration_generic(K, ct, rr, V, cw, mu);
+#else
+    for (int it = 0; it < iterations; ++it) solver_iteration_generic(K, ct, rr, V, cw, mu);
+#endif
+}
+
 template <bool RECORD_FORCE>
 __device__ __forceinline__ void physics_substep_group(const RvParams &p, const StepConsts &K, GroupLane &g,
                                                       float *Fw /* 3: this wheel's force */, int sidx = 0)
@@ -819,47 +941,36 @@ __device__ __forceinline__ void physics_substep_group(const RvParams &p, const S
     ct.ln = RV_WARM_START * g.lam;
     ct.lt = 0.0f;
     ct.ls = 0.0f;
-    if (!g.wheel_active) {
-        // idle slots 6, 7: zero directions, Jacobians and masses => every impulse and every contribution is exactly +0
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { ct.n[i] = 0.0f; ct.t[i] = 0.0f; ct.s[i] = 0.0f; ct.jn_a[i] = 0.0f; ct.jt_a[i] = 0.0f; ct.js_a[i] = 0.0f; }
-        ct.jn_b = 0.0f; ct.jt_b = 0.0f; ct.js_b = 0.0f;
-        ct.mn = 0.0f; ct.mt = 0.0f; ct.ms = 0.0f;
-        ct.a_nt = 0.0f; ct.a_ns = 0.0f; ct.a_ts = 0.0f;
-        ct.bias = 0.0f; ct.ln = 0.0f;
-    }
-    float dv[3], dw[3], db;
-    wheel_warm(K, ct, g.b_winv, dv, dw, db);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        v[i] += group_sum8(dv[i]);
-        w[i] += group_sum8(dw[i]);
-    }
-    bd += db + dpp_xor1(db);
-    const float wheel_w = g.wheel_active ? g.wqd : 0.0f;
+    // Idle slots 6, 7 shadow wheel slot 5 (same state, same contact frame, hence the same impulses) and need no zeroing: slot 7
+    // applies its contributions with NEGATED inverse masses (g.idle_sign = -1), so the first level of every cross-slot sum
+    // forms s6 + s7 = c + (-c) = +0 exactly -- the exact zero the oracle's tree has in those two places.
+    // this lane's role: two channel pairs of the Jacobians (+ prescaled copies) and of the shared velocities
+    const bool rb = g.role_b;
+    RoleRows rr;
     {
-        ContactPairs cp;
-        f2 vw[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            cp.nj[i] = (f2){ct.n[i], ct.jn_a[i]};
-            cp.tj[i] = (f2){ct.t[i], ct.jt_a[i]};
-            cp.sj[i] = (f2){ct.s[i], ct.js_a[i]};
-            cp.minv[i] = (f2){K.inv_m, K.inv_I[i]};
-            vw[i] = (f2){v[i], w[i]};
-        }
-        for (int it = 0; it < p.cfg.solver_iterations; ++it) {
-            f2 dvw[3];
-            wheel_rows_packed(K, ct, cp, vw, bd, g.b_winv, mu, wheel_w, dvw, db);
-            float a0 = dvw[0].x, a1 = dvw[1].x, a2 = dvw[2].x, a3 = dvw[0].y, a4 = dvw[1].y, a5 = dvw[2].y;
-            group_sum8x6_pair(a0, a1, a2, a3, a4, a5, db);
-            vw[0] += (f2){a0, a3};
-            vw[1] += (f2){a1, a4};
-            vw[2] += (f2){a2, a5};
-            bd += db;
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { v[i] = vw[i].x; w[i] = vw[i].y; }
+        make_role(ct, rb, g.minv0, g.minv1, rr);
+    }
+    f2 V[2];
+    V[0] = rb ? (f2){v[2], w[2]} : (f2){v[0], w[0]};
+    V[1] = rb ? (f2){bd, 0.0f} : (f2){v[1], w[1]};
+    const float cw = RV_WHEEL_CONTACT_RADIUS * g.wqd;  // rim speed prescribed by the (stiff) motor
+    {
+        // warm start: contribution of the cached normal impulse alone
+        const f2 l2 = {ct.ln, ct.ln};
+        const f2 o0 = rr.Mn[0] * l2, o1 = rr.Mn[1] * l2;
+        float a0 = o0.x, a1 = o0.y, a2 = o1.x, a3 = o1.y;
+        slot_sum4(a0, a1, a2, a3);
+        V[0] += (f2){a0, a1};
+        V[1] += (f2){a2, a3};
+    }
+    solver_iterations_group(K, ct, rr, V, cw, mu, p.cfg.solver_iterations);
+    {
+        // both roles need the full velocity again: fetch the other role's two pairs
+        const float p0x = dpp_ror8(V[0].x), p0y = dpp_ror8(V[0].y), p1x = dpp_ror8(V[1].x), p1y = dpp_ror8(V[1].y);
+        v[0] = rb ? p0x : V[0].x; w[0] = rb ? p0y : V[0].y;
+        v[1] = rb ? p1x : V[1].x; w[1] = rb ? p1y : V[1].y;
+        v[2] = rb ? V[0].x : p0x; w[2] = rb ? V[0].y : p0y;
+        bd = rb ? V[1].x : p1x;
     }
     K1_STAMP(4 + 3 * sidx);
     wheel_motor(K, g.wheel_t, ct.lt, g.wq, g.wqd);
@@ -1078,8 +1189,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
     // rover_env.py:64-72 decimation loop; the contact report is the one of the last physics step
     float F[ROVER_NUM_BODIES * 3];
-    StepConsts K;
-    make_step_consts(c.sim_dt, K);
+    const StepConsts &K = p.K;
     for (int s = 0; s < c.decimation - 1; ++s) physics_substep<false>(p, K, S, steer_m, wheel_m, nullptr);
     if (c.decimation > 0) {
         physics_substep<true>(p, K, S, steer_m, wheel_m, F);
@@ -1157,31 +1267,50 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
 }
 
-// ---- per-lane constants / state of the "group" mapping
-__device__ const float d_WHEEL_B[6][3] = RV_WHEEL_B_INIT;
-__device__ const int d_WHEEL_STEER[6] = RV_WHEEL_STEER_INIT;
-__device__ const int d_WHEEL_BODY[6] = RV_WHEEL_BODY_INIT;
-__device__ const int d_SLOT_WHEEL[6] = RV_SLOT_WHEEL_INIT;
-__device__ const float d_BOGIE_PIVOT[3][3] = RV_BOGIE_PIVOT_INIT;
-__device__ const float d_BOGIE_AXIS[3][3] = RV_BOGIE_AXIS_INIT;
+// ---- per-slot constants of the "group" mapping: one 64-byte row per wheel slot, fetched with ONE level of loads
+struct SlotConst {
+    float wb[3], P[3], ax[3];
+    int32_t k, j, si, body;   // wheel, bogie, steer joint (-1: none), contact-sensor body row
+    int32_t pad[3];
+};
+#define RV_SLOT_ROW(k_, j_, si_, body_) \
+    {{RV_WB_##k_}, {RV_BP_##j_}, {RV_BA_##j_}, k_, j_, si_, body_, {0, 0, 0}}
+#define RV_WB_0 0.44f, 0.3925f, -0.16699f
+#define RV_WB_1 0.44f, -0.3925f, -0.16699f
+#define RV_WB_2 0.007f, 0.3885f, -0.16699f
+#define RV_WB_3 0.007f, -0.3885f, -0.16699f
+#define RV_WB_4 -0.44f, 0.3925f, -0.16699f
+#define RV_WB_5 -0.44f, -0.3925f, -0.16699f
+#define RV_BP_0 0.1535f, 0.2225f, 0.03f
+#define RV_BP_1 0.1535f, -0.2225f, 0.03f
+#define RV_BP_2 -0.325f, 0.0f, 0.03f
+#define RV_BA_0 0.0f, 1.0f, 0.0f
+#define RV_BA_1 0.0f, -1.0f, 0.0f
+#define RV_BA_2 1.0f, 0.0f, 0.0f
+// slots [FL, CL, FR, CR, RL, RR, -, -] = wheels [0, 2, 1, 3, 4, 5]; the idle slots 6, 7 shadow slot 5
+__device__ const SlotConst d_SLOT[8] = {
+    RV_SLOT_ROW(0, 0, 0, 9), RV_SLOT_ROW(2, 0, -1, 7), RV_SLOT_ROW(1, 1, 1, 10), RV_SLOT_ROW(3, 1, -1, 8),
+    RV_SLOT_ROW(4, 2, 2, 11), RV_SLOT_ROW(5, 2, 3, 12), RV_SLOT_ROW(5, 2, 3, 12), RV_SLOT_ROW(5, 2, 3, 12)};
 
 struct GroupIds {
     int slot, k, j, si, body;
-    bool wheel_active;
+    bool wheel_active, role_b;
+    bool owner;  // the lane that stores this wheel's words (role A of an active slot)
 };
-__device__ __forceinline__ GroupIds group_ids(int lane)
+__device__ __forceinline__ GroupIds group_ids(int lane, const SlotConst &sc)
 {
     GroupIds id;
     id.slot = lane & 7;
+    id.role_b = (lane & 8) != 0;
     id.wheel_active = id.slot < 6;
-    const int sc = id.wheel_active ? id.slot : 5;  // idle slots 6, 7 shadow slot 5 and contribute exact zeros
-    id.k = d_SLOT_WHEEL[sc];
-    id.j = sc >> 1;
-    id.si = d_WHEEL_STEER[id.k];
-    id.body = d_WHEEL_BODY[id.k];
+    id.owner = id.wheel_active && !id.role_b;
+    id.k = sc.k;
+    id.j = sc.j;
+    id.si = sc.si;
+    id.body = sc.body;
     return id;
 }
-__device__ __forceinline__ void group_load(const float *__restrict__ state, int N, int e, const GroupIds &id,
+__device__ __forceinline__ void group_load(const float *__restrict__ state, int N, int e, const GroupIds &id, const SlotConst &sc,
                                            const StepConsts &K, GroupLane &g)
 {
 #pragma unroll
@@ -1202,9 +1331,9 @@ __device__ __forceinline__ void group_load(const float *__restrict__ state, int 
     g.lam = state[(size_t)(ROVER_LAMBDA_N + id.k) * N + e];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        g.wb[i] = d_WHEEL_B[id.k][i];
-        g.P[i] = d_BOGIE_PIVOT[id.j][i];
-        g.ax[i] = d_BOGIE_AXIS[id.j][i];
+        g.wb[i] = sc.wb[i];
+        g.P[i] = sc.P[i];
+        g.ax[i] = sc.ax[i];
     }
     {
         // per-lane pick of the bogie constants (same values as K.b_winv[j] / K.bogie_keep[j])
@@ -1216,11 +1345,18 @@ __device__ __forceinline__ void group_load(const float *__restrict__ state, int 
     }
     g.steerable = id.si >= 0;
     g.wheel_active = id.wheel_active;
+    g.role_b = id.role_b;
+    {
+        const float sg = id.slot == 7 ? -1.0f : 1.0f;
+        const float m = sg * K.inv_m;
+        g.minv0 = (f2){m, sg * (id.role_b ? K.inv_I[2] : K.inv_I[0])};
+        g.minv1 = (f2){id.role_b ? sg * g.b_winv : m, id.role_b ? 0.0f : sg * K.inv_I[1]};
+    }
 }
-// physical state back to HBM: chassis by slot 0, bogie j by slot 2j, steer / wheel words by their wheel's slot
+// physical state back to HBM: chassis by slot 0 / role A, bogie j by slot 2j, steer / wheel words by their wheel's role-A lane
 __device__ __forceinline__ void group_store(float *__restrict__ state, int N, int e, const GroupIds &id, const GroupLane &g)
 {
-    if (id.slot == 0) {
+    if (id.slot == 0 && !id.role_b) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) state[(size_t)(ROVER_POS + i) * N + e] = g.pos[i];
 #pragma unroll
@@ -1230,7 +1366,7 @@ __device__ __forceinline__ void group_store(float *__restrict__ state, int N, in
 #pragma unroll
         for (int i = 0; i < 3; ++i) state[(size_t)(ROVER_ANGVEL + i) * N + e] = g.angvel[i];
     }
-    if (id.wheel_active) {
+    if (id.owner) {
         if ((id.slot & 1) == 0) {
             state[(size_t)(ROVER_BOGIE_Q + id.j) * N + e] = g.bq;
             state[(size_t)(ROVER_BOGIE_QD + id.j) * N + e] = g.bqd;
@@ -1246,27 +1382,39 @@ __device__ __forceinline__ void group_store(float *__restrict__ state, int N, in
 }
 
 // ================================================================================================ K1g: step, group mapping
-// Eight lanes per env (64-thread workgroup = 8 envs).  Physics: one wheel per lane (slots 0..5), chassis replicated;
-// MDP tail (terminations, rewards, reset, command): replicated in the 8 lanes, stored by slot 0.
-__global__ __launch_bounds__(64) void rover_step_kernel_group(RvParams p, float *__restrict__ state,
+// Sixteen lanes per env: a wave holds 4 envs, a 256-thread workgroup 16.  The waves of a workgroup never talk to each
+// other; the workgroup exists for PLACEMENT: its four waves go to the four SIMDs of one CU, so at N = 4096 (256 workgroups
+// on 256 CUs) every SIMD issues for exactly one wave -- with single-wave workgroups two waves can land on one SIMD, where
+// the younger one starves behind the older one's VALU stream (measured: 61 us instead of 30 us).
+// Physics: one wheel slot x role per lane, chassis replicated; MDP tail (terminations, rewards, reset, command):
+// replicated in the 16 lanes, stored by lane 0 of the group.
+#define RV_K1G_THREADS 256
+#define RV_K1G_ENVS (RV_K1G_THREADS / 16)
+__global__ __launch_bounds__(RV_K1G_THREADS) void rover_step_kernel_group(RvParams p, float *__restrict__ state,
                                                               const float *__restrict__ action, float *__restrict__ obs,
                                                               float *__restrict__ reward, uint8_t *__restrict__ terminated,
                                                               uint8_t *__restrict__ truncated, float *__restrict__ force,
                                                               float *__restrict__ log_partial)
 {
-    const int lane = threadIdx.x;
-    const int e_raw = blockIdx.x * 8 + (lane >> 3);
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (RV_K1G_THREADS / 64) + (threadIdx.x >> 6);
+    const int e_raw = wave * 4 + (lane >> 4);
     const bool active = e_raw < p.n;
     const int e = active ? e_raw : p.n - 1;
     const int N = p.n;
     const rover_config &c = p.cfg;
-    const GroupIds id = group_ids(lane);
+    const SlotConst sc = d_SLOT[lane & 7];
+    const GroupIds id = group_ids(lane, sc);
     K1_STAMP(0);
 
+#ifdef RV_K1_CONSTS_IN_KERNEL
     StepConsts K;
     make_step_consts(c.sim_dt, K);
+#else
+    const StepConsts &K = p.K;
+#endif
     GroupLane g;
-    group_load(state, N, e, id, K, g);
+    group_load(state, N, e, id, sc, K, g);
     // rover_env.py:62 ActionManager.process_action
     float act[2], prev[2];
     prev[0] = state[(size_t)(ROVER_ACTION + 0) * N + e];
@@ -1274,6 +1422,13 @@ __global__ __launch_bounds__(64) void rover_step_kernel_group(RvParams p, float 
     const float2 a = reinterpret_cast<const float2 *>(action)[e];
     act[0] = a.x;
     act[1] = a.y;
+    // manager words: issued now so that their latency hides under the physics (the group mapping has registers to spare)
+    float S[ROVER_STATE_WORDS];
+#pragma unroll
+    for (int i = ROVER_TARGET_W; i < ROVER_ACTION; ++i) S[i] = state[(size_t)i * N + e];
+#pragma unroll
+    for (int i = ROVER_TIME_LEFT; i < ROVER_LAMBDA_N; ++i) S[i] = state[(size_t)i * N + e];
+    S[ROVER_RESET_COUNT] = state[(size_t)ROVER_RESET_COUNT * N + e];
     {
         float processed[2], steer[4], wheel[6];
         ackermann_one(c, act, processed, steer, wheel);
@@ -1287,13 +1442,6 @@ __global__ __launch_bounds__(64) void rover_step_kernel_group(RvParams p, float 
         g.steer_t = st;
         g.wheel_t = wt;
     }
-    // manager words: issued now so that their latency hides under the physics (the group mapping has registers to spare)
-    float S[ROVER_STATE_WORDS];
-#pragma unroll
-    for (int i = ROVER_TARGET_W; i < ROVER_ACTION; ++i) S[i] = state[(size_t)i * N + e];
-#pragma unroll
-    for (int i = ROVER_TIME_LEFT; i < ROVER_LAMBDA_N; ++i) S[i] = state[(size_t)i * N + e];
-    S[ROVER_RESET_COUNT] = state[(size_t)ROVER_RESET_COUNT * N + e];
     // rover_env.py:64-72 decimation loop
     float Fw[3] = {0.0f, 0.0f, 0.0f};
     K1_STAMP(1);
@@ -1309,13 +1457,13 @@ __global__ __launch_bounds__(64) void rover_step_kernel_group(RvParams p, float 
     for (int i = 0; i < ROVER_NUM_BODIES * 3; ++i) F[i] = 0.0f;
     {
         constexpr int BODY_SLOT[6] = {1, 3, 0, 2, 4, 5};  // bodies 7..12 = CL, CR, FL, FR, RL, RR -> solver slot
-        const int base = lane & ~7;
+        const int base = lane & ~15;
 #pragma unroll
         for (int b = 0; b < 6; ++b)
 #pragma unroll
             for (int i = 0; i < 3; ++i) F[(7 + b) * 3 + i] = __shfl(Fw[i], base + BODY_SLOT[b], 64);
     }
-    if (force && active && id.wheel_active) {
+    if (force && active && id.owner) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) force[(size_t)(id.body * 3 + i) * N + e] = Fw[i];
     }
@@ -1351,7 +1499,9 @@ __global__ __launch_bounds__(64) void rover_step_kernel_group(RvParams p, float 
         }
     }
     const bool do_reset = term_any | time_out;
-    const bool writer = active && id.slot == 0;
+    const bool writer = active && (lane & 15) == 0;
+    // episodic log contributions: only waves in which some env resets pay for the 14 wave reductions
+    const bool any_reset = __ballot(do_reset && writer) != 0ull;
     float lg[14];
 #pragma unroll
     for (int i = 0; i < 14; ++i) lg[i] = 0.0f;
@@ -1368,11 +1518,11 @@ __global__ __launch_bounds__(64) void rover_step_kernel_group(RvParams p, float 
     if (do_reset) {
         reset_one(p, S, gid);
         if (active) {
-            // the reset rewrites the root pose (slot 0 stores it below), the contact cache of every wheel and, in
+            // the reset rewrites the root pose (lane 0 stores it below), the contact cache of every wheel and, in
             // reset_mode 1, all velocities / joint words
-            if (id.wheel_active) state[(size_t)(ROVER_LAMBDA_N + id.k) * N + e] = 0.0f;
+            if (id.owner) state[(size_t)(ROVER_LAMBDA_N + id.k) * N + e] = 0.0f;
             if (c.reset_mode == 1) {
-                if (id.wheel_active) {
+                if (id.owner) {
                     state[(size_t)(ROVER_WHEEL_Q + id.k) * N + e] = 0.0f;
                     state[(size_t)(ROVER_WHEEL_QD + id.k) * N + e] = 0.0f;
                     if (id.si >= 0) {
@@ -1384,7 +1534,7 @@ __global__ __launch_bounds__(64) void rover_step_kernel_group(RvParams p, float 
                         state[(size_t)(ROVER_BOGIE_QD + id.j) * N + e] = 0.0f;
                     }
                 }
-                if (id.slot == 0) {
+                if (id.slot == 0 && !id.role_b) {
 #pragma unroll
                     for (int i = ROVER_LINVEL; i < ROVER_BOGIE_Q; ++i) state[(size_t)i * N + e] = 0.0f;
                 }
@@ -1395,13 +1545,15 @@ __global__ __launch_bounds__(64) void rover_step_kernel_group(RvParams p, float 
     command_compute(p, S, gid, step_dt);
     K1_STAMP(22);
 
+    if (any_reset) {
 #pragma unroll
-    for (int i = 0; i < 14; ++i) lg[i] = wave_sum(lg[i]);
+        for (int i = 0; i < 14; ++i) lg[i] = wave_sum(lg[i]);
+    }
     if (lane < 14) {
         float vsel = 0.0f;
 #pragma unroll
         for (int i = 0; i < 14; ++i) vsel = (lane == i) ? lg[i] : vsel;
-        log_partial[(size_t)blockIdx.x * ROVER_LOG_WORDS + lane] = vsel;
+        log_partial[(size_t)wave * ROVER_LOG_WORDS + lane] = vsel;
     }
     if (writer) {
         write_obs_head(p, S, obs, e);
@@ -1421,26 +1573,27 @@ __global__ __launch_bounds__(64) void rover_step_kernel_group(RvParams p, float 
     }
 }
 
-__global__ __launch_bounds__(64) void rover_physics_kernel_group(RvParams p, float *__restrict__ state, const float *steer_t,
-                                                                 const float *wheel_t, int substeps, float *force)
+__global__ __launch_bounds__(RV_K1G_THREADS) void rover_physics_kernel_group(RvParams p, float *__restrict__ state,
+                                                                             const float *steer_t, const float *wheel_t,
+                                                                             int substeps, float *force)
 {
-    const int lane = threadIdx.x;
-    const int e_raw = blockIdx.x * 8 + (lane >> 3);
+    const int lane = threadIdx.x & 63;
+    const int e_raw = (blockIdx.x * (RV_K1G_THREADS / 64) + (threadIdx.x >> 6)) * 4 + (lane >> 4);
     const bool active = e_raw < p.n;
     const int e = active ? e_raw : p.n - 1;
     const int N = p.n;
-    const GroupIds id = group_ids(lane);
-    StepConsts K;
-    make_step_consts(p.cfg.sim_dt, K);
+    const SlotConst sc = d_SLOT[lane & 7];
+    const GroupIds id = group_ids(lane, sc);
+    const StepConsts &K = p.K;
     GroupLane g;
-    group_load(state, N, e, id, K, g);
+    group_load(state, N, e, id, sc, K, g);
     g.steer_t = steer_t[4 * e + (id.si >= 0 ? id.si : 0)];
     g.wheel_t = wheel_t[6 * e + id.k];
     float Fw[3] = {0.0f, 0.0f, 0.0f};
     for (int s = 0; s < substeps - 1; ++s) physics_substep_group<false>(p, K, g, nullptr);
     if (substeps > 0) physics_substep_group<true>(p, K, g, Fw);
     if (active) group_store(state, N, e, id, g);
-    if (force && active && id.wheel_active) {
+    if (force && active && id.owner) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) force[(size_t)(id.body * 3 + i) * N + e] = Fw[i];
     }
@@ -1769,8 +1922,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     for (int k = 0; k < 6; ++k) wt[k] = wheel_t[6 * e + k];
 #pragma unroll
     for (int i = 0; i < ROVER_NUM_BODIES * 3; ++i) F[i] = 0.0f;
-    StepConsts K;
-    make_step_consts(p.cfg.sim_dt, K);
+    const StepConsts &K = p.K;
     for (int s = 0; s < substeps - 1; ++s) physics_substep<false>(p, K, S, st, wt, nullptr);
     if (substeps > 0) physics_substep<true>(p, K, S, st, wt, F);
 #pragma unroll
@@ -1821,7 +1973,8 @@ struct rover_sim {
     size_t ws_log_floats;
     size_t ws_bytes;
     int n_waves;       // log-partial rows written by the step kernel of the selected mapping
-    bool group_mapping; // eight lanes per env
+    int step_blocks;   // workgroups of the step kernel
+    bool group_mapping; // sixteen lanes per env
     size_t lds_bytes;
     int n_cu;          // compute units of the device
     int scan_wgs;      // persistent scan workgroups: what the device holds at once
@@ -1888,6 +2041,7 @@ int rover_create(const rover_config *cfg, int32_t num_envs, int32_t env_id_offse
     if (!s) return fail(ROVER_ERR_INVALID, "out of host memory");
     memset(s, 0, sizeof(*s));
     s->p.cfg = *cfg;
+    make_step_consts(cfg->sim_dt, s->p.K);
     s->p.n = num_envs;
     s->p.env_id_offset = env_id_offset;
     s->p.rays = cfg->scan_nx * cfg->scan_ny;
@@ -1899,11 +2053,13 @@ int rover_create(const rover_config *cfg, int32_t num_envs, int32_t env_id_offse
         s->n_cu = n_cu;
     }
     if (cfg->step_mapping < 0 || cfg->step_mapping > 2) { delete s; return fail(ROVER_ERR_INVALID, "step_mapping must be 0, 1 or 2"); }
-    // latency mapping (8 lanes per env) while one-env-per-lane would leave most SIMDs without a wave
-    s->group_mapping = cfg->step_mapping == 2 || (cfg->step_mapping == 0 && num_envs < 65536);
-    s->n_waves = s->group_mapping ? (num_envs + 7) / 8 : (num_envs + 63) / 64;
+    // latency mapping (16 lanes per env) while one-env-per-lane would leave most SIMDs without a wave
+    s->group_mapping = cfg->step_mapping == 2 || (cfg->step_mapping == 0 && num_envs < RV_GROUP_MAPPING_BELOW);
+    // log-partial rows = waves launched (the group mapping launches whole 256-thread workgroups)
+    s->step_blocks = s->group_mapping ? (num_envs + RV_K1G_ENVS - 1) / RV_K1G_ENVS : (num_envs + 63) / 64;
+    s->n_waves = s->group_mapping ? s->step_blocks * (RV_K1G_THREADS / 64) : s->step_blocks;
     // workspace: [log partials, padded to 128 B][scan descriptors: n x 32 B]
-    s->ws_log_floats = (((size_t)((num_envs + 7) / 8) * ROVER_LOG_WORDS) + 31) & ~(size_t)31;
+    s->ws_log_floats = (((size_t)(((num_envs + RV_K1G_ENVS - 1) / RV_K1G_ENVS) * (RV_K1G_THREADS / 64)) * ROVER_LOG_WORDS) + 31) & ~(size_t)31;
     s->ws_bytes = (s->ws_log_floats + (size_t)num_envs * 8) * sizeof(float);
     *out = s;
     return ROVER_OK;
@@ -2048,10 +2204,10 @@ int rover_step(rover_sim *sim, const float *action, float *obs, float *reward, u
     hipStream_t st = static_cast<hipStream_t>(stream);
     const RvParams &p = sim->p;
     if (sim->group_mapping)
-        hipLaunchKernelGGL(rover_step_kernel_group, dim3(sim->n_waves), dim3(64), 0, st, p, sim->state, action, obs, reward,
+        hipLaunchKernelGGL(rover_step_kernel_group, dim3(sim->step_blocks), dim3(RV_K1G_THREADS), 0, st, p, sim->state, action, obs, reward,
                            terminated, truncated, force, sim->log_partial);
     else
-        hipLaunchKernelGGL(rover_step_kernel, dim3(sim->n_waves), dim3(64), 0, st, p, sim->state, action, obs, reward,
+        hipLaunchKernelGGL(rover_step_kernel, dim3(sim->step_blocks), dim3(64), 0, st, p, sim->state, action, obs, reward,
                            terminated, truncated, force, sim->log_partial);
     launch_scan<2>(sim, p.n + 1, st, obs, p.obs_w, 4, sim->log_partial, sim->n_waves, log);
     HIP_TRY(hipGetLastError());
@@ -2073,10 +2229,10 @@ int rover_profile_step(rover_sim *sim, const float *action, float *obs, float *r
     for (int i = 0; i < 3; ++i) HIP_TRY(hipEventCreate(&ev[i]));
     HIP_TRY(hipEventRecord(ev[0], st));
     if (sim->group_mapping)
-        hipLaunchKernelGGL(rover_step_kernel_group, dim3(sim->n_waves), dim3(64), 0, st, p, sim->state, action, obs, reward,
+        hipLaunchKernelGGL(rover_step_kernel_group, dim3(sim->step_blocks), dim3(RV_K1G_THREADS), 0, st, p, sim->state, action, obs, reward,
                            terminated, truncated, force, sim->log_partial);
     else
-        hipLaunchKernelGGL(rover_step_kernel, dim3(sim->n_waves), dim3(64), 0, st, p, sim->state, action, obs, reward,
+        hipLaunchKernelGGL(rover_step_kernel, dim3(sim->step_blocks), dim3(64), 0, st, p, sim->state, action, obs, reward,
                            terminated, truncated, force, sim->log_partial);
     HIP_TRY(hipEventRecord(ev[1], st));
     launch_scan<2>(sim, p.n + 1, st, obs, p.obs_w, 4, sim->log_partial, sim->n_waves, log);
@@ -2171,7 +2327,7 @@ int rover_physics(rover_sim *sim, const float *steer_target, const float *wheel_
     if (!steer_target || !wheel_target || substeps < 0) return fail(ROVER_ERR_INVALID, "bad argument");
     DeviceGuard guard(sim->device);
     if (sim->group_mapping)
-        hipLaunchKernelGGL(rover_physics_kernel_group, dim3((sim->p.n + 7) / 8), dim3(64), 0, static_cast<hipStream_t>(stream),
+        hipLaunchKernelGGL(rover_physics_kernel_group, dim3((sim->p.n + RV_K1G_ENVS - 1) / RV_K1G_ENVS), dim3(RV_K1G_THREADS), 0, static_cast<hipStream_t>(stream),
                            sim->p, sim->state, steer_target, wheel_target, substeps, force);
     else
         hipLaunchKernelGGL(rover_physics_kernel, dim3((sim->p.n + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream),

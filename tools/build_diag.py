@@ -17,6 +17,10 @@ sys.path.insert(0, ROOT)
 from isaac_rover_orbit_amd import build as b  # noqa: E402
 
 VARIANTS = {"STAMP": ("rover_kernels.hip", "-DRV_K2_STAMP"), "K1STAMP": ("rover_kernels.hip", "-DRV_K1_STAMP"),
+            "K1STAMP_INK": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_K1_CONSTS_IN_KERNEL"),
+            "K1_INK": ("rover_kernels.hip", "-DRV_K1_CONSTS_IN_KERNEL"),
+            "NOSLP": ("rover_kernels.hip", "-fno-slp-vectorize"),
+            "NOSLP_STAMP": ("rover_kernels.hip", "-fno-slp-vectorize -DRV_K1_STAMP"),
             "POLSTAMP": ("policy_kernels.hip", "-DPOL_STAMP")}
 
 
@@ -28,7 +32,7 @@ def main():
     for tag in (sys.argv[1:] or list(VARIANTS)):
         src_name, define = VARIANTS[tag]
         obj = os.path.join(out_dir, f"{tag}.o")
-        subprocess.check_call([hipcc, *b.FLAGS, define, "-c", "-o", obj, os.path.join(ROOT, "isaac_rover_orbit_amd", "csrc", src_name)])
+        subprocess.check_call([hipcc, *b.FLAGS, *define.split(), "-c", "-o", obj, os.path.join(ROOT, "isaac_rover_orbit_amd", "csrc", src_name)])
         objs = [obj if os.path.basename(s) == src_name else os.path.join(b.OBJ_DIR, os.path.splitext(os.path.basename(s))[0] + ".o")
                 for s in b.SOURCES]
         lib = os.path.join(out_dir, f"librover_abl{tag}.so")

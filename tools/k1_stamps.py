@@ -8,12 +8,12 @@ from isaac_rover_orbit_amd import _lib, terrain as T
 from isaac_rover_orbit_amd.cfg import RoverEnvCfg
 from isaac_rover_orbit_amd.envs import RoverEnv
 n = 4096
-_lib.LIB_PATH = os.path.join(ROOT, "build", "abl", "librover_ablK1STAMP.so")
+_lib.LIB_PATH = os.path.join(ROOT, "build", "abl", f"librover_abl{os.environ.get('K1TAG', 'K1STAMP')}.so")
 _lib.EXPORTS.append("rover_debug_set_k1_stamps")
 ter = T.make_procedural_terrain((2048, 2048)); ter.make_spawns(2 * n)
 cfg = RoverEnvCfg(); cfg.scene.num_envs = n; cfg.terrain.kind = "custom"
 env = RoverEnv(cfg, terrain=ter); env.reset()
-stamps = torch.zeros(n // 8, 32, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(n // 16, 32, dtype=torch.int64, device="cuda")
 fn = env._lib.rover_debug_set_k1_stamps; fn.argtypes = [C.c_void_p]
 assert fn(C.c_void_p(stamps.data_ptr())) == 0
 g = torch.Generator(device="cuda").manual_seed(0)
