@@ -150,6 +150,14 @@ __device__ __forceinline__ void rv_sincosf(float x, float *s, float *c)
     *s = (q & 2) ? -ss : ss;
     *c = ((q + 1) & 2) ? -cc : cc;
 }
+// rv_sincosf for |x| < pi/4: the reduction finds k = 0 and leaves r = x, the quadrant selects pick (sp, cp) -- so the two
+// polynomials alone give bit-identical results (bogie angles are clamped to +-10 deg)
+__device__ __forceinline__ void rv_sincosf_small(float x, float *s, float *c)
+{
+    const float z = x * x;
+    *s = x + x * z * (-1.6666654611e-1f + z * (8.3321608736e-3f + z * (-1.9515295891e-4f)));
+    *c = 1.0f - 0.5f * z + z * z * (4.166664568298827e-2f + z * (-1.388731625493765e-3f + z * 2.443315711809948e-5f));
+}
 __device__ __forceinline__ float rv_sinf(float x) { float s, c; rv_sincosf(x, &s, &c); return s; }
 __device__ __forceinline__ float rv_cosf(float x) { float s, c; rv_sincosf(x, &s, &c); return c; }
 __device__ __forceinline__ float rv_atan2f(float y, float x)
@@ -280,7 +288,10 @@ __device__ __forceinline__ void terrain_sample(const RvParams &p, float x, float
 // ------------------------------------------------------------------------------------------------ (a6) command
 __device__ __forceinline__ float wrap_to_pi(float a)
 {
-    float r = fmodf(a, RV_TWO_PI_F);
+    // fmodf(a, 2 pi) for |a| < 4 pi (here |a| <= 2 pi: a difference of two headings in [-pi, pi]): the quotient is 0 or +-1 and
+    // a -+ 2 pi is exact (Sterbenz), so this IS fmodf's result -- sign of a zero result included -- without its long division
+    float r = a;
+    if (fabsf(a) >= RV_TWO_PI_F) r = copysignf(a - copysignf(RV_TWO_PI_F, a), a);
     if (r != 0.0f && r < 0.0f) r += RV_TWO_PI_F;
     if (r > RV_PI_F) r -= RV_TWO_PI_F;
     return r;
@@ -294,7 +305,7 @@ __device__ __forceinline__ float heading_of(const float *q)
 }
 // TerrainBasedPositionCommand._update_command, terrain_importer.py:97-101 (ORBIT yaw_quat + quat_rotate_inverse)
 __device__ __forceinline__ void update_command_one(const float *pos, const float *quat, const float *target_w,
-                                                   float heading_cmd_w, float *cmd_b, float *heading_b)
+                                                   float heading_cmd_w, float *cmd_b, float *heading_b, const float *heading_w = nullptr)
 {
     const float qw = quat[0], qx = quat[1], qy = quat[2], qz = quat[3];
     const float yaw = rv_atan2f(2.0f * (qw * qz + qx * qy), 1.0f - 2.0f * (qy * qy + qz * qz));
@@ -310,7 +321,7 @@ __device__ __forceinline__ void update_command_one(const float *pos, const float
     const float dt = qv[0] * v[0] + qv[1] * v[1] + qv[2] * v[2];
 #pragma unroll
     for (int i = 0; i < 3; ++i) cmd_b[i] = v[i] * s - cr[i] * yw * 2.0f + qv[i] * dt * 2.0f;
-    *heading_b = wrap_to_pi(heading_cmd_w - heading_of(quat));
+    *heading_b = wrap_to_pi(heading_cmd_w - (heading_w ? *heading_w : heading_of(quat)));
 }
 
 // ------------------------------------------------------------------------------------------------ (a9-a11) mdp terms
@@ -437,19 +448,31 @@ __device__ __forceinline__ void wheel_motor(const StepConsts &k, float target, f
     qd = v;
 }
 
+// constants of a wheel's bogie arm (functions of the slot only): d0 = wheel centre - pivot, ax x d0, ax . d0
+struct ArmConsts {
+    float d0[3], axd[3], ad;
+};
+__device__ __forceinline__ ArmConsts make_arm(const float *wb, const float *P, const float *ax)
+{
+    ArmConsts a;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a.d0[i] = wb[i] - P[i];
+    cross3f(ax, a.d0, a.axd);
+    a.ad = dot3f(ax, a.d0);
+    return a;
+}
 // contact geometry, Jacobians, split effective masses and bias of ONE wheel
 template <bool WANT_OBST>
 __device__ __forceinline__ void wheel_geometry(const RvParams &p, const StepConsts &k, const float R[3][3], const float *pos,
-                                               const float *com_w, const float *wb, const float *P, const float *ax,
+                                               const float *com_w, const ArmConsts &arm, const float *P, const float *ax,
                                                float b_winv, float bq, bool at_hi, bool at_lo, bool steerable, float steer_q,
                                                Contact &ct)
 {
-    const float d0[3] = {wb[0] - P[0], wb[1] - P[1], wb[2] - P[2]};
+    const float *d0 = arm.d0, *axd = arm.axd;
+    const float ad = arm.ad;
     float sb, cb;
-    rv_sincosf(bq, &sb, &cb);
-    float axd[3];
-    cross3f(ax, d0, axd);
-    const float ad = dot3f(ax, d0);
+    if (fabsf(bq) < 0.75f) rv_sincosf_small(bq, &sb, &cb);   // always, for states the integrator produced (|bq| <= 10 deg)
+    else rv_sincosf(bq, &sb, &cb);
     float cen_b[3], cen_w[3], piv_w[3], ax_w[3], tmp[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) cen_b[i] = P[i] + fmaf(ax[i], ad * (1.0f - cb), fmaf(axd[i], sb, d0[i] * cb));
@@ -573,7 +596,8 @@ __device__ __forceinline__ void impulse_update(const StepConsts &k, Contact &ct,
 
 // chassis integration shared by both mappings: velocity cap, symplectic Euler, quaternion update
 __device__ __forceinline__ void chassis_integrate(float h, const float R[3][3], float *v, float *wb, float *com_w,
-                                                  float *pos, float *quat, float *linvel, float *angvel)
+                                                  float *pos, float *quat, float *linvel, float *angvel,
+                                                  float (*R_next)[3] = nullptr, float *com_off_next = nullptr)
 {
     constexpr float COM_B[3] = RV_COM_B_INIT;
     const float sp = sqrtf(dot3f(v, v));
@@ -600,6 +624,14 @@ __device__ __forceinline__ void chassis_integrate(float h, const float R[3][3], 
     mat_vecf(R2, COM_B, com_off);
 #pragma unroll
     for (int i = 0; i < 3; ++i) pos[i] = com_w[i] - com_off[i];
+    if (R_next) {  // the next substep starts from exactly these values (same quaternion): hand them over instead of re-forming
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            com_off_next[i] = com_off[i];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) R_next[i][j] = R2[i][j];
+        }
+    }
 }
 
 __device__ __forceinline__ void bogie_integrate(float h, float bq0, float bdv, float &q_out, float &qd_out)
@@ -668,7 +700,8 @@ __device__ __forceinline__ void physics_substep(const RvParams &p, const StepCon
         const float wb[3] = {WHEEL_B[k][0], WHEEL_B[k][1], WHEEL_B[k][2]};
         const float P[3] = {BOGIE_PIVOT[j][0], BOGIE_PIVOT[j][1], BOGIE_PIVOT[j][2]};
         const float ax[3] = {BOGIE_AXIS[j][0], BOGIE_AXIS[j][1], BOGIE_AXIS[j][2]};
-        wheel_geometry<RECORD_FORCE>(p, K, R, S + ROVER_POS, com_w, wb, P, ax, K.b_winv[j], bq[j], at_hi[j], at_lo[j], si >= 0,
+        const ArmConsts arm = make_arm(wb, P, ax);
+        wheel_geometry<RECORD_FORCE>(p, K, R, S + ROVER_POS, com_w, arm, P, ax, K.b_winv[j], bq[j], at_hi[j], at_lo[j], si >= 0,
                                      S[ROVER_STEER_Q + (si >= 0 ? si : 0)], C[s]);
         C[s].ln = RV_WARM_START * S[ROVER_LAMBDA_N + k];
         C[s].lt = 0.0f;
@@ -746,11 +779,13 @@ __device__ __forceinline__ void physics_substep(const RvParams &p, const StepCon
 struct GroupLane {
     // chassis (identical in the 16 lanes of a group)
     float pos[3], quat[4], linvel[3], angvel[3];
+    float R[3][3], com_off[3];  // rotation matrix of `quat` and R * COM_B, carried from substep to substep
     // this lane's bogie / steer joint / wheel
     float bq, bqd, sq, sqd, wq, wqd, lam;
     float steer_t, wheel_t;
     // constants of this lane's slot
-    float wb[3], P[3], ax[3], b_winv, bogie_keep;
+    float P[3], ax[3], b_winv, bogie_keep;
+    ArmConsts arm;
     f2 minv0, minv1;  // inverse mass pairs of the lane's two channels (negated in idle slot 7, see physics_substep_group)
     bool steerable, wheel_active, role_b;
 };
@@ -923,12 +958,13 @@ __device__ __forceinline__ void physics_substep_group(const RvParams &p, const S
     const float h = K.h;
     const float mu = p.cfg.friction_mu;
     if (g.steerable) steer_joint(K, g.steer_t, g.sq, g.sqd);
-    float R[3][3];
-    quat_to_mat(g.quat, R);
-    float com_off[3], com_w[3];
-    mat_vecf(R, COM_B, com_off);
+    float R[3][3], com_w[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) com_w[i] = g.pos[i] + com_off[i];
+    for (int i = 0; i < 3; ++i) {
+        com_w[i] = g.pos[i] + g.com_off[i];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) R[i][j] = g.R[i][j];
+    }
     float v[3] = {g.linvel[0], g.linvel[1], fmaf(-RV_GRAVITY, h, g.linvel[2])};
     float w[3];
     mat_tvecf(R, g.angvel, w);
@@ -936,7 +972,7 @@ __device__ __forceinline__ void physics_substep_group(const RvParams &p, const S
     float bd = g.bqd * g.bogie_keep;
     const bool at_hi = bq >= RV_BOGIE_QLIM - 1.0e-5f, at_lo = bq <= -RV_BOGIE_QLIM + 1.0e-5f;
     Contact ct;
-    wheel_geometry<RECORD_FORCE>(p, K, R, g.pos, com_w, g.wb, g.P, g.ax, g.b_winv, bq, at_hi, at_lo, g.steerable, g.sq, ct);
+    wheel_geometry<RECORD_FORCE>(p, K, R, g.pos, com_w, g.arm, g.P, g.ax, g.b_winv, bq, at_hi, at_lo, g.steerable, g.sq, ct);
     K1_STAMP(3 + 3 * sidx);
     ct.ln = RV_WARM_START * g.lam;
     ct.lt = 0.0f;
@@ -980,7 +1016,7 @@ __device__ __forceinline__ void physics_substep_group(const RvParams &p, const S
 #pragma unroll
         for (int i = 0; i < 3; ++i) Fw[i] = on ? fmaf(ct.s[i], ct.ls, fmaf(ct.t[i], ct.lt, ct.n[i] * ct.ln)) * K.inv_h : 0.0f;
     }
-    chassis_integrate(h, R, v, w, com_w, g.pos, g.quat, g.linvel, g.angvel);
+    chassis_integrate(h, R, v, w, com_w, g.pos, g.quat, g.linvel, g.angvel, g.R, g.com_off);
     bogie_integrate(h, bq, bd, g.bq, g.bqd);
 }
 
@@ -1064,11 +1100,12 @@ __device__ __forceinline__ void reset_one(const RvParams &p, float *S, uint32_t 
 // CommandTerm.compute: metrics -> timer -> (resample) -> update (terrain_importer.py:97-106)
 __device__ __forceinline__ void command_compute(const RvParams &p, float *S, uint32_t gid, float step_dt)
 {
+    const float heading_w = heading_of(S + ROVER_QUAT);   // the pose does not change inside this function
     {
         const float dx = S[ROVER_TARGET_W] - S[ROVER_POS], dy = S[ROVER_TARGET_W + 1] - S[ROVER_POS + 1],
                     dz = S[ROVER_TARGET_W + 2] - S[ROVER_POS + 2];
         S[ROVER_METRIC_POS] = sqrtf(dx * dx + dy * dy + dz * dz);
-        S[ROVER_METRIC_HEAD] = fabsf(wrap_to_pi(S[ROVER_HEADING_CMD_W] - heading_of(S + ROVER_QUAT)));
+        S[ROVER_METRIC_HEAD] = fabsf(wrap_to_pi(S[ROVER_HEADING_CMD_W] - heading_w));
     }
     S[ROVER_TIME_LEFT] -= step_dt;
     if (S[ROVER_TIME_LEFT] <= 0.0f) {
@@ -1078,7 +1115,7 @@ __device__ __forceinline__ void command_compute(const RvParams &p, float *S, uin
         resample_command(p, S, gid, count ^ 0x80000000u, u01(r[2]));
     }
     update_command_one(S + ROVER_POS, S + ROVER_QUAT, S + ROVER_TARGET_W, S[ROVER_HEADING_CMD_W], S + ROVER_CMD_B,
-                       S + ROVER_HEADING_CMD_B);
+                       S + ROVER_HEADING_CMD_B, &heading_w);
 }
 
 // observation head [last_action(2), distance * 0.11, heading / pi] (ObservationCfg, rover_env_cfg.py:97-123)
@@ -1331,10 +1368,10 @@ __device__ __forceinline__ void group_load(const float *__restrict__ state, int 
     g.lam = state[(size_t)(ROVER_LAMBDA_N + id.k) * N + e];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        g.wb[i] = sc.wb[i];
         g.P[i] = sc.P[i];
         g.ax[i] = sc.ax[i];
     }
+    g.arm = make_arm(sc.wb, sc.P, sc.ax);
     {
         // per-lane pick of the bogie constants (same values as K.b_winv[j] / K.bogie_keep[j])
         float bw = K.b_winv[0], bk = K.bogie_keep[0];
@@ -1346,6 +1383,11 @@ __device__ __forceinline__ void group_load(const float *__restrict__ state, int 
     g.steerable = id.si >= 0;
     g.wheel_active = id.wheel_active;
     g.role_b = id.role_b;
+    {
+        constexpr float COM_B[3] = RV_COM_B_INIT;
+        quat_to_mat(g.quat, g.R);
+        mat_vecf(g.R, COM_B, g.com_off);
+    }
     {
         const float sg = id.slot == 7 ? -1.0f : 1.0f;
         const float m = sg * K.inv_m;
@@ -1451,11 +1493,12 @@ __global__ __launch_bounds__(RV_K1G_THREADS) void rover_step_kernel_group(RvPara
     if (!id.wheel_active) { Fw[0] = 0.0f; Fw[1] = 0.0f; Fw[2] = 0.0f; }
     if (active) group_store(state, N, e, id, g);
 
-    // contact report: gather the six Drive-body forces of the env (sensor body order) into every lane
+    // contact report: gather the six Drive-body forces of the env (sensor body order) into every lane -- only in waves
+    // where some wheel stands on the obstacle layer (otherwise every force is the +0 the array already holds)
     float F[ROVER_NUM_BODIES * 3];
 #pragma unroll
     for (int i = 0; i < ROVER_NUM_BODIES * 3; ++i) F[i] = 0.0f;
-    {
+    if (__ballot(Fw[0] != 0.0f || Fw[1] != 0.0f || Fw[2] != 0.0f) != 0ull) {
         constexpr int BODY_SLOT[6] = {1, 3, 0, 2, 4, 5};  // bodies 7..12 = CL, CR, FL, FR, RL, RR -> solver slot
         const int base = lane & ~15;
 #pragma unroll
@@ -1467,6 +1510,7 @@ __global__ __launch_bounds__(RV_K1G_THREADS) void rover_step_kernel_group(RvPara
 #pragma unroll
         for (int i = 0; i < 3; ++i) force[(size_t)(id.body * 3 + i) * N + e] = Fw[i];
     }
+    K1_STAMP(23);
 
     // ---- MDP tail on the manager words (replicated in the group; loaded before the physics, see above)
 #pragma unroll
@@ -1486,6 +1530,7 @@ __global__ __launch_bounds__(RV_K1G_THREADS) void rover_step_kernel_group(RvPara
     float rew[ROVER_NUM_REW];
     bool term[ROVER_NUM_TERM];
     mdp_terms_one(c, S + ROVER_CMD_B, S + ROVER_ACTION, S + ROVER_PREV_ACTION, ep_len, F, rew, term);
+    K1_STAMP(24);
     const bool time_out = term[0];
     const bool term_any = term[1] | term[2] | term[3];
     const float step_dt = c.sim_dt * (float)c.decimation;
@@ -1571,6 +1616,7 @@ __global__ __launch_bounds__(RV_K1G_THREADS) void rover_step_kernel_group(RvPara
         terminated[e] = term_any ? 1 : 0;
         truncated[e] = time_out ? 1 : 0;
     }
+    K1_STAMP(25);
 }
 
 __global__ __launch_bounds__(RV_K1G_THREADS) void rover_physics_kernel_group(RvParams p, float *__restrict__ state,

@@ -25,13 +25,14 @@ s = stamps.cpu().numpy().astype(np.float64)
 names = {0: "start", 1: "state loaded + ackermann"}
 for i in range(6):
     names[2 + 3 * i] = f"sub{i} start"; names[3 + 3 * i] = f"sub{i} geometry done"; names[4 + 3 * i] = f"sub{i} solver done"
-names.update({20: "physics done", 21: "mdp/reset done", 22: "command done"})
-keys = sorted(names)
+names.update({20: "physics done", 23: "state stored + force gathered", 24: "mdp terms done", 21: "rewards + reset done", 22: "command done", 25: "log + final stores done"})
+order = [0, 1] + [k for i in range(6) for k in (2 + 3 * i, 3 + 3 * i, 4 + 3 * i)] + [20, 23, 24, 21, 22, 25]
+keys = order
 prev = None
-tot = np.median(s[:, 22] - s[:, 0])
+tot = np.median(s[:, 25] - s[:, 0])
 for k in keys:
     if prev is not None:
         d = s[:, k] - s[:, prev]
         print(f"{names[k]:28s} +{np.median(d):8.0f} cycles (p90 {np.percentile(d, 90):8.0f})")
     prev = k
-print("total start->command done median", tot, "cycles")
+print("total start->end median", tot, "cycles")
