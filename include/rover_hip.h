@@ -76,7 +76,11 @@ typedef struct rover_config {
     int32_t solver_iterations;
     int32_t max_target_tries;
     int32_t step_mapping;    /* mapping of the step kernel: 0 = auto (by num_envs), 1 = one env per lane,
-                                2 = eight lanes per env (wave-cooperative); results are bit-identical */
+                                2 = sixteen lanes per env (wave-cooperative); results are bit-identical */
+    int32_t scan_surface;    /* surface the vertical rays of the height scanner hit (RayCasterCfg mesh_prim_paths,
+                                rover_env_cfg.py:84): 0 = the TRIANGLE MESH of the heightfield (every 0.05 m cell split
+                                along its (i, j) - (i+1, j+1) diagonal: what a mesh ray-cast of that terrain returns),
+                                1 = the bilinear patch (smooth; the wheels' contact surface) */
 } rover_config;
 
 typedef struct rover_sim rover_sim;
@@ -98,6 +102,12 @@ int rover_destroy(rover_sim *sim);
  *   spawns     (n_spawns, 3) fp32 spawn table                     -- terrain_utils.py:330-385                   */
 int rover_set_terrain(rover_sim *sim, const float *height, const float *obstacle, const uint8_t *safe_mask, int32_t H,
                       int32_t W, float resolution, float min_x, float min_y, const float *spawns, int32_t n_spawns);
+
+/* Optional: a separate (H, W) fp32 heightmap for HeightmapManager.get_height_at (the z of a sampled target,
+ * terrain_importer.py:153-155 -> terrain_utils.py:62-84).  The reference builds that heightmap by bounding-box rasterisation
+ * (terrain_utils.py:23-57), which is NOT the surface its physics and ray-caster see (the mesh itself); terrains ingested
+ * from a mesh therefore carry both.  NULL = use `height` (procedural terrains: one and the same array). */
+int rover_set_terrain_lookup(rover_sim *sim, const float *lookup_height);
 
 /* Optional: an EXACT 16-bit copy of `height` for the ray-caster kernel -- height[i] == height_q[i] * q_scale for every
  * cell, q_scale a positive power of two (checked; anything else is ROVER_ERR_INVALID).  The caller guarantees the

@@ -5,6 +5,7 @@
  *     rover_envs/envs/navigation/utils/terrains/terrain_utils.py
  *         HeightmapManager.mesh_to_heightmap          :23-57    -> rover_terrain_rasterize
  *         TerrainManager.find_rocks_in_heightmap      :265-311  -> rover_terrain_rock_mask
+ *     and adds rover_terrain_surface: the mesh's true height at the grid nodes (what the reference's RayCaster / PhysX see)
  * (random_rover_spawns :330-385 draws from numpy's legacy MT19937 stream and stays on the host.)
  *
  * Conventions as in rover_hip.h: plain C, caller-owned DEVICE buffers, int return codes, rover_last_error() for the
@@ -29,6 +30,17 @@ extern "C" {
  * Asynchronous on `stream`. */
 int rover_terrain_rasterize(const int32_t *bbox, const float *zmax, int32_t n_faces, float *height, int32_t H, int32_t W,
                             void *stream);
+
+/* The surface the wheels touch and the height scanner's rays hit, sampled from the SOURCE MESH: height[j, i] = z of the
+ * first hit of a vertical ray from above through node (min_x + i * res, min_y + j * res) = max over the triangles whose
+ * xy-projection covers the node of the triangle's plane there; nodes no triangle covers stay at -99.  (The reference
+ * ray-casts the hidden terrain mesh itself, rover_env_cfg.py:78-86; its bounding-box heightmap above over-estimates every
+ * slope and is kept for what the reference uses it for: target / spawn look-ups.)
+ *   tri      (n_faces, 9) fp64   triangle corners (ax, ay, az, bx, by, bz, cx, cy, cz)
+ *   node_box (n_faces, 4) int32  {min_i, max_i, min_j, max_j}: nodes inside the triangle's bounding box, clamped to the grid
+ * Same arithmetic as isaac_rover_orbit_amd/terrain.py::mesh_surface_heights (bit-identical).  Asynchronous on `stream`. */
+int rover_terrain_surface(const double *tri, const int32_t *node_box, int32_t n_faces, float *height, int32_t H, int32_t W,
+                          double min_x, double min_y, double resolution, void *stream);
 
 /* find_rocks_in_heightmap, terrain_utils.py:265-311: Sobel (wrap) gradient magnitude > threshold -> MORPH_CLOSE 3x3 ->
  * fill holes -> MORPH_OPEN 7x7 -> dilate 11x11 (`rock`) -> dilate 42x42 (`safe`); cv2 anchor convention for the even

@@ -23,7 +23,8 @@ EXPORTS = [
     "rover_reset", "rover_reset_with_draws", "rover_set_seed", "rover_step", "rover_profile_step",
     "rover_profile_event_overhead", "rover_mdp_terms", "rover_ackermann", "rover_height_scan", "rover_physics", "rover_model_constants",
     "rover_state_words", "rover_config_bytes", "rover_last_error", "rover_version",
-    "rover_terrain_rasterize", "rover_terrain_rock_mask", "rover_terrain_scratch_bytes",   # include/rover_terrain.h
+    "rover_terrain_rasterize", "rover_terrain_surface", "rover_terrain_rock_mask", "rover_terrain_scratch_bytes",   # rover_terrain.h
+    "rover_set_terrain_lookup",
     "rover_policy_default_desc", "rover_policy_packed_floats", "rover_policy_pack", "rover_policy_forward",  # rover_policy.h
 ]
 POLICY_MAX_LAYERS = 8
@@ -63,7 +64,7 @@ class RoverConfig(C.Structure):
         ("scan_height_offset", C.c_float), ("scan_nx", C.c_int32), ("scan_ny", C.c_int32),
         ("reset_z_offset", C.c_float), ("reset_mode", C.c_int32), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
         ("friction_mu", C.c_float), ("solver_iterations", C.c_int32), ("max_target_tries", C.c_int32),
-        ("step_mapping", C.c_int32),
+        ("step_mapping", C.c_int32), ("scan_surface", C.c_int32),
     ]
 
 
@@ -120,6 +121,8 @@ def load():
     lib.rover_physics.argtypes = [vp, vp, vp, i32, vp, vp]
     lib.rover_model_constants.argtypes = [vp, i32]
     lib.rover_terrain_rasterize.argtypes = [vp, vp, i32, vp, i32, i32, vp]
+    lib.rover_terrain_surface.argtypes = [vp, vp, i32, vp, i32, i32, C.c_double, C.c_double, C.c_double, vp]
+    lib.rover_set_terrain_lookup.argtypes = [vp, vp]
     lib.rover_terrain_rock_mask.argtypes = [vp, i32, i32, C.c_double, vp, vp, vp, vp]
     lib.rover_terrain_scratch_bytes.argtypes = [i32, i32]
     lib.rover_terrain_scratch_bytes.restype = C.c_size_t

@@ -50,6 +50,9 @@ class RayCasterCfg:
     attach_yaw_only: bool = True
     max_distance: float = 100.0
     height_offset: float = 0.26878   # observations.py:45
+    # what the vertical rays hit: "triangles" = the triangle mesh of the heightfield (each cell split along its
+    # (i, j) - (i+1, j+1) diagonal; what ORBIT's Warp mesh ray-cast of that terrain returns), "bilinear" = smooth patch
+    surface: str = "triangles"
 
     @property
     def grid(self):
@@ -154,7 +157,7 @@ class RoverEnvCfg:
     seed: int = 0
     friction: float = 0.75
     solver_iterations: int = 16             # Jacobi sweeps of the contact solver (ORBIT cfg: 32 position iterations)
-    step_mapping: str = "auto"              # "auto" | "lane" (one env per lane) | "group" (eight lanes per env)
+    step_mapping: str = "auto"              # "auto" | "lane" (one env per lane) | "group" (sixteen lanes per env)
     record_contact_forces: bool = True       # materialise contact_sensor.data.force_matrix_w every step
     use_int16_terrain: bool = True           # stage the exact int16 copy of the heightfield in the scan kernel when it exists
     # multi-GPU sharding: this process simulates global env ids [env_id_offset, env_id_offset + num_envs)
@@ -211,6 +214,7 @@ class RoverEnvCfg:
         c.scan_resolution, c.scan_size_x, c.scan_size_y = hs.resolution, hs.size[0], hs.size[1]
         c.scan_nx, c.scan_ny = hs.grid
         c.scan_height_offset = hs.height_offset
+        c.scan_surface = {"triangles": 0, "bilinear": 1}[hs.surface]
         c.reset_z_offset = self.reset_z_offset
         c.reset_mode = 0 if self.reset_velocities == "reference" else 1
         c.seed_lo, c.seed_hi = self.seed & 0xFFFFFFFF, (self.seed >> 32) & 0xFFFFFFFF

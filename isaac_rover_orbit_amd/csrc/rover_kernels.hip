@@ -68,6 +68,7 @@ struct RvParams {
     rover_config cfg;
     StepConsts K;
     const float *height;
+    const float *lookup;     // heightmap of HeightmapManager.get_height_at (target z); == height unless set separately
     const float *obstacle;
     const uint8_t *safe_mask;
     const float *spawns;
@@ -1060,7 +1061,7 @@ __device__ __forceinline__ void resample_command(const RvParams &p, float *S, ui
     quirk_cell(p, tx, ty, cx, cy);
     S[ROVER_TARGET_W + 0] = tx;
     S[ROVER_TARGET_W + 1] = ty;
-    S[ROVER_TARGET_W + 2] = p.height[(size_t)cy * p.W + cx] + 0.0f;
+    S[ROVER_TARGET_W + 2] = p.lookup[(size_t)cy * p.W + cx] + 0.0f;
     S[ROVER_HEADING_CMD_W] = heading_u * (c.heading_hi - c.heading_lo) + c.heading_lo;
     S[ROVER_TIME_LEFT] = c.resample_time;
 }
@@ -1683,7 +1684,8 @@ __global__ __launch_bounds__(64) void rover_reset_kernel(RvParams p, float *__re
 #ifndef RV_K2_THREADS
 #define RV_K2_THREADS 512   // 8 waves share the LDS tiles; <= 40 KiB of LDS per workgroup admits 4 workgroups = 32 waves per CU
 #endif
-template <int MODE, bool Q16>
+//   TRI     the rays hit the triangle mesh of the heightfield (cfg.scan_surface = 0) instead of the bilinear patch
+template <int MODE, bool Q16, bool TRI>
 __global__ __launch_bounds__(RV_K2_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void rover_scan_obs_kernel(RvParams p, const float *__restrict__ state,
                                                              float *__restrict__ out, int row_stride, int col0,
                                                              const float *__restrict__ log_partial, int n_waves,
@@ -1835,14 +1837,25 @@ __global__ __launch_bounds__(RV_K2_THREADS) __attribute__((amdgpu_waves_per_eu(8
     RV_STAMP(3);
 
     float *row = out + (size_t)e * row_stride + col0;
-    // bilinear height from four staged cells; for the int16 tile the interpolation runs on the raw integers and is scaled
-    // once at the end: q_scale is a power of two, so this is bit-identical to interpolating the scaled heights
+    // surface height from four staged cells: the plane of the cell's triangle the ray falls in (cells split along the
+    // (i, j) - (i+1, j+1) diagonal: what a ray-cast of the terrain's triangle mesh returns) or the bilinear patch.  For the
+    // int16 tile the interpolation runs on the raw integers and is scaled once at the end: q_scale is a power of two, so
+    // this is bit-identical to interpolating the scaled heights
     auto bilerp = [&](const cell_t *q, float fx, float fy) -> float {
         const float h00 = (float)q[0], h01 = (float)q[1], h10 = (float)q[pitch], h11 = (float)q[pitch + 1];
-        const float dx0 = h01 - h00, dx1 = h11 - h10;
-        const float hx0 = h00 + fx * dx0;
-        const float hx1 = h10 + fx * dx1;
-        const float hh = hx0 + fy * (hx1 - hx0);
+        float hh;
+        if (TRI) {
+            const bool lower = fx >= fy;                       // lower triangle: corners 00, 01, 11; upper: 00, 10, 11
+            const float pm = lower ? h01 : h10;
+            const float d1 = pm - h00, d2 = h11 - pm;
+            const float a = lower ? d1 : d2, b = lower ? d2 : d1;
+            hh = fmaf(fy, b, fmaf(fx, a, h00));
+        } else {
+            const float dx0 = h01 - h00, dx1 = h11 - h10;
+            const float hx0 = h00 + fx * dx0;
+            const float hx1 = h10 + fx * dx1;
+            hh = hx0 + fy * (hx1 - hx0);
+        }
         return Q16 ? hh * p.q_scale : hh;
     };
     // one vertical ray: bilinear height of the staged tile at the yaw-rotated grid point.  FAST (whole-workgroup uniform,
@@ -2033,12 +2046,15 @@ static void launch_scan(rover_sim *sim, int grid, hipStream_t st, float *out, in
                         int n_waves, float *log_out)
 {
     grid = (sim->p.n < sim->scan_wgs ? sim->p.n : sim->scan_wgs) + (MODE == 2 ? 1 : 0);
-    if (sim->p.height_q)
-        hipLaunchKernelGGL((rover_scan_obs_kernel<MODE, true>), dim3(grid), dim3(RV_K2_THREADS), sim->lds_bytes, st, sim->p,
-                           sim->state, out, row_stride, col0, log_partial, n_waves, log_out, sim->p.scan_desc);
-    else
-        hipLaunchKernelGGL((rover_scan_obs_kernel<MODE, false>), dim3(grid), dim3(RV_K2_THREADS), sim->lds_bytes, st, sim->p,
-                           sim->state, out, row_stride, col0, log_partial, n_waves, log_out, sim->p.scan_desc);
+    const bool q16 = sim->p.height_q != nullptr, tri = sim->p.cfg.scan_surface == 0;
+#define RV_LAUNCH_SCAN(Q, T)                                                                                                  \
+    hipLaunchKernelGGL((rover_scan_obs_kernel<MODE, Q, T>), dim3(grid), dim3(RV_K2_THREADS), sim->lds_bytes, st, sim->p,       \
+                       sim->state, out, row_stride, col0, log_partial, n_waves, log_out, sim->p.scan_desc)
+    if (q16 && tri) RV_LAUNCH_SCAN(true, true);
+    else if (q16) RV_LAUNCH_SCAN(true, false);
+    else if (tri) RV_LAUNCH_SCAN(false, true);
+    else RV_LAUNCH_SCAN(false, false);
+#undef RV_LAUNCH_SCAN
 }
 
 extern "C" {
@@ -2069,6 +2085,7 @@ int rover_default_config(rover_config *c)
     c->solver_iterations = 16;
     c->step_mapping = 0;
     c->max_target_tries = 32;
+    c->scan_surface = 0;
     return ROVER_OK;
 }
 
@@ -2078,7 +2095,8 @@ int rover_create(const rover_config *cfg, int32_t num_envs, int32_t env_id_offse
     if (num_envs <= 0 || env_id_offset < 0) return fail(ROVER_ERR_INVALID, "num_envs must be > 0 and env_id_offset >= 0");
     if (cfg->scan_nx > 64 || cfg->scan_ny > 64) return fail(ROVER_ERR_UNSUPPORTED, "scan grid larger than 64 x 64 rays");
     if (cfg->scan_nx <= 0 || cfg->scan_ny <= 0 || cfg->scan_resolution <= 0.0f || cfg->decimation < 0 ||
-        cfg->solver_iterations < 0 || cfg->max_target_tries < 1 || cfg->sim_dt <= 0.0f || cfg->max_episode_length <= 0)
+        cfg->solver_iterations < 0 || cfg->max_target_tries < 1 || cfg->sim_dt <= 0.0f || cfg->max_episode_length <= 0 ||
+        cfg->scan_surface < 0 || cfg->scan_surface > 1)
         return fail(ROVER_ERR_INVALID, "invalid rover_config");
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count));
@@ -2124,7 +2142,7 @@ int rover_set_terrain(rover_sim *sim, const float *height, const float *obstacle
     if (!height || !obstacle || !safe_mask || !spawns) return fail(ROVER_ERR_INVALID, "terrain pointer is NULL");
     if (H < 2 || W < 2 || resolution <= 0.0f || n_spawns < 1) return fail(ROVER_ERR_INVALID, "bad terrain shape");
     RvParams &p = sim->p;
-    p.height = height; p.obstacle = obstacle; p.safe_mask = safe_mask; p.spawns = spawns;
+    p.height = height; p.lookup = height; p.obstacle = obstacle; p.safe_mask = safe_mask; p.spawns = spawns;
     p.H = H; p.W = W; p.n_spawns = n_spawns; p.res = resolution; p.min_x = min_x; p.min_y = min_y;
     // LDS tile: diagonal of the ray pattern in cells + slack
     const float diag = sqrtf(p.cfg.scan_size_x * p.cfg.scan_size_x + p.cfg.scan_size_y * p.cfg.scan_size_y);
@@ -2134,6 +2152,14 @@ int rover_set_terrain(rover_sim *sim, const float *height, const float *obstacle
     configure_tile(sim, 4);
     if (sim->lds_bytes > 64 * 1024) return fail(ROVER_ERR_UNSUPPORTED, "ray pattern too large for the LDS tile (64 KiB)");
     sim->have_terrain = true;
+    return ROVER_OK;
+}
+
+int rover_set_terrain_lookup(rover_sim *sim, const float *lookup_height)
+{
+    if (!sim) return fail(ROVER_ERR_INVALID, "sim is NULL");
+    if (!sim->have_terrain) return fail(ROVER_ERR_STATE, "rover_set_terrain has not been called");
+    sim->p.lookup = lookup_height ? lookup_height : sim->p.height;
     return ROVER_OK;
 }
 

@@ -256,6 +256,10 @@ class RoverEnv(RLTaskEnv):
                                                    H, W, float(terrain.resolution), float(terrain.min_x),
                                                    float(terrain.min_y), _ptr(self._spawns_dev),
                                                    int(self._spawns_dev.shape[0])), "rover_set_terrain")
+            self._lookup_dev = None
+            if terrain.lookup_height is not None:   # mesh-ingested terrain: the reference's look-up heightmap next to the surface
+                self._lookup_dev = torch.from_numpy(terrain.lookup_height).to(dev)
+                _lib.check(self._lib.rover_set_terrain_lookup(h, _ptr(self._lookup_dev)), "rover_set_terrain_lookup")
             self._height_q_dev = None
             q16 = terrain.height_q16() if getattr(self.cfg, "use_int16_terrain", True) else None
             if q16 is not None:     # exact 16-bit copy for the ray-caster kernel (half the staged bytes, same results)

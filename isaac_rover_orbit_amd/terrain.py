@@ -79,6 +79,53 @@ def mesh_to_heightmap(vertices: np.ndarray, faces: np.ndarray, resolution: float
 
 
 # ----------------------------------------------------------------------------------------------- rock masks
+def mesh_node_boxes(vertices: np.ndarray, faces: np.ndarray, shape, min_x: float, min_y: float, resolution: float = RESOLUTION):
+    """Per-triangle corners (F, 9) fp64 and the grid NODES inside each triangle's xy bounding box (F, 4) int32
+    ``{min_i, max_i, min_j, max_j}`` (clamped to the grid; empty boxes have max < min) -- shared by the host loop below and the
+    device kernel (``terrain_hip.mesh_surface_heights``)."""
+    tri = np.asarray(vertices, dtype=np.float64)[np.asarray(faces).astype(np.int64)]       # (F, 3, 3)
+    lo, hi = tri[:, :, :2].min(axis=1), tri[:, :, :2].max(axis=1)
+    H, W = shape
+    min_i = np.maximum(np.ceil((lo[:, 0] - min_x) / resolution - 1e-9), 0).astype(np.int64)
+    max_i = np.minimum(np.floor((hi[:, 0] - min_x) / resolution + 1e-9), W - 1).astype(np.int64)
+    min_j = np.maximum(np.ceil((lo[:, 1] - min_y) / resolution - 1e-9), 0).astype(np.int64)
+    max_j = np.minimum(np.floor((hi[:, 1] - min_y) / resolution + 1e-9), H - 1).astype(np.int64)
+    box = np.stack([min_i, max_i, min_j, max_j], axis=1).astype(np.int32)
+    return np.ascontiguousarray(tri.reshape(-1, 9)), box
+
+
+def mesh_surface_heights(vertices: np.ndarray, faces: np.ndarray, shape, min_x: float, min_y: float,
+                         resolution: float = RESOLUTION) -> np.ndarray:
+    """Height of the mesh at every grid node: z of the first hit of a vertical ray from above through
+    ``(min_x + i * res, min_y + j * res)`` = max over the covering triangles of the triangle's plane there; -99 where no
+    triangle covers the node.  This is the surface the reference's RayCaster (mesh ray-cast, rover_env_cfg.py:78-86) and
+    PhysX see; ``mesh_to_heightmap`` above (bounding-box max) is only what the reference uses for target / spawn look-ups.
+    Host loop over triangles (fine up to ~1e5 faces); ``terrain_hip.mesh_surface_heights`` is the device version (identical
+    arithmetic, bit-identical result)."""
+    tri, box = mesh_node_boxes(vertices, faces, shape, min_x, min_y, resolution)
+    H, W = shape
+    out = np.full((H, W), -99.0, dtype=np.float32)
+    for f in range(tri.shape[0]):
+        i0, i1, j0, j1 = (int(v) for v in box[f])
+        if i1 < i0 or j1 < j0:
+            continue
+        ax, ay, az, bx, by, bz, cx, cy, cz = (float(v) for v in tri[f])
+        den = (by - cy) * (ax - cx) + (cx - bx) * (ay - cy)
+        if den == 0.0:
+            continue
+        px = (min_x + resolution * np.arange(i0, i1 + 1, dtype=np.float64))[None, :]
+        py = (min_y + resolution * np.arange(j0, j1 + 1, dtype=np.float64))[:, None]
+        w0 = ((by - cy) * (px - cx) + (cx - bx) * (py - cy)) / den
+        w1 = ((cy - ay) * (px - cx) + (ax - cx) * (py - cy)) / den
+        w2 = 1.0 - w0 - w1
+        inside = (w0 >= -1e-9) & (w1 >= -1e-9) & (w2 >= -1e-9)
+        if inside.any():
+            z = (w0 * az + w1 * bz + w2 * cz).astype(np.float32)
+            blk = out[j0:j1 + 1, i0:i1 + 1]
+            np.maximum(blk, np.where(inside, z, np.float32(-99.0)), out=blk)
+    return out
+
+
 def _dilate(mask: np.ndarray, k: int) -> np.ndarray:
     """cv2.dilate with a k x k ones kernel, default anchor (k // 2) and default (ignored) border:
     dst(y, x) = max src(y + dy, x + dx), dy, dx in [-(k // 2), k - 1 - k // 2]."""
@@ -208,6 +255,9 @@ class Terrain:
     safe_rock_mask: np.ndarray | None = None
     spawn_locations: np.ndarray | None = None
     backend: str = "numpy"   # who derives the rock masks: "numpy" (host, as the reference) or "hip" (device kernels)
+    # heightmap of HeightmapManager.get_height_at (target z look-ups).  None = `height` (procedural terrains); terrains
+    # ingested from a mesh carry the reference's bounding-box heightmap here next to the exact mesh surface in `height`
+    lookup_height: np.ndarray | None = None
     height: np.ndarray = field(init=False)
 
     def __post_init__(self):
@@ -215,15 +265,20 @@ class Terrain:
         self.obstacle = np.ascontiguousarray(self.obstacle, dtype=np.float32)
         assert self.ground.shape == self.obstacle.shape and self.ground.ndim == 2
         self.height = (self.ground + self.obstacle).astype(np.float32)
+        if self.lookup_height is not None:
+            self.lookup_height = np.ascontiguousarray(self.lookup_height, dtype=np.float32)
+            assert self.lookup_height.shape == self.ground.shape
         if self.backend not in ("numpy", "hip"):
             raise ValueError(f"unknown terrain backend {self.backend!r}")
         if self.rock_mask is None or self.safe_rock_mask is None:
+            # the reference derives the masks from ITS heightmap (terrain_utils.py:118-121)
+            src = self.lookup_height if self.lookup_height is not None else self.height
             if self.backend == "hip":   # explicit choice, no fallback: raises without the HIP library / a GPU
                 from . import terrain_hip
-                rock, safe = terrain_hip.find_rocks_in_heightmap(self.height, GRADIENT_THRESHOLD)
+                rock, safe = terrain_hip.find_rocks_in_heightmap(src, GRADIENT_THRESHOLD)
                 self.rock_mask, self.safe_rock_mask = rock.cpu().numpy(), safe.cpu().numpy()
             else:
-                self.rock_mask, self.safe_rock_mask = find_rocks_in_heightmap(self.height, GRADIENT_THRESHOLD)
+                self.rock_mask, self.safe_rock_mask = find_rocks_in_heightmap(src, GRADIENT_THRESHOLD)
 
     @property
     def shape(self):
@@ -245,7 +300,9 @@ class Terrain:
 
     def make_spawns(self, n_spawns: int, seed=SPAWN_SEED, border_offset=SPAWN_BORDER_M) -> np.ndarray:
         """Spawn table of the reference: ``n_spawns = 2 * num_envs`` (terrain_utils.py:123-124)."""
-        self.spawn_locations = random_rover_spawns(self.safe_rock_mask, self.height, n_spawns, self.min_x, self.min_y,
+        # the reference reads the spawn heights off ITS heightmap (terrain_utils.py:122-124)
+        hm = self.lookup_height if self.lookup_height is not None else self.height
+        self.spawn_locations = random_rover_spawns(self.safe_rock_mask, hm, n_spawns, self.min_x, self.min_y,
                                                    self.resolution, border_offset, seed)
         return self.spawn_locations
 
@@ -259,7 +316,7 @@ class Terrain:
 
     def get_height_at(self, xy: np.ndarray) -> np.ndarray:
         cx, cy = self.cell_of(xy)
-        return self.height[cy, cx]
+        return (self.lookup_height if self.lookup_height is not None else self.height)[cy, cx]
 
     def target_invalid(self, xy: np.ndarray) -> np.ndarray:
         cx, cy = self.cell_of(xy)
@@ -287,31 +344,57 @@ def make_procedural_terrain(shape=(2048, 2048), seed=1234, sigma_z=0.15, n_rocks
 
 
 def terrain_from_mesh(vertices, faces, ground_vertices=None, ground_faces=None, backend: str = "numpy",
-                      quantize: float | None = None) -> Terrain:
-    """Ingest triangle meshes the way ``TerrainManager.__init__`` does (terrain_utils.py:92-127): the merged
-    (hidden) mesh gives the heightmap; an optional ground-only mesh of the same extent (``terrain_only.usd``) gives
-    the ground layer, and the obstacle layer is their positive difference.  Without it the terrain has no obstacles.
-    ``quantize`` (a power of two, e.g. ``2 ** -12``) snaps the heights to that quantum -- a deviation of at most half a
-    quantum from the mesh -- which gives the terrain an exact int16 copy for the ray-caster kernel.
+                      quantize: float | None = None, surface: str = "mesh") -> Terrain:
+    """Ingest triangle meshes the way ``TerrainManager.__init__`` does (terrain_utils.py:92-127) -- and keep what the
+    reference's *simulation* sees next to what its *look-ups* see:
+
+    * ``lookup_height`` = ``mesh_to_heightmap`` of the merged (hidden) mesh: the reference's bounding-box heightmap, used
+      exactly where the reference uses it (rock masks, spawn heights, target z);
+    * ``height`` (ground + obstacle) = the mesh surface itself sampled at the grid nodes (``surface="mesh"``, default): what
+      the reference's ray-caster hits and its wheels stand on (rover_env_cfg.py:78-86, debug_terrains.py:17-52).  With
+      ``surface="heightmap"`` the bounding-box heightmap doubles as the surface (the round-1 behaviour; over-estimates every
+      slope by up to one triangle's height range).
+
+    An optional ground-only mesh of the same extent (``terrain_only.usd``) gives the ground layer, and the obstacle layer is
+    the positive difference of the two surfaces.  Without it the terrain has no obstacles.  ``quantize`` (a power of two, e.g.
+    ``2 ** -12``) snaps the surface heights to that quantum -- at most half a quantum off the mesh -- which gives the terrain an
+    exact int16 copy for the ray-caster kernel.
     """
+    if surface not in ("mesh", "heightmap"):
+        raise ValueError("surface must be 'mesh' or 'heightmap'")
     if backend == "hip":
         from . import terrain_hip
 
         def to_hm(v, f):
             h, x0, y0, x1, y1 = terrain_hip.mesh_to_heightmap(v, f)
             return h.cpu().numpy(), x0, y0, x1, y1
+
+        def to_surface(v, f, shape, x0, y0):
+            return terrain_hip.mesh_surface_heights(v, f, shape, x0, y0).cpu().numpy()
     else:
-        to_hm = mesh_to_heightmap
-    hm, min_x, min_y, _, _ = to_hm(vertices, faces)
+        to_hm, to_surface = mesh_to_heightmap, mesh_surface_heights
+
+    def layer(v, f):
+        hm, x0, y0, _, _ = to_hm(v, f)
+        if surface == "heightmap":
+            return hm, hm, x0, y0
+        surf = to_surface(v, f, hm.shape, float(x0), float(y0))
+        surf = np.where(surf <= -98.0, hm, surf).astype(np.float32)   # nodes no triangle covers: the look-up value
+        return hm, surf, x0, y0
+
+    hm, surf, min_x, min_y = layer(vertices, faces)
     if quantize is not None:
-        hm = quantize_heights(hm, quantize)
+        surf = quantize_heights(surf, quantize)
+    lookup = None if surface == "heightmap" else hm
     if ground_vertices is None:
-        return Terrain(ground=hm, obstacle=np.zeros_like(hm), min_x=float(min_x), min_y=float(min_y), backend=backend)
-    gm, gx, gy, _, _ = to_hm(ground_vertices, ground_faces)
+        return Terrain(ground=surf, obstacle=np.zeros_like(surf), min_x=float(min_x), min_y=float(min_y), backend=backend,
+                       lookup_height=lookup)
+    _, gsurf, gx, gy = layer(ground_vertices, ground_faces)
     if quantize is not None:
-        gm = quantize_heights(gm, quantize)
-    if gm.shape != hm.shape or abs(gx - min_x) > 1e-6 or abs(gy - min_y) > 1e-6:
+        gsurf = quantize_heights(gsurf, quantize)
+    if gsurf.shape != surf.shape or abs(gx - min_x) > 1e-6 or abs(gy - min_y) > 1e-6:
         raise ValueError("ground mesh and merged mesh must cover the same extent")
-    obstacle = np.maximum(hm - gm, 0.0).astype(np.float32)
+    obstacle = np.maximum(surf - gsurf, 0.0).astype(np.float32)
     obstacle[obstacle < 1e-3] = 0.0
-    return Terrain(ground=hm - obstacle, obstacle=obstacle, min_x=float(min_x), min_y=float(min_y), backend=backend)
+    return Terrain(ground=surf - obstacle, obstacle=obstacle, min_x=float(min_x), min_y=float(min_y), backend=backend,
+                   lookup_height=lookup)

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .terrain import GRADIENT_THRESHOLD, RESOLUTION, mesh_bounding_boxes
+from .terrain import GRADIENT_THRESHOLD, RESOLUTION, mesh_bounding_boxes, mesh_node_boxes
 
 
 def _stream(device) -> C.c_void_p:
@@ -42,6 +42,24 @@ def mesh_to_heightmap(vertices: np.ndarray, faces: np.ndarray, resolution: float
                                                int(shape[0]), int(shape[1]), _stream(dev)), "rover_terrain_rasterize")
         torch.cuda.current_stream(dev).synchronize()   # bbox_d / zmax_d may be freed after this
     return hm, min_x, min_y, max_x, max_y
+
+
+def mesh_surface_heights(vertices: np.ndarray, faces: np.ndarray, shape, min_x: float, min_y: float,
+                         resolution: float = RESOLUTION, device="cuda") -> torch.Tensor:
+    """``(H, W)`` fp32 device tensor: the mesh's height at every grid node (``rover_terrain_surface``; bit-identical to
+    ``terrain.mesh_surface_heights``).  The per-triangle node boxes are computed on the host (vectorised, O(F))."""
+    dev = _device(device)
+    lib = _lib.load()
+    tri, box = mesh_node_boxes(vertices, faces, shape, float(min_x), float(min_y), resolution)
+    with torch.cuda.device(dev):
+        tri_d = torch.from_numpy(tri).to(dev)
+        box_d = torch.from_numpy(np.ascontiguousarray(box)).to(dev)
+        hm = torch.empty(tuple(shape), dtype=torch.float32, device=dev)
+        _lib.check(lib.rover_terrain_surface(tri_d.data_ptr(), box_d.data_ptr(), int(tri.shape[0]), hm.data_ptr(), int(shape[0]),
+                                             int(shape[1]), float(min_x), float(min_y), float(resolution), _stream(dev)),
+                   "rover_terrain_surface")
+        torch.cuda.current_stream(dev).synchronize()
+    return hm
 
 
 def find_rocks_in_heightmap(heightmap, threshold: float = GRADIENT_THRESHOLD, device="cuda"):

@@ -78,6 +78,7 @@ typedef struct {
     int32_t solver_iterations;
     int32_t max_target_tries;
     int32_t step_mapping;        /* GPU-side kernel mapping selector; ignored by the oracle */
+    int32_t scan_surface;        /* 0 = triangle mesh of the heightfield (cells split along (i,j)-(i+1,j+1)), 1 = bilinear */
 } rvo_config;
 
 typedef struct {
@@ -88,6 +89,7 @@ typedef struct {
     float resolution, min_x, min_y;
     const float *spawns;          /* (n_spawns, 3) spawn table (terrain_utils.py:330-385)                     */
     int32_t n_spawns;
+    const float *lookup;          /* (H, W) heightmap of get_height_at (target z); NULL = `height`              */
 } rvo_terrain;
 
 void rvo_default_config(rvo_config *cfg);

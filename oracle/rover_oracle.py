@@ -38,7 +38,7 @@ class Config(C.Structure):
         ("scan_height_offset", C.c_float), ("scan_nx", C.c_int32), ("scan_ny", C.c_int32),
         ("reset_z_offset", C.c_float), ("reset_mode", C.c_int32), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
         ("friction_mu", C.c_float), ("solver_iterations", C.c_int32), ("max_target_tries", C.c_int32),
-        ("step_mapping", C.c_int32),
+        ("step_mapping", C.c_int32), ("scan_surface", C.c_int32),
     ]
 
 
@@ -46,7 +46,7 @@ class Terrain(C.Structure):
     _fields_ = [
         ("height", C.c_void_p), ("obstacle", C.c_void_p), ("safe_mask", C.c_void_p),
         ("H", C.c_int32), ("W", C.c_int32), ("resolution", C.c_float), ("min_x", C.c_float), ("min_y", C.c_float),
-        ("spawns", C.c_void_p), ("n_spawns", C.c_int32),
+        ("spawns", C.c_void_p), ("n_spawns", C.c_int32), ("lookup", C.c_void_p),
     ]
 
 
@@ -96,15 +96,17 @@ def default_config(**overrides) -> Config:
 class TerrainData:
     """Keeps the numpy arrays alive behind the C struct."""
 
-    def __init__(self, height, obstacle=None, safe_mask=None, resolution=0.05, min_x=0.0, min_y=0.0, spawns=None):
+    def __init__(self, height, obstacle=None, safe_mask=None, resolution=0.05, min_x=0.0, min_y=0.0, spawns=None,
+                 lookup=None):
         self.height = _f32(height)
+        self.lookup = _f32(lookup) if lookup is not None else None
         H, W = self.height.shape
         self.obstacle = _f32(obstacle) if obstacle is not None else np.zeros((H, W), np.float32)
         self.safe_mask = (np.ascontiguousarray(safe_mask, dtype=np.uint8) if safe_mask is not None
                           else np.zeros((H, W), np.uint8))
         self.spawns = _f32(spawns) if spawns is not None else np.zeros((1, 3), np.float32)
         self.c = Terrain(_p(self.height), _p(self.obstacle), _p(self.safe_mask), H, W, resolution, min_x, min_y,
-                         _p(self.spawns), self.spawns.shape[0])
+                         _p(self.spawns), self.spawns.shape[0], _p(self.lookup))
 
 
 def model_constants() -> np.ndarray:

@@ -23,7 +23,7 @@ def oracle_terrain(ro, ter, n_spawns=None, spawn_seed=41):
     if n_spawns is not None and (ter.spawn_locations is None or ter.spawn_locations.shape[0] != n_spawns):
         ter.make_spawns(n_spawns, seed=spawn_seed)
     return ro.TerrainData(ter.height, ter.obstacle, ter.safe_rock_mask, ter.resolution, ter.min_x, ter.min_y,
-                          ter.spawn_locations)
+                          ter.spawn_locations, lookup=getattr(ter, "lookup_height", None))
 
 
 def oracle_config_from(ro, native):

@@ -41,6 +41,24 @@ def test_mesh_to_heightmap_matches_host():
     assert np.array_equal(hm.cpu().numpy(), ref) and (ref == -99).any() and (ref == 0).any()
 
 
+def test_mesh_surface_matches_host_and_feeds_terrain_from_mesh():
+    """rover_terrain_surface (the mesh's height at the grid nodes) is bit-identical to terrain.mesh_surface_heights, also
+    through terrain_from_mesh(backend="hip"), which keeps the reference's bounding-box heightmap as the look-up layer."""
+    from isaac_rover_orbit_amd import terrain as T, terrain_hip as TH
+    verts, faces = _grid_mesh(141, 117, 14.0, 11.6, seed=9)
+    verts[:, 0] += 0.013
+    verts[:, 1] -= 0.021                                    # vertices off the 0.05 m grid
+    hm, x0, y0, _, _ = T.mesh_to_heightmap(verts, faces)
+    ref = T.mesh_surface_heights(verts, faces, hm.shape, float(x0), float(y0))
+    dev = TH.mesh_surface_heights(verts, faces, hm.shape, float(x0), float(y0)).cpu().numpy()
+    assert np.array_equal(dev, ref)
+    assert ((ref > -99) & (ref <= hm + 1e-6)).mean() > 0.5
+    a = T.terrain_from_mesh(verts, faces)
+    b = T.terrain_from_mesh(verts, faces, backend="hip")
+    assert np.array_equal(a.height, b.height) and np.array_equal(a.lookup_height, b.lookup_height)
+    assert np.array_equal(a.safe_rock_mask, b.safe_rock_mask)
+
+
 @pytest.mark.parametrize("name", ["quad", "wavy"])
 def test_mesh_to_heightmap_golden(golden_dir, name):
     """The reference's own mesh_to_heightmap outputs (tools/gen_golden.py) through the device rasteriser."""

@@ -73,9 +73,40 @@ def test_procedural_terrain_contract():
 
 
 def test_terrain_from_mesh_roundtrip(golden_dir):
+    """A mesh-ingested terrain carries the reference's bounding-box heightmap for the look-ups (golden fixture) and the
+    mesh surface itself for the wheels / ray-caster; surface="heightmap" reproduces the one-layer round-1 behaviour."""
     h = np.load(f"{golden_dir}/heightmap.npz")
     t = T.terrain_from_mesh(h["wavy_vertices"], h["wavy_faces"])
-    assert np.array_equal(t.height, h["wavy_heightmap"]) and (t.obstacle == 0).all()
+    assert np.array_equal(t.lookup_height, h["wavy_heightmap"]) and (t.obstacle == 0).all()
+    assert np.array_equal(t.get_height_at(h["wavy_query_xy"]), h["wavy_query_height"])        # reference look-ups unchanged
+    assert (t.height <= t.lookup_height + 1e-6).all(), "bounding-box max can only over-estimate the mesh"
+    assert (t.lookup_height - t.height).max() > 0.01
+    one = T.terrain_from_mesh(h["wavy_vertices"], h["wavy_faces"], surface="heightmap")
+    assert np.array_equal(one.height, h["wavy_heightmap"]) and one.lookup_height is None
+
+
+def test_mesh_surface_is_the_exact_vertical_ray_hit(golden_dir):
+    """mesh_surface_heights == first hit of a vertical ray through every grid node (the reference's RayCaster semantics,
+    rover_env_cfg.py:78-86), checked against the exact float64 mesh ray-cast of oracle/mesh_raycast.py."""
+    from oracle import mesh_raycast as mr
+    h = np.load(f"{golden_dir}/heightmap.npz")
+    V, F = h["wavy_vertices"], h["wavy_faces"]
+    t = T.terrain_from_mesh(V, F)
+    H, W = t.shape
+    X, Y = np.meshgrid(t.min_x + 0.05 * np.arange(W), t.min_y + 0.05 * np.arange(H), indexing="xy")
+    z = mr.vertical_ray_hits(V, F, np.stack([X.ravel(), Y.ravel()], 1)).reshape(H, W)
+    hit = np.isfinite(z)
+    assert hit.mean() > 0.99
+    assert np.abs(t.height[hit] - z[hit]).max() < 1e-6
+    # and between the nodes the triangle surface of the heightfield stays close to the mesh (0.25 m triangles, smooth sheet)
+    rng = np.random.RandomState(0)
+    q = np.stack([rng.uniform(t.min_x + 0.1, t.min_x + 0.05 * (W - 3), 4000), rng.uniform(t.min_y + 0.1, t.min_y + 0.05 * (H - 3), 4000)], 1)
+    zq = mr.vertical_ray_hits(V, F, q)
+    hv, hf = mr.heightfield_mesh(t.height, 0.05, t.min_x, t.min_y)
+    zs = mr.vertical_ray_hits(hv, hf, q)
+    zl = mr.vertical_ray_hits(*mr.heightfield_mesh(t.lookup_height, 0.05, t.min_x, t.min_y), q)
+    assert np.abs(zs - zq).max() < 2e-3, "node-sampled surface follows the mesh"
+    assert np.abs(zl - zq).max() > 0.05, "the bounding-box heightmap does not (it is a look-up table, not a surface)"
 
 
 def test_exact_int16_copy_and_mesh_quantisation():
