@@ -77,6 +77,13 @@ typedef struct rover_config {
     int32_t max_target_tries;
     int32_t step_mapping;    /* mapping of the step kernel: 0 = auto (by num_envs), 1 = one env per lane,
                                 2 = sixteen lanes per env (wave-cooperative); results are bit-identical */
+    int32_t spawn_draw;      /* how a reset picks its spawn table row (randomizations.py:22 `randperm(len(table))[:k]`):
+                                1 = DISTINCT rows inside one reset batch, like the reference's randperm prefix: row =
+                                (a * global_env_id + b) mod n_spawns, (a, b) redrawn for every reset()/step() call from
+                                (seed, call counter), gcd(a, n_spawns) = 1 -- a bijection of the env ids, so no two envs
+                                that reset together share a row (needs n_spawns >= global num_envs; the reference's
+                                table has 2 x num_envs rows); 0 = independent uniform row per env (with replacement) */
+    uint32_t counter_lo, counter_hi; /* initial value of the call counter (rover_set_counter / checkpoint resume) */
     int32_t scan_surface;    /* surface the vertical rays of the height scanner hit (RayCasterCfg mesh_prim_paths,
                                 rover_env_cfg.py:84): 0 = the TRIANGLE MESH of the heightfield (every 0.05 m cell split
                                 along its (i, j) - (i+1, j+1) diagonal: what a mesh ray-cast of that terrain returns),
@@ -139,6 +146,11 @@ int rover_reset_with_draws(rover_sim *sim, const uint8_t *mask, const int32_t *s
 /* Replaces env.seed(seed) / reset(seed=...) (gymnasium contract): new key of the counter-based RNG used by the resets
  * that follow.  Host only, takes effect with the next launch. */
 int rover_set_seed(rover_sim *sim, uint32_t seed_lo, uint32_t seed_hi);
+
+/* The call counter: number of rover_reset / rover_step launches so far (= env.common_step_counter + resets).  It keys the
+ * per-batch spawn permutation (spawn_draw = 1); save it with the state words to resume a rollout bit for bit. */
+int rover_get_counter(const rover_sim *sim, uint64_t *counter);
+int rover_set_counter(rover_sim *sim, uint64_t counter);
 
 /* Replaces RoverEnv.step (rover_env.py:42-102), including the in-step reset of finished envs (_reset_idx :27-39,
  * reset_root_state_rover randomizations.py:12-39, TerrainBasedPositionCommand._resample_command

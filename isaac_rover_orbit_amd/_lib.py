@@ -20,7 +20,7 @@ CMD_B, HEADING_CMD_B, EP_SUM, METRIC_POS, METRIC_HEAD, LAMBDA_N, RESET_COUNT = 5
 
 EXPORTS = [
     "rover_default_config", "rover_create", "rover_destroy", "rover_set_terrain", "rover_set_terrain_q16", "rover_workspace_bytes", "rover_bind",
-    "rover_reset", "rover_reset_with_draws", "rover_set_seed", "rover_step", "rover_profile_step",
+    "rover_reset", "rover_reset_with_draws", "rover_set_seed", "rover_get_counter", "rover_set_counter", "rover_step", "rover_profile_step",
     "rover_profile_event_overhead", "rover_mdp_terms", "rover_ackermann", "rover_height_scan", "rover_physics", "rover_model_constants",
     "rover_state_words", "rover_config_bytes", "rover_last_error", "rover_version",
     "rover_terrain_rasterize", "rover_terrain_surface", "rover_terrain_rock_mask", "rover_terrain_scratch_bytes",   # rover_terrain.h
@@ -64,7 +64,8 @@ class RoverConfig(C.Structure):
         ("scan_height_offset", C.c_float), ("scan_nx", C.c_int32), ("scan_ny", C.c_int32),
         ("reset_z_offset", C.c_float), ("reset_mode", C.c_int32), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
         ("friction_mu", C.c_float), ("solver_iterations", C.c_int32), ("max_target_tries", C.c_int32),
-        ("step_mapping", C.c_int32), ("scan_surface", C.c_int32),
+        ("step_mapping", C.c_int32), ("spawn_draw", C.c_int32), ("counter_lo", C.c_uint32), ("counter_hi", C.c_uint32),
+        ("scan_surface", C.c_int32),
     ]
 
 
@@ -112,6 +113,8 @@ def load():
     lib.rover_reset.argtypes = [vp, vp, vp]
     lib.rover_reset_with_draws.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     lib.rover_set_seed.argtypes = [vp, C.c_uint32, C.c_uint32]
+    lib.rover_get_counter.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.rover_set_counter.argtypes = [vp, C.c_uint64]
     lib.rover_profile_event_overhead.argtypes = [vp, vp, i32, C.POINTER(C.c_float)]
     lib.rover_mdp_terms.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.rover_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]

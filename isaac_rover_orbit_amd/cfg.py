@@ -154,6 +154,9 @@ class RoverEnvCfg:
     terrain: TerrainCfg = field(default_factory=TerrainCfg)
     reset_z_offset: float = 0.5              # randomizations.py:12
     reset_velocities: str = "reference"      # "reference" (root pose only, B-17) | "zero"
+    # spawn row of a reset (randomizations.py:22 draws a randperm prefix): "distinct" = no two envs reset in the same call
+    # share a row (like the reference), "independent" = one uniform draw per env (rows may repeat)
+    spawn_draw: str = "distinct"
     seed: int = 0
     friction: float = 0.75
     solver_iterations: int = 16             # Jacobi sweeps of the contact solver (ORBIT cfg: 32 position iterations)
@@ -176,6 +179,8 @@ class RoverEnvCfg:
                     raise ValueError(f"{what} term '{name}' must use func '{fn}' (got '{table[name].func}')")
         if self.reset_velocities not in ("reference", "zero"):
             raise ValueError("reset_velocities must be 'reference' or 'zero'")
+        if self.spawn_draw not in ("distinct", "independent"):
+            raise ValueError("spawn_draw must be 'distinct' or 'independent'")
         if self.commands.simple_heading:
             raise ValueError("simple_heading=True is not supported (the reference cfg uses False, rover_env_cfg.py:195)")
 
@@ -217,6 +222,7 @@ class RoverEnvCfg:
         c.scan_surface = {"triangles": 0, "bilinear": 1}[hs.surface]
         c.reset_z_offset = self.reset_z_offset
         c.reset_mode = 0 if self.reset_velocities == "reference" else 1
+        c.spawn_draw = {"independent": 0, "distinct": 1}[self.spawn_draw]
         c.seed_lo, c.seed_hi = self.seed & 0xFFFFFFFF, (self.seed >> 32) & 0xFFFFFFFF
         c.friction_mu = self.friction
         c.solver_iterations = self.solver_iterations

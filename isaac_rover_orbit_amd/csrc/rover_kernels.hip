@@ -75,6 +75,7 @@ struct RvParams {
     int H, W, n_spawns;
     float res, min_x, min_y;
     int n, env_id_offset;
+    uint32_t spawn_a, spawn_b;  // spawn_draw = 1: row = (spawn_a * global id + spawn_b) mod n_spawns for this launch
     int rays, obs_w;
     int tile_dim;    // LDS tile rows (cells) for the scan kernel
     int tile_pitch;  // cells per LDS tile row (multiple of the cells per 16-byte chunk)
@@ -179,13 +180,14 @@ __device__ __forceinline__ float rv_atan2f(float y, float x)
 }
 
 // Philox4x32-10, counter = (global env id, reset count, draw block, stream), key = seed
-__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
-                                           uint32_t out[4])
+__host__ __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                                    uint32_t out[4])
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += 0x9E3779B9u;
@@ -1073,7 +1075,11 @@ __device__ __forceinline__ void reset_one(const RvParams &p, float *S, uint32_t 
     const uint32_t count = __float_as_uint(S[ROVER_RESET_COUNT]);
     uint32_t r[4];
     philox4x32(gid, count, 0u, 0u, c.seed_lo, c.seed_hi, r);
-    const uint32_t row = inj ? (uint32_t)inj->spawn_row : r[0] % (uint32_t)p.n_spawns;
+    uint32_t row;
+    if (inj) row = (uint32_t)inj->spawn_row;
+    else if (c.spawn_draw == 1)   // distinct rows inside one reset batch (randomizations.py:22: a randperm prefix)
+        row = (uint32_t)(((uint64_t)p.spawn_a * (uint64_t)(gid % (uint32_t)p.n_spawns) + (uint64_t)p.spawn_b) % (uint64_t)p.n_spawns);
+    else row = r[0] % (uint32_t)p.n_spawns;
     const float px = p.spawns[3 * row + 0], py = p.spawns[3 * row + 1];
     const float pz = p.spawns[3 * row + 2] + c.reset_z_offset;
     const float angle = (inj ? inj->yaw_u : u01(r[1])) * 2.0f * RV_PI_F;
@@ -2033,6 +2039,7 @@ struct rover_sim {
     size_t ws_bytes;
     int n_waves;       // log-partial rows written by the step kernel of the selected mapping
     int step_blocks;   // workgroups of the step kernel
+    uint64_t counter;  // rover_reset / rover_step launches so far (keys the per-batch spawn permutation)
     bool group_mapping; // sixteen lanes per env
     size_t lds_bytes;
     int n_cu;          // compute units of the device
@@ -2040,6 +2047,22 @@ struct rover_sim {
 };
 
 static void configure_tile(rover_sim *sim, int chunk_cells);
+
+// spawn_draw = 1: (a, b) of this launch's affine row bijection from (seed, call counter); then the counter advances.
+// Same arithmetic as spawn_affine() of the oracle.
+static uint32_t gcd_u32(uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; }
+static void next_batch(rover_sim *sim)
+{
+    RvParams &p = sim->p;
+    const uint32_t n = (uint32_t)p.n_spawns;
+    uint32_t r[4];
+    philox4x32((uint32_t)(sim->counter & 0xFFFFFFFFu), (uint32_t)(sim->counter >> 32), 0x5eedu, 2u, p.cfg.seed_lo, p.cfg.seed_hi, r);
+    uint32_t a = n > 1 ? r[0] % n : 0u;
+    while (n > 1 && gcd_u32(a, n) != 1u) a = (a + 1u) % n;
+    p.spawn_a = a;
+    p.spawn_b = n > 0 ? r[1] % n : 0u;
+    ++sim->counter;
+}
 
 template <int MODE>
 static void launch_scan(rover_sim *sim, int grid, hipStream_t st, float *out, int row_stride, int col0, const float *log_partial,
@@ -2086,6 +2109,8 @@ int rover_default_config(rover_config *c)
     c->step_mapping = 0;
     c->max_target_tries = 32;
     c->scan_surface = 0;
+    c->spawn_draw = 1;
+    c->counter_lo = 0u; c->counter_hi = 0u;
     return ROVER_OK;
 }
 
@@ -2096,7 +2121,7 @@ int rover_create(const rover_config *cfg, int32_t num_envs, int32_t env_id_offse
     if (cfg->scan_nx > 64 || cfg->scan_ny > 64) return fail(ROVER_ERR_UNSUPPORTED, "scan grid larger than 64 x 64 rays");
     if (cfg->scan_nx <= 0 || cfg->scan_ny <= 0 || cfg->scan_resolution <= 0.0f || cfg->decimation < 0 ||
         cfg->solver_iterations < 0 || cfg->max_target_tries < 1 || cfg->sim_dt <= 0.0f || cfg->max_episode_length <= 0 ||
-        cfg->scan_surface < 0 || cfg->scan_surface > 1)
+        cfg->scan_surface < 0 || cfg->scan_surface > 1 || cfg->spawn_draw < 0 || cfg->spawn_draw > 1)
         return fail(ROVER_ERR_INVALID, "invalid rover_config");
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count));
@@ -2105,6 +2130,7 @@ int rover_create(const rover_config *cfg, int32_t num_envs, int32_t env_id_offse
     if (!s) return fail(ROVER_ERR_INVALID, "out of host memory");
     memset(s, 0, sizeof(*s));
     s->p.cfg = *cfg;
+    s->counter = ((uint64_t)cfg->counter_hi << 32) | cfg->counter_lo;
     make_step_consts(cfg->sim_dt, s->p.K);
     s->p.n = num_envs;
     s->p.env_id_offset = env_id_offset;
@@ -2236,6 +2262,7 @@ int rover_reset(rover_sim *sim, float *obs, void *stream)
     if (!obs) return fail(ROVER_ERR_INVALID, "obs is NULL");
     DeviceGuard guard(sim->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    next_batch(sim);
     const RvParams &p = sim->p;
     hipLaunchKernelGGL(rover_reset_kernel, dim3((p.n + 63) / 64), dim3(64), 0, st, p, sim->state, nullptr, nullptr, nullptr,
                        nullptr, nullptr);
@@ -2259,6 +2286,20 @@ int rover_reset_with_draws(rover_sim *sim, const uint8_t *mask, const int32_t *s
     return ROVER_OK;
 }
 
+int rover_get_counter(const rover_sim *sim, uint64_t *counter)
+{
+    if (!sim || !counter) return fail(ROVER_ERR_INVALID, "NULL argument");
+    *counter = sim->counter;
+    return ROVER_OK;
+}
+
+int rover_set_counter(rover_sim *sim, uint64_t counter)
+{
+    if (!sim) return fail(ROVER_ERR_INVALID, "sim is NULL");
+    sim->counter = counter;
+    return ROVER_OK;
+}
+
 int rover_set_seed(rover_sim *sim, uint32_t seed_lo, uint32_t seed_hi)
 {
     if (!sim) return fail(ROVER_ERR_INVALID, "sim is NULL");
@@ -2274,6 +2315,7 @@ int rover_step(rover_sim *sim, const float *action, float *obs, float *reward, u
     if (!action || !obs || !reward || !terminated || !truncated || !log) return fail(ROVER_ERR_INVALID, "NULL buffer");
     DeviceGuard guard(sim->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    next_batch(sim);
     const RvParams &p = sim->p;
     if (sim->group_mapping)
         hipLaunchKernelGGL(rover_step_kernel_group, dim3(sim->step_blocks), dim3(RV_K1G_THREADS), 0, st, p, sim->state, action, obs, reward,
@@ -2296,6 +2338,7 @@ int rover_profile_step(rover_sim *sim, const float *action, float *obs, float *r
         return fail(ROVER_ERR_INVALID, "NULL buffer");
     DeviceGuard guard(sim->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    next_batch(sim);
     const RvParams &p = sim->p;
     hipEvent_t ev[3];
     for (int i = 0; i < 3; ++i) HIP_TRY(hipEventCreate(&ev[i]));

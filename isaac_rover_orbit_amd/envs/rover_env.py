@@ -312,6 +312,32 @@ class RoverEnv(RLTaskEnv):
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    @property
+    def call_counter(self) -> int:
+        """Number of reset() / step() launches so far: keys the per-batch spawn permutation (cfg.spawn_draw="distinct")."""
+        c = C.c_uint64(0)
+        _lib.check(self._lib.rover_get_counter(self._h, C.byref(c)), "rover_get_counter")
+        return int(c.value)
+
+    def set_call_counter(self, counter: int):
+        """Restore the call counter (checkpoint resume / replaying a rollout from a given point)."""
+        _lib.check(self._lib.rover_set_counter(self._h, int(counter)), "rover_set_counter")
+        self._sync_counter()
+
+    def _bump_counter(self):
+        # mirror of the handle's call counter in the config struct (one launch = one count): a config derived from
+        # `_native_cfg` at any time (tests: the oracle's) continues in step with the handle
+        cfg = self._native_cfg
+        lo = cfg.counter_lo + 1
+        if lo > 0xFFFFFFFF:
+            lo, cfg.counter_hi = 0, cfg.counter_hi + 1
+        cfg.counter_lo = lo
+
+    def _sync_counter(self):
+        # the struct mirror tracks the handle, so that a config derived from it (tests: the oracle's) continues in step
+        c = self.call_counter
+        self._native_cfg.counter_lo, self._native_cfg.counter_hi = c & 0xFFFFFFFF, (c >> 32) & 0xFFFFFFFF
+
     def seed(self, seed: int = -1) -> int:
         """gymnasium / ORBIT ``env.seed``: re-keys the counter-based RNG of every reset that follows (``rover_set_seed``).
         A negative seed keeps the current key (ORBIT draws a random one there; determinism is preferred here)."""
@@ -329,6 +355,7 @@ class RoverEnv(RLTaskEnv):
             self.seed(seed)
         obs = self._obs[self._cur]
         _lib.check(self._lib.rover_reset(self._h, _ptr(obs), self._stream()), "rover_reset")
+        self._bump_counter()
         self.obs_buf = {"policy": obs}
         return self.obs_buf, self.extras
 
@@ -367,6 +394,7 @@ class RoverEnv(RLTaskEnv):
                                   self._stream())
         if rc != 0:
             _lib.check(rc, "rover_step")
+        self._bump_counter()
         self.common_step_counter += 1
         self.obs_buf = self._obs_dicts[k]
         self.reward_buf = self._rew[k]
@@ -384,6 +412,7 @@ class RoverEnv(RLTaskEnv):
         _lib.check(self._lib.rover_profile_step(self._h, C.c_void_p(action.data_ptr()), self._obs_ptr[k], self._rew_ptr[k],
                                                 self._term_ptr[k], self._trunc_ptr[k], self._force_ptr, self._log_ptr,
                                                 self._stream(), C.byref(a), C.byref(b)), "rover_profile_step")
+        self._bump_counter()
         self.common_step_counter += 1
         self.obs_buf = self._obs_dicts[k]
         self.reward_buf = self._rew[k]
@@ -466,6 +495,7 @@ class RoverEnv(RLTaskEnv):
     # ---- state access (env state is never checkpointed in the reference; here it is just a tensor) -------------
     def get_state(self) -> torch.Tensor:
         """(num_envs, 72) copy of the per-env state words (AoS, same word order as include/rover_hip.h)."""
+        self._sync_counter()
         return self.state.t().contiguous()
 
     def set_state(self, state_aos: torch.Tensor):
@@ -477,7 +507,7 @@ class RoverEnv(RLTaskEnv):
         """Everything needed to continue bit-for-bit: state words, the last observation, the episodic log vector."""
         return {"state": self.get_state().cpu(), "obs": self.obs_buf["policy"].detach().cpu().clone(),
                 "log": self._log.detach().cpu().clone(), "num_envs": self.num_envs,
-                "common_step_counter": int(self.common_step_counter)}
+                "common_step_counter": int(self.common_step_counter), "call_counter": self.call_counter}
 
     def load_state_dict(self, sd: dict):
         """Restore a ``state_dict()`` of an env of the same size and configuration; returns the observation dict."""
@@ -487,6 +517,7 @@ class RoverEnv(RLTaskEnv):
         self._log.copy_(sd["log"].to(self._log.device))
         self._obs[self._cur].copy_(sd["obs"].to(self.device))
         self.common_step_counter = int(sd.get("common_step_counter", 0))
+        _lib.check(self._lib.rover_set_counter(self._h, int(sd.get("call_counter", 0))), "rover_set_counter")
         self.obs_buf = self._obs_dicts[self._cur]
         return self.obs_buf
 

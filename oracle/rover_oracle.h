@@ -78,6 +78,8 @@ typedef struct {
     int32_t solver_iterations;
     int32_t max_target_tries;
     int32_t step_mapping;        /* GPU-side kernel mapping selector; ignored by the oracle */
+    int32_t spawn_draw;          /* 1 = distinct rows per reset batch (affine bijection of the env ids), 0 = independent   */
+    uint32_t counter_lo, counter_hi; /* call counter keying the per-batch spawn permutation (the caller increments it)  */
     int32_t scan_surface;        /* 0 = triangle mesh of the heightfield (cells split along (i,j)-(i+1,j+1)), 1 = bilinear */
 } rvo_config;
 

@@ -38,7 +38,8 @@ class Config(C.Structure):
         ("scan_height_offset", C.c_float), ("scan_nx", C.c_int32), ("scan_ny", C.c_int32),
         ("reset_z_offset", C.c_float), ("reset_mode", C.c_int32), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
         ("friction_mu", C.c_float), ("solver_iterations", C.c_int32), ("max_target_tries", C.c_int32),
-        ("step_mapping", C.c_int32), ("scan_surface", C.c_int32),
+        ("step_mapping", C.c_int32), ("spawn_draw", C.c_int32), ("counter_lo", C.c_uint32), ("counter_hi", C.c_uint32),
+        ("scan_surface", C.c_int32),
     ]
 
 
@@ -202,10 +203,18 @@ def new_state(n: int) -> np.ndarray:
     return s
 
 
+def _bump_counter(cfg: Config):
+    """The call counter (number of reset / step calls so far) lives in the config struct on the oracle side: the C functions
+    read it, this binding advances it after every reset_all / step, like the HIP library does inside its handle."""
+    c = ((cfg.counter_hi << 32) | cfg.counter_lo) + 1
+    cfg.counter_lo, cfg.counter_hi = c & 0xFFFFFFFF, (c >> 32) & 0xFFFFFFFF
+
+
 def reset_all(cfg: Config, t: TerrainData, state, env_id_offset=0):
     n = state.shape[0]
     obs = np.zeros((n, 4 + cfg.scan_nx * cfg.scan_ny), np.float32)
     lib().rvo_reset_all(C.byref(cfg), C.byref(t.c), n, env_id_offset, _p(state), _p(obs))
+    _bump_counter(cfg)
     return obs
 
 
@@ -235,6 +244,7 @@ def step(cfg: Config, t: TerrainData, state, action, env_id_offset=0, log=None):
         log = np.zeros(LOG_WORDS, np.float32)
     lib().rvo_step(C.byref(cfg), C.byref(t.c), n, env_id_offset, _p(state), _p(action), _p(obs), _p(reward),
                    _p(terminated), _p(truncated), _p(force), _p(log))
+    _bump_counter(cfg)
     return obs, reward, terminated, truncated, force, log
 
 

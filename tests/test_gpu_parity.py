@@ -30,8 +30,12 @@ def make_env(n, ter, **over):
     return RoverEnv(cfg, terrain=ter)
 
 
-def oracle_side(ro, env):
+def oracle_side(ro, env, counter=None):
+    """Oracle config + terrain of an env.  The config carries the env's current call counter (it keys the per-batch spawn
+    rows); ``counter`` overrides it, e.g. 0 to replay the env's history from its first reset."""
     ocfg = oracle_config_from(ro, env._native_cfg)
+    if counter is not None:
+        ocfg.counter_lo, ocfg.counter_hi = counter & 0xFFFFFFFF, counter >> 32
     oter = oracle_terrain(ro, env.terrain_data)
     return ocfg, oter
 
@@ -191,8 +195,8 @@ def test_height_scan_misses_are_minus_inf(oracle):
 def test_reset_matches_oracle(oracle):
     ter = small_procedural()
     env = make_env(512, ter, seed=1234567890123)
-    obs, info = env.reset()
     ocfg, oter = oracle_side(oracle, env)
+    obs, info = env.reset()
     So = oracle.new_state(512)
     obs_o = oracle.reset_all(ocfg, oter, So)
     S = state_np(env)
@@ -236,9 +240,9 @@ def test_physics_substeps_match_oracle(oracle, mapping):
 
 # ------------------------------------------------------------------------------------------------ full step
 def rollout_compare(oracle, env, steps, actions, tol_step, tol_final, resync):
-    ocfg, oter = oracle_side(oracle, env)
     n = env.num_envs
     env.reset()
+    ocfg, oter = oracle_side(oracle, env)
     So = state_np(env)
     flips = 0
     log_o = np.zeros(16, np.float32)
@@ -267,7 +271,7 @@ def rollout_compare(oracle, env, steps, actions, tol_step, tol_final, resync):
 
 def oracle_state_after(oracle, env, actions):
     """Replay the same rollout on the oracle alone (from its own reset) and return its final state."""
-    ocfg, oter = oracle_side(oracle, env)
+    ocfg, oter = oracle_side(oracle, env, counter=env.call_counter - len(actions) - 1)
     So = oracle.new_state(env.num_envs)
     oracle.reset_all(ocfg, oter, So, env_id_offset=env.cfg.env_id_offset)
     for a in actions:
@@ -540,6 +544,7 @@ def test_random_configurations_match_oracle(oracle, seed):
     cfg.rewards["reached_target"].params["threshold"] = thr
     cfg.use_int16_terrain = bool(rng.randint(0, 2))
     cfg.height_scanner.surface = str(rng.choice(["triangles", "bilinear"]))
+    cfg.spawn_draw = str(rng.choice(["distinct", "independent"]))
     env = RoverEnv(cfg, terrain=ter)
     assert env.num_rays == nx * ny, (env.num_rays, nx, ny, res)
     actions = rng.uniform(-1, 1, (12, n, 2)).astype(np.float32)

@@ -67,6 +67,44 @@ def test_point_turn_spins_in_place(oracle):
     assert np.allclose(S[0, ro.STEER_Q:ro.STEER_Q + 4], steer[0], atol=2e-2)
 
 
+@pytest.mark.parametrize("R", [1.5, 3.0, -2.0])
+def test_steady_state_turn_radius(oracle, R):
+    """on flat ground a kinematically consistent Ackermann command (every wheel tangent to its circle
+    about a common centre on the centre-axle line, rim speeds proportional to the circle radii) is followed without slip:
+    the measured radius v / yaw_rate equals the commanded one.  (AckermannAction2 itself does NOT command this -- it gives all
+    four steer joints the SAME angle, quirk B-5; that kinematics is pinned by the fixture, not by this plausibility test.)"""
+    ro = oracle
+    cfg, t = ro.default_config(), oracle_terrain(ro, flat(), 2)
+    S = settle(ro, cfg, t, fresh(ro))
+    mc = ro.model_constants()
+    wheels = mc[7:25].reshape(6, 3)                 # FL, FR, CL, CR, RL, RR in the body frame (x forward, y left)
+    r_contact = float(mc[46])              # wheel contact radius 0.10179
+    xc = float(wheels[2, 0])                        # centre axle
+    v_cmd = 0.35
+    yaw_rate = v_cmd / R
+    steer = np.zeros((1, 4), np.float32)
+    wheel = np.zeros((1, 6), np.float32)
+    for k, si in ((0, 0), (1, 1), (4, 2), (5, 3)):  # steerable wheels -> steer joints FL, FR, RL, RR
+        steer[0, si] = np.arctan2(wheels[k, 0] - xc, R - wheels[k, 1]) if R > 0 else np.arctan2(-(wheels[k, 0] - xc), -(R - wheels[k, 1]))
+    for k in range(6):
+        rho = np.hypot(wheels[k, 0] - xc, R - wheels[k, 1])
+        wheel[0, k] = abs(yaw_rate) * rho / r_contact
+    ro.physics_step(cfg, t, S, steer, wheel, 150)                 # reach the steady state
+    p0, q0 = S[0, 0:2].copy(), S[0, ro.QUAT:ro.QUAT + 4].copy()
+    n = 120
+    ro.physics_step(cfg, t, S, steer, wheel, n)
+    yaw = lambda q: 2.0 * np.arctan2(q[3], q[0])                  # noqa: E731  (flat ground: pure yaw)
+    dyaw = (yaw(S[0, ro.QUAT:ro.QUAT + 4]) - yaw(q0) + np.pi) % (2 * np.pi) - np.pi
+    speed = np.linalg.norm(S[0, ro.LINVEL:ro.LINVEL + 2])
+    rate = dyaw / (n * H)
+    assert np.sign(rate) == np.sign(R)
+    assert abs(speed / abs(rate) - abs(R)) < 0.08 * abs(R), (speed, rate, R)       # radius within 8 %
+    assert abs(speed - v_cmd) < 0.05 * v_cmd + 0.01                                # body-origin speed = commanded
+    chord = np.linalg.norm(S[0, 0:2] - p0)
+    assert abs(chord - 2 * abs(R) * abs(np.sin(dyaw / 2))) < 0.05 * chord + 0.01   # the path is that circle's chord
+    assert abs(S[0, ro.POS + 2] - 0.26878) < 2e-3                                  # stays on the ground
+
+
 def test_steering_joint_is_first_order_lag(oracle):
     """kp 8000 / kd 1000 => time constant ~ kd / kp = 0.125 s, rate limit 6 rad/s (aau_rover_simple.py:43-49)."""
     ro = oracle
@@ -168,11 +206,12 @@ def test_collision_only_from_obstacle_layer(oracle):
 def test_oracle_is_deterministic_and_shard_invariant(oracle):
     ro = oracle
     ter = small_procedural()
-    cfg, t = ro.default_config(seed_lo=77), oracle_terrain(ro, ter, 256)
+    t = oracle_terrain(ro, ter, 256)
     rng = np.random.RandomState(4)
     acts = rng.uniform(-1, 1, (10, 128, 2)).astype(np.float32)
 
     def run(lo, hi):
+        cfg = ro.default_config(seed_lo=77)          # a fresh config = call counter 0 (it keys the per-batch spawn rows)
         S = ro.new_state(hi - lo)
         ro.reset_all(cfg, t, S, env_id_offset=lo)
         outs = []
@@ -210,3 +249,33 @@ def test_step_ordering_quirks(oracle):
     assert log[13] == 2 and log[7] == 1 and log[8] == 1                      # one time_limit, one is_success
     # fresh command for the observation: distance obs ~ 9 m * 0.11 after the reset
     assert abs(obs[0, 2] - 0.99) < 2e-3
+
+
+def test_spawn_rows_are_distinct_inside_a_reset_batch(oracle):
+    """randomizations.py:22 takes a randperm PREFIX: envs that reset together never share a spawn table row.  spawn_draw = 1
+    (default) reproduces that with an affine bijection of the global env ids, redrawn per call from (seed, call counter);
+    spawn_draw = 0 draws one row per env independently (rows repeat)."""
+    ro = oracle
+    n = 300
+    table = np.stack([np.arange(2 * n, dtype=np.float32) + 20.0, np.full(2 * n, 25.0, np.float32), np.zeros(2 * n, np.float32)], 1)
+    ter = flat()
+    t = ro.TerrainData(ter.height, ter.obstacle, ter.safe_rock_mask, ter.resolution, ter.min_x, ter.min_y, table)
+    seen = []
+    for draw, expect_distinct in ((1, True), (0, False)):
+        cfg = ro.default_config(spawn_draw=draw, seed_lo=3)
+        S = ro.new_state(n)
+        ro.reset_all(cfg, t, S)
+        rows = (S[:, 0] - 20.0).astype(int)
+        assert (len(set(rows.tolist())) == n) == expect_distinct
+        assert rows.min() >= 0 and rows.max() < 2 * n
+        S2 = ro.new_state(n)
+        ro.reset_all(cfg, t, S2)                       # next call: a different permutation (independent draws are keyed
+        assert np.array_equal(S2[:, 0], S[:, 0]) != expect_distinct    # by the env's own reset count instead)
+        seen.append(rows)
+    # shards of one batch draw from the same bijection: no collision across GPUs either
+    cfg = ro.default_config(seed_lo=3)
+    lo, hi = ro.new_state(100), ro.new_state(200)
+    ro.reset_all(cfg, t, lo, env_id_offset=0)
+    cfg.counter_lo = 0
+    ro.reset_all(cfg, t, hi, env_id_offset=100)
+    assert np.array_equal(np.concatenate([lo[:, 0], hi[:, 0]]) - 20.0, seen[0].astype(np.float32))
