@@ -34,6 +34,56 @@ def algorithmic_bytes(rays: int):
     return scan, dyn
 
 
+def bench_lift(args):
+    """BASELINE config 5: FrankaCubeLift-v0, num_envs = 2048, 1 x MI355X; env-steps/s through FrankaCubeLiftEnv.step()."""
+    import numpy as np
+    import torch
+    from isaac_rover_orbit_amd.envs import FrankaCubeLiftEnv, LiftEnvCfg
+    n = args.num_envs if args.num_envs != 4096 else 2048
+    torch.cuda.set_device(0)
+    cfg = LiftEnvCfg()
+    cfg.scene.num_envs = n
+    env = FrankaCubeLiftEnv(cfg)
+    total = args.steps + args.warmup
+    g = torch.Generator(device=env.device).manual_seed(0)
+    acts = torch.rand(min(total, 512), n, 8, device=env.device, generator=g) * 2 - 1
+    env.reset()
+    for k in range(args.warmup):
+        env.step(acts[k % acts.shape[0]])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.warmup, total):
+        env.step(acts[k % acts.shape[0]])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"metric": "env-steps/sec FrankaCubeLift-v0 (BASELINE config 5)", "value": n * args.steps / dt, "unit": "env-steps/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"FrankaCubeLift-v0 num_envs={n}, random U(-1,1) actions, 100 Hz x decimation 2, in-step resets "
+                                  "(BASELINE config 5)", "baseline_config": 5, "num_envs_per_gpu": n}}
+    if not args.no_cpu_baseline:
+        try:
+            from oracle import lift_oracle as lo
+            lo.build()
+            oc = lo.default_config()
+            S = lo.new_state(n)
+            lo.reset(oc, S)
+            a = np.random.RandomState(0).uniform(-1, 1, (16, n, 8)).astype(np.float32)
+            lo.step(oc, S, a[0])
+            t0 = time.perf_counter()
+            m = 0
+            while m < 2000 and (m < 4 or time.perf_counter() - t0 < args.cpu_seconds):
+                lo.step(oc, S, a[m % 16])
+                m += 1
+            d = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": n * m / d, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": f"{m} steps of the same N={n} workload on the CPU build of the model (OpenMP), {d:.1f} s"}
+        except Exception as e:
+            out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
+    env.close()
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -44,10 +94,13 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-forces", action="store_true", help="do not materialise contact_sensor.force_matrix_w")
-    ap.add_argument("--config", type=int, default=2, choices=(2, 4),
+    ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5),
                     help="BASELINE.json config: 2 = headline (31x31 rays @0.1 m, sigma_z 0.15 m); "
-                         "4 = dense scanner stress (32x32 rays @0.05 m, sigma_z 0.4 m)")
+                         "4 = dense scanner stress (32x32 rays @0.05 m, sigma_z 0.4 m); "
+                         "5 = manipulation task FrankaCubeLift-v0 (default num_envs 2048)")
     args = ap.parse_args()
+    if args.config == 5:
+        return bench_lift(args)
 
     import numpy as np
     import torch

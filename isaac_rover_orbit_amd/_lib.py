@@ -26,6 +26,8 @@ EXPORTS = [
     "rover_terrain_rasterize", "rover_terrain_surface", "rover_terrain_rock_mask", "rover_terrain_scratch_bytes",   # rover_terrain.h
     "rover_set_terrain_lookup",
     "rover_policy_default_desc", "rover_policy_packed_floats", "rover_policy_pack", "rover_policy_forward",  # rover_policy.h
+    "rover_lift_default_config", "rover_lift_config_bytes", "rover_lift_state_words", "rover_lift_create", "rover_lift_destroy",
+    "rover_lift_workspace_bytes", "rover_lift_bind", "rover_lift_reset", "rover_lift_step", "rover_lift_terms",   # rover_lift.h
 ]
 POLICY_MAX_LAYERS = 8
 ACT_NONE, ACT_LEAKY_RELU, ACT_TANH = 0, 1, 2
@@ -47,6 +49,26 @@ class PolicyDesc(C.Structure):
 
 class RoverHipError(RuntimeError):
     pass
+
+
+LIFT_NUM_REW, LIFT_OBS, LIFT_ACT, LIFT_STATE_WORDS, LIFT_LOG_WORDS = 6, 36, 8, 64, 16
+# lift state word offsets (csrc/lift_model.h)
+LIFT_Q, LIFT_QD, LIFT_OBJ_POS, LIFT_OBJ_QUAT, LIFT_OBJ_LIN, LIFT_OBJ_ANG, LIFT_CMD = 0, 9, 18, 21, 25, 28, 31
+LIFT_TIME_LEFT, LIFT_EP_LEN, LIFT_ACTION, LIFT_PREV_ACTION, LIFT_EP_SUM, LIFT_RESET_COUNT = 38, 39, 40, 48, 56, 62
+
+
+class LiftConfig(C.Structure):
+    """Mirror of ``struct lift_config`` (csrc/lift_model.h)."""
+    _fields_ = [
+        ("sim_dt", C.c_float), ("decimation", C.c_int32), ("max_episode_length", C.c_int32), ("max_episode_length_s", C.c_float),
+        ("action_scale", C.c_float), ("finger_open", C.c_float), ("finger_close", C.c_float),
+        ("rew_weight", C.c_float * LIFT_NUM_REW),
+        ("reach_std", C.c_float), ("goal_std", C.c_float), ("goal_fine_std", C.c_float), ("minimal_height", C.c_float),
+        ("drop_height", C.c_float), ("cmd_lo", C.c_float * 3), ("cmd_hi", C.c_float * 3), ("cmd_resample_time", C.c_float),
+        ("obj_init", C.c_float * 3), ("obj_range_lo", C.c_float * 3), ("obj_range_hi", C.c_float * 3), ("ee_offset_z", C.c_float),
+        ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32), ("solver_iterations", C.c_int32), ("mu_table", C.c_float),
+        ("mu_pad", C.c_float),
+    ]
 
 
 class RoverConfig(C.Structure):
@@ -134,6 +156,16 @@ def load():
     lib.rover_policy_packed_floats.restype = C.c_size_t
     lib.rover_policy_pack.argtypes = [C.POINTER(PolicyDesc), C.POINTER(vp), C.POINTER(vp), vp]
     lib.rover_policy_forward.argtypes = [C.POINTER(PolicyDesc), vp, i32, vp, i32, vp, vp]
+    lib.rover_lift_default_config.argtypes = [C.POINTER(LiftConfig)]
+    lib.rover_lift_config_bytes.restype = C.c_size_t
+    lib.rover_lift_create.argtypes = [C.POINTER(LiftConfig), i32, i32, i32, C.POINTER(vp)]
+    lib.rover_lift_destroy.argtypes = [vp]
+    lib.rover_lift_workspace_bytes.argtypes = [vp]
+    lib.rover_lift_workspace_bytes.restype = C.c_size_t
+    lib.rover_lift_bind.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.rover_lift_reset.argtypes = [vp, vp, vp]
+    lib.rover_lift_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.rover_lift_terms.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.rover_last_error.restype = C.c_char_p
     lib.rover_version.restype = C.c_char_p
     for name in EXPORTS:
@@ -143,6 +175,8 @@ def load():
     lib.rover_config_bytes.restype = C.c_size_t
     if lib.rover_config_bytes() != C.sizeof(RoverConfig):
         raise RoverHipError("struct rover_config of librover_hip.so does not match the Python mirror")
+    if lib.rover_lift_config_bytes() != C.sizeof(LiftConfig) or lib.rover_lift_state_words() != LIFT_STATE_WORDS:
+        raise RoverHipError("struct lift_config / lift state layout of librover_hip.so does not match the Python mirror")
     if lib.rover_state_words() != STATE_WORDS:
         raise RoverHipError("librover_hip.so state layout does not match the Python binding")
     _lib = lib

@@ -149,3 +149,7 @@ def register_default_tasks():
     gym = gym_api()
     gym.register(id="AAURoverEnv-v0", entry_point="isaac_rover_orbit_amd.envs:RoverEnv", disable_env_checker=True,
                  kwargs={"env_cfg_entry_point": AAURoverEnvCfg})
+    from ..envs.lift_env import LiftEnvCfg
+    # manipulation/config/franka/__init__.py:6-14 (entry point there: ORBIT's generic RLTaskEnv on FrankaCubeLiftEnvCfg)
+    gym.register(id="FrankaCubeLift-v0", entry_point="isaac_rover_orbit_amd.envs:FrankaCubeLiftEnv", disable_env_checker=True,
+                 kwargs={"env_cfg_entry_point": LiftEnvCfg})

@@ -1,0 +1,129 @@
+"""FrankaCubeLift-v0 on the MI355X (BASELINE config 5): the HIP path through the C ABI (include/rover_lift.h)
+against the reference fixture for the term arithmetic the reference owns, and against the CPU build of the model bit for bit
+(state, observations, rewards, flags) over closed-loop rollouts with resets.  extras["log"] means: rtol 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lo():
+    from oracle import lift_oracle
+    lift_oracle.build()
+    lift_oracle.lib()
+    return lift_oracle
+
+
+def make_env(n, **over):
+    from isaac_rover_orbit_amd.envs import FrankaCubeLiftEnv, LiftEnvCfg
+    cfg = LiftEnvCfg()
+    cfg.scene.num_envs = n
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return FrankaCubeLiftEnv(cfg)
+
+
+def oracle_cfg(lo, env):
+    c = lo.Config()
+    for name, _ in lo.Config._fields_:
+        v = getattr(env._native_cfg, name)
+        if hasattr(v, "__len__"):
+            for i in range(len(v)):
+                getattr(c, name)[i] = v[i]
+        else:
+            setattr(c, name, v)
+    return c
+
+
+def test_lift_terms_match_reference_fixture(lo, golden_dir):
+    g = np.load(f"{golden_dir}/lift_terms.npz")
+    env = make_env(64)
+    lifted, reach, goal, fine, pos_b = [t.cpu().numpy() for t in env.terms(g["object_pos_w"], g["ee_pos_w"], g["robot_root_state_w"],
+                                                                            g["command"])]
+    assert_close(lifted, g["rew_object_is_lifted"], 0, 0, "object_is_lifted")
+    assert_close(reach, g["rew_object_ee_distance"], 3e-7, 2e-6, "object_ee_distance")
+    assert_close(goal, g["rew_object_goal_distance_03"], 3e-7, 2e-6, "object_goal_distance 0.3")
+    assert_close(fine, g["rew_object_goal_distance_005"], 3e-7, 2e-6, "object_goal_distance 0.05")
+    assert_close(pos_b, g["obs_object_position_in_robot_root_frame"], 3e-7, 2e-6, "object_position_in_robot_root_frame")
+    # and bit-exact against the oracle's independent restatement
+    o = lo.terms(g["object_pos_w"], g["ee_pos_w"], g["robot_root_state_w"], g["command"])
+    for a, b, nm in zip((lifted, reach, goal, fine, pos_b), o, ("lifted", "reach", "goal", "fine", "pos_b")):
+        assert_close(a, b, 0, 0, nm + " vs oracle")
+    env.close()
+
+
+@pytest.mark.parametrize("n,seed", [(64, 0), (333, 5)])
+def test_lift_rollout_matches_oracle(lo, n, seed):
+    """300 closed-loop steps (every env times out once: in-step resets, command resampling), random actions incl. gripper."""
+    env = make_env(n, seed=seed)
+    ocfg = oracle_cfg(lo, env)
+    obs, info = env.reset()
+    So = lo.new_state(n)
+    obs_o = lo.reset(ocfg, So)
+    assert_close(obs["policy"].cpu().numpy(), obs_o, 0, 0, "obs after reset")
+    assert np.array_equal(env.get_state().cpu().numpy().view(np.int32), So.view(np.int32))
+    rng = np.random.RandomState(seed)
+    log_o = np.zeros(16, np.float32)
+    for k in range(300):
+        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+        if k % 50 < 25:
+            a[:, 7] = -1.0
+        obs, rew, term, trunc, info = env.step(torch.from_numpy(a).to(env.device))
+        obs_o, rew_o, term_o, trunc_o, log_o = lo.step(ocfg, So, a, log=log_o)
+        assert np.array_equal(term.cpu().numpy(), term_o.astype(bool)) and np.array_equal(trunc.cpu().numpy(), trunc_o.astype(bool)), k
+        assert_close(obs["policy"].cpu().numpy(), obs_o, 0, 0, f"obs step {k}")
+        assert_close(rew.cpu().numpy(), rew_o, 0, 0, f"reward step {k}")
+        log = env._log.cpu().numpy()
+        assert log[8] == log_o[8]
+        assert_close(log[:8], log_o[:8], 1e-7, 1e-5, f"log step {k}")
+    assert np.array_equal(env.get_state().cpu().numpy().view(np.int32), So.view(np.int32)), "final state bit exact"
+    assert trunc_o.sum() == 0 and So[:, lo.EP_LEN].view(np.int32).max() < 60
+    env.close()
+
+
+def test_lift_boundary_surface():
+    """What skrl / gym consumers touch (SURVEY 8b pattern): spaces, managers, extras, registration."""
+    import isaac_rover_orbit_amd.compat as compat
+    from isaac_rover_orbit_amd.envs import FrankaCubeLiftEnv, RLTaskEnv
+    compat.register_default_tasks()
+    gym = compat.gym_api()
+    from isaac_rover_orbit_amd.envs import LiftEnvCfg
+    cfg = LiftEnvCfg()
+    cfg.scene.num_envs = 128
+    env = gym.make("FrankaCubeLift-v0", cfg=cfg)
+    assert isinstance(env.unwrapped, RLTaskEnv) and isinstance(env, FrankaCubeLiftEnv)
+    assert env.observation_manager.group_obs_dim["policy"] == (36,) and env.action_manager.total_action_dim == 8
+    assert env.action_space.shape == (128, 8) and env.single_observation_space["policy"].shape == (36,)
+    obs, info = env.reset()
+    assert obs["policy"].shape == (128, 36) and int(env.max_episode_length) == 250
+    o, r, t, u, info = env.step(torch.zeros(128, 8, device=env.device))
+    assert r.shape == (128,) and t.dtype == torch.bool and u.dtype == torch.bool
+    assert set(info["episode"]) == {f"Episode Reward/{k}" for k in ("reaching_object", "lifting_object", "object_goal_tracking",
+                                    "object_goal_tracking_fine_grained", "action_rate", "joint_vel")} | \
+        {"Episode Termination/time_out", "Episode Termination/object_dropping"}
+    assert env.command_manager.get_command("object_pose").shape == (128, 7)
+    with pytest.raises(ValueError):
+        env.step(torch.zeros(128, 7, device=env.device))
+    env.close()
+
+
+def test_lift_full_size_properties():
+    """BASELINE config 5 size (2048 envs): finite everywhere over 260 random steps, timers and resets consistent."""
+    n = 2048
+    env = make_env(n, seed=3)
+    env.reset()
+    g = torch.Generator(device=env.device).manual_seed(0)
+    resets = 0
+    for k in range(260):
+        a = torch.rand(n, 8, device=env.device, generator=g) * 2 - 1
+        obs, rew, term, trunc, info = env.step(a)
+        resets += int(term.sum()) + int(trunc.sum())
+    S = env.get_state()
+    assert torch.isfinite(S[:, :62]).all() and torch.isfinite(obs["policy"]).all() and torch.isfinite(rew).all()
+    assert resets >= n and int(env.episode_length_buf.max()) <= 12
+    assert (S[:, 18 + 2] > -0.06).all()                       # nothing below the drop height survives a step
+    env.close()

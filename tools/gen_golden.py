@@ -21,6 +21,12 @@ Outputs (small .npz files, data only -- inputs and the reference's outputs):
                           (spawn index, yaw uniform, the theta uniforms incl. rejected ones, heading uniform) so that
                           the outcome can be replayed by injecting the draws (torch's RNG stream itself cannot be)
 
+* ``lift_terms.npz``  -- FrankaCubeLift-v0: the reference's own reward / observation terms
+                          (manipulation/mdp/rewards.py:20-67, observations.py:19-31) on 192 rows incl. every threshold; the
+                          two ORBIT frame-transform helpers they call (``utils.math.combine_frame_transforms`` /
+                          ``subtract_frame_transforms``, third-party, absent) are supplied as a restatement of their
+                          documented quaternion algebra -- that part is restated, not pinned
+
 Functions that live in third-party code absent from the container (ORBIT math utils, PhysX, Warp
 ray-caster, cv2 morphology) cannot be evaluated and are NOT covered here; see DESIGN.md "parity".
 """
@@ -379,7 +385,81 @@ def gen_reset():
     np.savez_compressed(os.path.join(OUT, "reset.npz"), **out)
 
 
+# --------------------------------------------------------------------------------------- manipulation (lift) terms
+def _quat_apply(q, v):
+    """ORBIT utils.math.quat_apply (w, x, y, z): v + 2 w (q_v x v) + 2 q_v x (q_v x v)."""
+    w, xyz = q[:, 0:1], q[:, 1:4]
+    t = torch.cross(xyz, v, dim=-1) * 2
+    return v + w * t + torch.cross(xyz, t, dim=-1)
+
+
+def _combine_frame_transforms(t01, q01, t12=None, q12=None):
+    t02 = t01 + _quat_apply(q01, t12) if t12 is not None else t01
+    return t02, q01            # q12 is never passed by the reference's terms (identity)
+
+
+def _subtract_frame_transforms(t01, q01, t02=None, q02=None):
+    q10 = torch.cat([q01[:, 0:1], -q01[:, 1:4]], dim=-1)
+    t12 = _quat_apply(q10, t02 - t01) if t02 is not None else _quat_apply(q10, -t01)
+    return t12, q10
+
+
+def gen_lift_terms():
+    class SceneEntityCfg:       # default arguments of the reference's term functions are built at import time
+        def __init__(self, name, **kw):
+            self.name = name
+    sys.modules["omni.isaac.orbit.managers"].SceneEntityCfg = SceneEntityCfg
+    m = sys.modules["omni.isaac.orbit.utils.math"]
+    m.combine_frame_transforms, m.subtract_frame_transforms = _combine_frame_transforms, _subtract_frame_transforms
+    # the package __init__ builds the whole ORBIT cfg tree (needs real configclasses); the term functions live in two
+    # self-contained modules, loaded here by path
+    import importlib.util
+    lift_mdp = types.SimpleNamespace()
+    for fn in ("rewards", "observations"):
+        spec = importlib.util.spec_from_file_location(
+            f"_ref_lift_{fn}", os.path.join(reference_stubs.REFERENCE_ROOT, "rover_envs", "envs", "manipulation", "mdp", fn + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        for k, v in vars(mod).items():
+            if callable(v) and getattr(v, "__module__", "") == mod.__name__:
+                setattr(lift_mdp, k, v)
+
+    g = torch.Generator().manual_seed(2024)
+    n = 192
+    obj = torch.rand(n, 3, generator=g) * torch.tensor([0.6, 0.8, 0.5]) + torch.tensor([0.2, -0.4, -0.1])
+    obj[:8, 2] = torch.tensor([0.06, 0.0600001, 0.0599999, 0.055, -0.05, -0.0500001, 0.2, 0.02])    # around every threshold
+    ee = obj + (torch.rand(n, 3, generator=g) - 0.5) * torch.tensor([0.6, 0.6, 0.6])
+    ee[8:12] = obj[8:12]                                                                            # distance 0
+    root = torch.zeros(n, 13)
+    root[:, 0:3] = (torch.rand(n, 3, generator=g) - 0.5) * 0.2
+    ang = torch.rand(n, generator=g) * 6.2831853
+    axis = torch.nn.functional.normalize(torch.rand(n, 3, generator=g) - 0.5, dim=-1)
+    root[:, 3] = torch.cos(ang / 2)
+    root[:, 4:7] = axis * torch.sin(ang / 2).unsqueeze(-1)
+    root[:64, 0:3] = 0.0
+    root[:64, 3:7] = torch.tensor([1.0, 0.0, 0.0, 0.0])          # the task's robot root: origin, identity
+    cmd = torch.zeros(n, 7)
+    cmd[:, 0:3] = torch.rand(n, 3, generator=g) * torch.tensor([0.4, 0.4, 0.5]) + torch.tensor([0.3, 0.3, 0.0])
+    cmd[:, 3] = 1.0
+    env = types.SimpleNamespace(
+        scene={"object": types.SimpleNamespace(data=types.SimpleNamespace(root_pos_w=obj)),
+               "ee_frame": types.SimpleNamespace(data=types.SimpleNamespace(target_pos_w=ee.unsqueeze(1))),
+               "robot": types.SimpleNamespace(data=types.SimpleNamespace(root_state_w=root))},
+        command_manager=types.SimpleNamespace(get_command=lambda name: cmd))
+    out = {
+        "object_pos_w": obj.numpy(), "ee_pos_w": ee.numpy(), "robot_root_state_w": root.numpy(), "command": cmd.numpy(),
+        "rew_object_is_lifted": lift_mdp.object_is_lifted(env, minimal_height=0.06).numpy(),
+        "rew_object_ee_distance": lift_mdp.object_ee_distance(env, std=0.1).numpy(),
+        "rew_object_goal_distance_03": lift_mdp.object_goal_distance(env, std=0.3, minimal_height=0.06, command_name="object_pose").numpy(),
+        "rew_object_goal_distance_005": lift_mdp.object_goal_distance(env, std=0.05, minimal_height=0.06, command_name="object_pose").numpy(),
+        "obs_object_position_in_robot_root_frame": lift_mdp.object_position_in_robot_root_frame(env).numpy(),
+    }
+    np.savez_compressed(os.path.join(OUT, "lift_terms.npz"), **out)
+    print("lift_terms:", {k: tuple(v.shape) for k, v in out.items()})
+
+
 if __name__ == "__main__":
+    gen_lift_terms()
     gen_reset()
     gen_ackermann()
     gen_mdp_terms()
