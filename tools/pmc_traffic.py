@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Dev tool: profiles/hbm_traffic.json from three rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum
 TCC_MISS_sum) of tools/pmc_run.py.  Usage: pmc_traffic.py <dir_fetch> <dir_write> <dir_tcc> <out.json> [note]"""
-import csv, glob, json, sys, collections
+import csv, glob, json, re, sys, collections
 
 
 def per_kernel(d):
@@ -10,7 +10,7 @@ def per_kernel(d):
         rows = list(csv.DictReader(open(f)))
         for r in rows:
             name = r["Kernel_Name"]
-            key = "rover_scan_obs_kernel" if "rover_scan_obs_kernel<2" in name or "rover_scan_obs_kernelILi2" in name else \
+            key = "rover_scan_obs_kernel" if re.search(r"rover_scan_obs_kernel(<2|ILi2)", name) else \
                   "rover_step_kernel" if "rover_step_kernel" in name else None
             if key:
                 acc[key][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
@@ -24,13 +24,16 @@ def per_kernel(d):
     return out
 
 
+for d in sys.argv[1:4]:
+    if not glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        sys.exit(f"{d}: no *counter_collection.csv (run rocprofv3 with --output-format csv)")
 fetch, write, tcc = per_kernel(sys.argv[1]), per_kernel(sys.argv[2]), per_kernel(sys.argv[3])
 res = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum (three separate passes) -- "
                "python3 tools/pmc_run.py 4096 20; per-launch means over launches 3..20, N=4096, 1x MI355X. FETCH_SIZE/WRITE_SIZE "
                "are KiB at the L2's memory side (Infinity-Cache hits included). MI355X_MICROARCH.md: on gfx950 FETCH_SIZE "
                "reports 1/2 of the bytes of a wide coalesced (16 B/lane) read stream -> doubled for rover_scan_obs_kernel (its "
                "tile staging is 16 B/lane global_load_lds); the step kernel's 4-byte gathers are an uncalibrated width -> raw value.",
-       "round": 1, "_kernels": sys.argv[5] if len(sys.argv) > 5 else ""}
+       "round": 2, "_build": sys.argv[5] if len(sys.argv) > 5 else ""}
 for k, corr in (("rover_scan_obs_kernel", 2.0), ("rover_step_kernel", 1.0)):
     f, w = fetch[k]["FETCH_SIZE"], write[k]["WRITE_SIZE"]
     h, m = tcc[k].get("TCC_HIT_sum", 0.0), tcc[k].get("TCC_MISS_sum", 0.0)
