@@ -1687,6 +1687,56 @@ __global__ __launch_bounds__(64) void rover_reset_kernel(RvParams p, float *__re
 //   MODE 1  pose from the state tensor + observation head                                   (rover_reset)
 //   MODE 2  pose + terrain window from the 32-byte descriptor the step kernel left (one scalar load), the head was
 //           written by the step kernel; the LAST workgroup reduces the log partials          (rover_step)
+// surface height from four staged cells (unscaled): the plane of the cell's triangle the ray falls in (cells split along
+// the (i, j) - (i+1, j+1) diagonal: what a ray-cast of the terrain's triangle mesh returns) or the bilinear patch
+template <bool TRI, typename cell_t>
+__device__ __forceinline__ float patch_height(const cell_t *q, int pitch, float fx, float fy)
+{
+    const float h00 = (float)q[0], h01 = (float)q[1], h10 = (float)q[pitch], h11 = (float)q[pitch + 1];
+    if (TRI) {
+        const bool lower = fx >= fy;                       // lower triangle: corners 00, 01, 11; upper: 00, 10, 11
+        const float pm = lower ? h01 : h10;
+        const float d1 = pm - h00, d2 = h11 - pm;
+        const float a = lower ? d1 : d2, b = lower ? d2 : d1;
+        return fmaf(fy, b, fmaf(fx, a, h00));
+    }
+    const float dx0 = h01 - h00, dx1 = h11 - h10;
+    const float hx0 = h00 + fx * dx0;
+    const float hx1 = h10 + fx * dx1;
+    return hx0 + fy * (hx1 - hx0);
+}
+// deterministic reduction of the per-wave log partials by ONE workgroup: GROUPS x 16 words, then a fixed-order sum
+template <int THREADS>
+__device__ __forceinline__ void reduce_log_partials(const rover_config &c, float *lds, int tid, const float *__restrict__ log_partial,
+                                                    int n_waves, float *__restrict__ log_out)
+{
+    constexpr int GROUPS = THREADS / 16;
+    const int word = tid & 15, grp = tid >> 4;
+    float acc = 0.0f;
+    for (int w = grp; w < n_waves; w += GROUPS) acc += log_partial[(size_t)w * ROVER_LOG_WORDS + word];
+    lds[grp * 16 + word] = acc;
+    __syncthreads();
+    if (tid < 16) {
+        float s = 0.0f;
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) s += lds[g * 16 + tid];
+        lds[THREADS + tid] = s;
+    }
+    __syncthreads();
+    if (tid < 14) {
+        const float cnt = lds[THREADS + 13];
+        if (tid == 13) {
+            log_out[13] = cnt;
+        } else if (cnt > 0.0f) {
+            const float s = lds[THREADS + tid];
+            float val;
+            if (tid < ROVER_NUM_REW) val = s / cnt / c.max_episode_length_s;  // Episode Reward/<term>
+            else if (tid < 11) val = s;                                        // Episode Termination/<term>
+            else val = s / cnt;                                                // Metrics/target_pose/*
+            log_out[tid] = val;
+        }
+    }
+}
 #ifndef RV_K2_THREADS
 #define RV_K2_THREADS 512   // 8 waves share the LDS tiles; <= 40 KiB of LDS per workgroup admits 4 workgroups = 32 waves per CU
 #endif
@@ -1704,33 +1754,7 @@ __global__ __launch_bounds__(RV_K2_THREADS) __attribute__((amdgpu_waves_per_eu(8
     const int tid = threadIdx.x;
     const int N = p.n;
     if (MODE == 2 && blockIdx.x == gridDim.x - 1) {
-        // deterministic reduction of the per-wave log partials: GROUPS x 16 words, then a fixed-order sum
-        constexpr int GROUPS = RV_K2_THREADS / 16;
-        const int word = tid & 15, grp = tid >> 4;
-        float acc = 0.0f;
-        for (int w = grp; w < n_waves; w += GROUPS) acc += log_partial[(size_t)w * ROVER_LOG_WORDS + word];
-        lds[grp * 16 + word] = acc;
-        __syncthreads();
-        if (tid < 16) {
-            float s = 0.0f;
-#pragma unroll
-            for (int g = 0; g < GROUPS; ++g) s += lds[g * 16 + tid];
-            lds[RV_K2_THREADS + tid] = s;
-        }
-        __syncthreads();
-        if (tid < 14) {
-            const float cnt = lds[RV_K2_THREADS + 13];
-            if (tid == 13) {
-                log_out[13] = cnt;
-            } else if (cnt > 0.0f) {
-                const float s = lds[RV_K2_THREADS + tid];
-                float val;
-                if (tid < ROVER_NUM_REW) val = s / cnt / p.cfg.max_episode_length_s;  // Episode Reward/<term>
-                else if (tid < 11) val = s;                                            // Episode Termination/<term>
-                else val = s / cnt;                                                    // Metrics/target_pose/*
-                log_out[tid] = val;
-            }
-        }
+        reduce_log_partials<RV_K2_THREADS>(p.cfg, lds, tid, log_partial, n_waves, log_out);
         return;
     }
     const rover_config &c = p.cfg;
@@ -1848,20 +1872,7 @@ __global__ __launch_bounds__(RV_K2_THREADS) __attribute__((amdgpu_waves_per_eu(8
     // int16 tile the interpolation runs on the raw integers and is scaled once at the end: q_scale is a power of two, so
     // this is bit-identical to interpolating the scaled heights
     auto bilerp = [&](const cell_t *q, float fx, float fy) -> float {
-        const float h00 = (float)q[0], h01 = (float)q[1], h10 = (float)q[pitch], h11 = (float)q[pitch + 1];
-        float hh;
-        if (TRI) {
-            const bool lower = fx >= fy;                       // lower triangle: corners 00, 01, 11; upper: 00, 10, 11
-            const float pm = lower ? h01 : h10;
-            const float d1 = pm - h00, d2 = h11 - pm;
-            const float a = lower ? d1 : d2, b = lower ? d2 : d1;
-            hh = fmaf(fy, b, fmaf(fx, a, h00));
-        } else {
-            const float dx0 = h01 - h00, dx1 = h11 - h10;
-            const float hx0 = h00 + fx * dx0;
-            const float hx1 = h10 + fx * dx1;
-            hh = hx0 + fy * (hx1 - hx0);
-        }
+        const float hh = patch_height<TRI>(q, pitch, fx, fy);
         return Q16 ? hh * p.q_scale : hh;
     };
     // one vertical ray: bilinear height of the staged tile at the yaw-rotated grid point.  FAST (whole-workgroup uniform,
@@ -1936,6 +1947,151 @@ __global__ __launch_bounds__(RV_K2_THREADS) __attribute__((amdgpu_waves_per_eu(8
     wn = wnn;
     e = e_next;
     }  // env loop
+}
+
+// ------------------------------------------------------------------------------------------------ K2, step form
+// The scan kernel of rover_step() when the host can promise 16-byte chunk staging (map width a multiple of the chunk,
+// aligned base) and two tile buffers -- every procedural or imported terrain of a power-of-two width.  Same schedule and
+// the same arithmetic as rover_scan_obs_kernel<2, ...>, written for a small SCALAR footprint: 8 waves per SIMD leave 80
+// SGPRs per wave (800 per SIMD, 16 of them the trap handler's), and the generic kernel keeps three decoded windows plus
+// every uniform of its fallback paths live, which costs ~50 v_readlane / v_writelane spill moves per env.  Here
+//   * the window of the env being cast lives in VGPRs (8 v_mov per env; VGPRs are plentiful: 64 per lane, < 40 used),
+//   * the two windows in flight (tile being staged; descriptor being fetched) stay as the raw 8-dword descriptors,
+//   * each thread's ray offsets (rays tid and tid + 512) are computed once, not per env (no table reads, no index split).
+__device__ __forceinline__ float to_vgpr(float uniform) { float v; asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(uniform)); return v; }
+__device__ __forceinline__ int to_vgpr(int uniform) { int v; asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(uniform)); return v; }
+
+template <bool Q16, bool TRI>
+__global__ __launch_bounds__(RV_K2_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void rover_scan_step_kernel(
+    RvParams p, float *__restrict__ out, int row_stride, int col0, const float *__restrict__ log_partial, int n_waves,
+    float *__restrict__ log_out, const float *__restrict__ scan_desc)
+{
+    extern __shared__ __align__(16) float lds[];
+    const int tid = threadIdx.x;
+    if (blockIdx.x == gridDim.x - 1) {
+        reduce_log_partials<RV_K2_THREADS>(p.cfg, lds, tid, log_partial, n_waves, log_out);
+        return;
+    }
+    const rover_config &c = p.cfg;
+    const int N = p.n;
+    const int n_wg = (int)gridDim.x - 1;
+    using cell_t = typename std::conditional<Q16, int16_t, float>::type;
+    constexpr int CC = Q16 ? 8 : 4;  // cells per 16-byte chunk
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    float *inv_tab = lds + 128;  // same LDS carve as the generic kernel; the ray-offset tables at [0, 128) are not needed
+    cell_t *tile_base = reinterpret_cast<cell_t *>(lds + 192);
+    const int tile_cells = p.tile_dim * p.tile_pitch;
+    const cell_t *hsrc = Q16 ? reinterpret_cast<const cell_t *>(p.height_q) : reinterpret_cast<const cell_t *>(p.height);
+    // ORBIT grid_pattern: arange(-size/2, size/2 + 1e-9, res) evaluated in double, x fastest (App. C)
+    auto pattern_x = [&](int j) { return (float)(-0.5 * (double)c.scan_size_x + (double)c.scan_resolution * (double)j); };
+    auto pattern_y = [&](int i) { return (float)(-0.5 * (double)c.scan_size_y + (double)c.scan_resolution * (double)i); };
+    if (tid >= 128 && tid < 192) inv_tab[tid - 128] = 1.0f / (float)max(tid - 128, 1);
+    const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
+    // this thread's two rays (the host sends patterns of more than 2 x 512 rays to the generic kernel).  A thread without a
+    // second (or any) ray of its own repeats its first ray (or ray 0): the duplicate stores write the same bits, and the
+    // ray phase needs no execution masks
+    const int r0 = tid < p.rays ? tid : 0;
+    const int r1 = tid + RV_K2_THREADS < p.rays ? tid + RV_K2_THREADS : r0;
+    const float ox0 = pattern_x(r0 % c.scan_nx), oy0 = pattern_y(r0 / c.scan_nx);
+    const float ox1 = pattern_x(r1 % c.scan_nx), oy1 = pattern_y(r1 / c.scan_nx);
+
+    int e = blockIdx.x;
+    if (e >= N) return;
+    __syncthreads();  // tables
+
+    // asynchronous dense copy of a th x tw4 chunk window into LDS (see rover_scan_obs_kernel)
+    auto issue_tile = [&](const float4 &d1, cell_t *tile) {
+        const int i_lo = __float_as_int(d1.y), j_lo = __float_as_int(d1.z), pk = __float_as_int(d1.w);
+        const int th = pk & 0x7FFF, tw4 = pk >> 16;
+        const v4f *src = reinterpret_cast<const v4f *>(hsrc + (size_t)i_lo * p.W + j_lo);
+        v4f *dst = reinterpret_cast<v4f *>(tile);
+        const int nchunk = th * tw4;
+        const float inv_tw4 = inv_tab[tw4];
+        for (int k0 = 0; k0 < nchunk; k0 += RV_K2_THREADS) {
+            const int k = k0 + tid;
+            if (k < nchunk) {
+                const int r = (int)(((float)k + 0.5f) * inv_tw4);  // k / tw4, exact for k < 2^20
+                const int cq = k - (int)__umul24(r, tw4);
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(src + (size_t)(__umul24(r, p.wq) + cq)),
+                    (__attribute__((address_space(3))) void *)(dst + (k0 + wave_base)), 16, 0, 0);
+            }
+        }
+    };
+    auto load_desc = [&](int env, float4 &d0, float4 &d1) {
+        const float4 *d = reinterpret_cast<const float4 *>(scan_desc + (size_t)env * 8);
+        d0 = d[0];
+        d1 = d[1];
+    };
+
+    float4 a0, a1, b0, b1;  // descriptors: a = env e + n_wg (its tile is staged while e is cast), b = the one after
+    load_desc(e, a0, a1);
+    issue_tile(a1, tile_base);
+    // the env being cast: pose and window origin in VGPRs, the packed sizes as one scalar
+    float px = to_vgpr(a0.x), py = to_vgpr(a0.y), pz = to_vgpr(a0.z), cy = to_vgpr(a0.w), sy = to_vgpr(a1.x);
+    int i_lo = to_vgpr(__float_as_int(a1.y)), j_lo = to_vgpr(__float_as_int(a1.z));
+    int pk = __float_as_int(a1.w);
+    if (e + n_wg < N) load_desc(e + n_wg, a0, a1);
+    for (int it = 0;; ++it) {
+        cell_t *tile = tile_base + (it & 1) * tile_cells;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int e_next = e + n_wg;
+        const bool more = e_next < N;
+        if (more) issue_tile(a1, tile_base + ((it + 1) & 1) * tile_cells);
+        if (e_next + n_wg < N) load_desc(e_next + n_wg, b0, b1);
+        else { b0 = a0; b1 = a1; }
+        const int th = pk & 0x7FFF;
+        const int pitch = (pk >> 16) * CC;  // cells per staged row
+        float *row = out + (size_t)e * row_stride + col0;
+        auto ray_obs = [&](float ox, float oy, auto fast_tag) -> float {
+            constexpr bool FAST = decltype(fast_tag)::value;
+            const float x = px + (cy * ox - sy * oy);
+            const float y = py + (sy * ox + cy * oy);
+            float hgt;
+            if (FAST) {
+                const float u = (x - p.min_x) * p.inv_res;
+                const float v = (y - p.min_y) * p.inv_res;
+                const int j0 = (int)u, i0 = (int)v;
+                const float fx = u - (float)j0, fy = v - (float)i0;
+                hgt = patch_height<TRI>(tile + (__umul24(i0 - i_lo, pitch) + (j0 - j_lo)), pitch, fx, fy);
+            } else if (x < p.min_x || x > p.x_max || y < p.min_y || y > p.y_max) {
+                return pz - INFINITY - c.scan_height_offset;  // ray leaves the terrain: ORBIT RayCaster reports +inf
+            } else {
+                float u = (x - p.min_x) * p.inv_res;
+                float v = (y - p.min_y) * p.inv_res;
+                u = clampf(u, 0.0f, (float)(p.W - 1));
+                v = clampf(v, 0.0f, (float)(p.H - 1));
+                int j0 = (int)u, i0 = (int)v;
+                if (j0 > p.W - 2) j0 = p.W - 2;
+                if (i0 > p.H - 2) i0 = p.H - 2;
+                const float fx = u - (float)j0, fy = v - (float)i0;
+                const int jl = j0 - j_lo, il = i0 - i_lo;
+                const int tw = min(pitch, p.W - j_lo);
+                const bool in_tile = jl >= 0 && il >= 0 && jl + 1 < tw && il + 1 < th;
+                const int jc = max(0, min(jl, tw - 2)), ic = max(0, min(il, th - 2));
+                hgt = patch_height<TRI>(tile + ic * pitch + jc, pitch, fx, fy);
+                if (!in_tile) return __int_as_float(0x7fc00000);  // a ray outside the staged window is a bug: NaN
+            }
+            if (Q16) hgt *= p.q_scale;
+            return pz - hgt - c.scan_height_offset;  // observations.py:45
+        };
+        auto all_rays = [&](auto fast_tag) {
+            const float o0 = ray_obs(ox0, oy0, fast_tag);
+            const float o1 = ray_obs(ox1, oy1, fast_tag);
+            row[r0] = o0;
+            row[r1] = o1;
+        };
+        if ((pk >> 15) & 1) all_rays(std::true_type{});
+        else all_rays(std::false_type{});
+        if (!more) break;
+        px = to_vgpr(a0.x); py = to_vgpr(a0.y); pz = to_vgpr(a0.z); cy = to_vgpr(a0.w); sy = to_vgpr(a1.x);
+        i_lo = to_vgpr(__float_as_int(a1.y)); j_lo = to_vgpr(__float_as_int(a1.z));
+        pk = __float_as_int(a1.w);
+        a0 = b0;
+        a1 = b1;
+        e = e_next;
+    }
 }
 
 // ================================================================================================ unit kernels
@@ -2070,14 +2226,24 @@ static void launch_scan(rover_sim *sim, int grid, hipStream_t st, float *out, in
 {
     grid = (sim->p.n < sim->scan_wgs ? sim->p.n : sim->scan_wgs) + (MODE == 2 ? 1 : 0);
     const bool q16 = sim->p.height_q != nullptr, tri = sim->p.cfg.scan_surface == 0;
-#define RV_LAUNCH_SCAN(Q, T)                                                                                                  \
-    hipLaunchKernelGGL((rover_scan_obs_kernel<MODE, Q, T>), dim3(grid), dim3(RV_K2_THREADS), sim->lds_bytes, st, sim->p,       \
-                       sim->state, out, row_stride, col0, log_partial, n_waves, log_out, sim->p.scan_desc)
-    if (q16 && tri) RV_LAUNCH_SCAN(true, true);
-    else if (q16) RV_LAUNCH_SCAN(true, false);
-    else if (tri) RV_LAUNCH_SCAN(false, true);
-    else RV_LAUNCH_SCAN(false, false);
-#undef RV_LAUNCH_SCAN
+    const int cc = q16 ? 8 : 4;
+    const uintptr_t base = q16 ? reinterpret_cast<uintptr_t>(sim->p.height_q) : reinterpret_cast<uintptr_t>(sim->p.height);
+    const bool simple = MODE == 2 && sim->p.tile_bufs == 2 && (sim->p.W & (cc - 1)) == 0 && (base & 15) == 0 &&
+                        sim->p.rays <= 2 * RV_K2_THREADS;
+#define RV_LAUNCH_SCAN_QT(Q, T)                                                                                               \
+    do {                                                                                                                      \
+        if (simple)                                                                                                           \
+            hipLaunchKernelGGL((rover_scan_step_kernel<Q, T>), dim3(grid), dim3(RV_K2_THREADS), sim->lds_bytes, st, sim->p,    \
+                               out, row_stride, col0, log_partial, n_waves, log_out, sim->p.scan_desc);                       \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((rover_scan_obs_kernel<MODE, Q, T>), dim3(grid), dim3(RV_K2_THREADS), sim->lds_bytes, st,       \
+                               sim->p, sim->state, out, row_stride, col0, log_partial, n_waves, log_out, sim->p.scan_desc);   \
+    } while (0)
+    if (q16 && tri) RV_LAUNCH_SCAN_QT(true, true);
+    else if (q16) RV_LAUNCH_SCAN_QT(true, false);
+    else if (tri) RV_LAUNCH_SCAN_QT(false, true);
+    else RV_LAUNCH_SCAN_QT(false, false);
+#undef RV_LAUNCH_SCAN_QT
 }
 
 extern "C" {
