@@ -603,10 +603,15 @@ __device__ __forceinline__ void chassis_integrate(float h, const float R[3][3], 
                                                   float (*R_next)[3] = nullptr, float *com_off_next = nullptr)
 {
     constexpr float COM_B[3] = RV_COM_B_INIT;
-    const float sp = sqrtf(dot3f(v, v));
-    if (sp > RV_MAX_LINEAR_VEL) {
-        const float sc = RV_MAX_LINEAR_VEL / sp;
-        v[0] *= sc; v[1] *= sc; v[2] *= sc;
+    // speed cap.  sqrt is monotonic, so |v|^2 <= cap^2 implies sqrt(|v|^2) <= cap: the square root and the division are only
+    // evaluated by waves in which some lane may exceed the cap (a wave-uniform branch; same results as testing every lane)
+    const float v2 = dot3f(v, v);
+    if (__builtin_amdgcn_ballot_w64(v2 > RV_MAX_LINEAR_VEL * RV_MAX_LINEAR_VEL) != 0ull) {
+        const float sp = sqrtf(v2);
+        if (sp > RV_MAX_LINEAR_VEL) {
+            const float sc = RV_MAX_LINEAR_VEL / sp;
+            v[0] *= sc; v[1] *= sc; v[2] *= sc;
+        }
     }
     float w[3];
     mat_vecf(R, wb, w);  // angular velocity back to the world frame
@@ -1692,7 +1697,11 @@ __global__ __launch_bounds__(64) void rover_reset_kernel(RvParams p, float *__re
 template <bool TRI, typename cell_t>
 __device__ __forceinline__ float patch_height(const cell_t *q, int pitch, float fx, float fy)
 {
-    const float h00 = (float)q[0], h01 = (float)q[1], h10 = (float)q[pitch], h11 = (float)q[pitch + 1];
+    // volatile: the four cells are read one by one.  hipcc would otherwise merge the two int16 cells of a row into ONE
+    // ds_read_b32 at a 2-byte-aligned address, and those cost more LDS time than the two reads they replace
+    // (scan kernel 22.5 -> 19.5 us at num_envs = 4096 with the merge suppressed)
+    const volatile cell_t *qv = q;
+    const float h00 = (float)qv[0], h01 = (float)qv[1], h10 = (float)qv[pitch], h11 = (float)qv[pitch + 1];
     if (TRI) {
         const bool lower = fx >= fy;                       // lower triangle: corners 00, 01, 11; upper: 00, 10, 11
         const float pm = lower ? h01 : h10;
@@ -1951,13 +1960,16 @@ __global__ __launch_bounds__(RV_K2_THREADS) __attribute__((amdgpu_waves_per_eu(8
 
 // ------------------------------------------------------------------------------------------------ K2, step form
 // The scan kernel of rover_step() when the host can promise 16-byte chunk staging (map width a multiple of the chunk,
-// aligned base) and two tile buffers -- every procedural or imported terrain of a power-of-two width.  Same schedule and
-// the same arithmetic as rover_scan_obs_kernel<2, ...>, written for a small SCALAR footprint: 8 waves per SIMD leave 80
-// SGPRs per wave (800 per SIMD, 16 of them the trap handler's), and the generic kernel keeps three decoded windows plus
-// every uniform of its fallback paths live, which costs ~50 v_readlane / v_writelane spill moves per env.  Here
-//   * the window of the env being cast lives in VGPRs (8 v_mov per env; VGPRs are plentiful: 64 per lane, < 40 used),
+// aligned base) and a pattern of at most 2 x 512 rays -- every procedural or imported terrain of a power-of-two width.
+// Same arithmetic as rover_scan_obs_kernel<2, ...>, written for a small SCALAR footprint: 8 waves per SIMD leave 80 SGPRs
+// per wave (800 per SIMD, 16 of them the trap handler's), and the generic kernel keeps three decoded windows plus every
+// uniform of its fallback paths live, which costs ~50 v_readlane / v_writelane spill moves per env.  Here
+//   * the window of the env being cast lives in VGPRs (8 v_mov per env; VGPRs are plentiful: 64 per lane, < 48 used),
 //   * the two windows in flight (tile being staged; descriptor being fetched) stay as the raw 8-dword descriptors,
-//   * each thread's ray offsets (rays tid and tid + 512) are computed once, not per env (no table reads, no index split).
+//   * each thread's ray offsets (rays tid and tid + 512) are computed once, not per env (no table reads, no index split),
+//   * ONE tile buffer: with four workgroups per CU the copy of one workgroup already overlaps the rays of the others, and a
+//     second buffer measured no faster (tools/n_sweep.py: 19.4 vs 19.6 us at 4096 envs, 116 vs 112 us at 32768).
+// No SGPR spills (was 68), 46 VGPRs.
 __device__ __forceinline__ float to_vgpr(float uniform) { float v; asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(uniform)); return v; }
 __device__ __forceinline__ int to_vgpr(int uniform) { int v; asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(uniform)); return v; }
 
@@ -1980,7 +1992,6 @@ __global__ __launch_bounds__(RV_K2_THREADS) __attribute__((amdgpu_waves_per_eu(8
     typedef float v4f __attribute__((ext_vector_type(4)));
     float *inv_tab = lds + 128;  // same LDS carve as the generic kernel; the ray-offset tables at [0, 128) are not needed
     cell_t *tile_base = reinterpret_cast<cell_t *>(lds + 192);
-    const int tile_cells = p.tile_dim * p.tile_pitch;
     const cell_t *hsrc = Q16 ? reinterpret_cast<const cell_t *>(p.height_q) : reinterpret_cast<const cell_t *>(p.height);
     // ORBIT grid_pattern: arange(-size/2, size/2 + 1e-9, res) evaluated in double, x fastest (App. C)
     auto pattern_x = [&](int j) { return (float)(-0.5 * (double)c.scan_size_x + (double)c.scan_resolution * (double)j); };
@@ -2032,13 +2043,12 @@ __global__ __launch_bounds__(RV_K2_THREADS) __attribute__((amdgpu_waves_per_eu(8
     int i_lo = to_vgpr(__float_as_int(a1.y)), j_lo = to_vgpr(__float_as_int(a1.z));
     int pk = __float_as_int(a1.w);
     if (e + n_wg < N) load_desc(e + n_wg, a0, a1);
-    for (int it = 0;; ++it) {
-        cell_t *tile = tile_base + (it & 1) * tile_cells;
+    for (;;) {
+        cell_t *tile = tile_base;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int e_next = e + n_wg;
         const bool more = e_next < N;
-        if (more) issue_tile(a1, tile_base + ((it + 1) & 1) * tile_cells);
         if (e_next + n_wg < N) load_desc(e_next + n_wg, b0, b1);
         else { b0 = a0; b1 = a1; }
         const int th = pk & 0x7FFF;
@@ -2085,6 +2095,8 @@ __global__ __launch_bounds__(RV_K2_THREADS) __attribute__((amdgpu_waves_per_eu(8
         if ((pk >> 15) & 1) all_rays(std::true_type{});
         else all_rays(std::false_type{});
         if (!more) break;
+        __syncthreads();  // every ray of this env has read the tile
+        issue_tile(a1, tile_base);
         px = to_vgpr(a0.x); py = to_vgpr(a0.y); pz = to_vgpr(a0.z); cy = to_vgpr(a0.w); sy = to_vgpr(a1.x);
         i_lo = to_vgpr(__float_as_int(a1.y)); j_lo = to_vgpr(__float_as_int(a1.z));
         pk = __float_as_int(a1.w);
@@ -2200,6 +2212,7 @@ struct rover_sim {
     size_t lds_bytes;
     int n_cu;          // compute units of the device
     int scan_wgs;      // persistent scan workgroups: what the device holds at once
+    int scan_form;     // measurement hook: 1 = the generic scan kernel on the step path too
 };
 
 static void configure_tile(rover_sim *sim, int chunk_cells);
@@ -2228,8 +2241,8 @@ static void launch_scan(rover_sim *sim, int grid, hipStream_t st, float *out, in
     const bool q16 = sim->p.height_q != nullptr, tri = sim->p.cfg.scan_surface == 0;
     const int cc = q16 ? 8 : 4;
     const uintptr_t base = q16 ? reinterpret_cast<uintptr_t>(sim->p.height_q) : reinterpret_cast<uintptr_t>(sim->p.height);
-    const bool simple = MODE == 2 && sim->p.tile_bufs == 2 && (sim->p.W & (cc - 1)) == 0 && (base & 15) == 0 &&
-                        sim->p.rays <= 2 * RV_K2_THREADS;
+    const bool simple = MODE == 2 && (sim->p.W & (cc - 1)) == 0 && (base & 15) == 0 && sim->p.rays <= 2 * RV_K2_THREADS &&
+                        sim->scan_form != 1;
 #define RV_LAUNCH_SCAN_QT(Q, T)                                                                                               \
     do {                                                                                                                      \
         if (simple)                                                                                                           \
@@ -2392,8 +2405,8 @@ static void configure_tile(rover_sim *sim, int chunk_cells)
 {
     RvParams &p = sim->p;
     p.chunk_cells = chunk_cells;
-    // + (chunk - 1) cells for the alignment of the left edge, + one chunk of padding
-    p.tile_pitch = ((p.tile_dim + 2 * (chunk_cells - 1)) & ~(chunk_cells - 1)) + chunk_cells;
+    // widest window: tile_dim cells + (chunk - 1) cells for the alignment of its left edge, rounded up to whole chunks
+    p.tile_pitch = (p.tile_dim + 2 * (chunk_cells - 1)) & ~(chunk_cells - 1);
     const size_t cell_bytes = chunk_cells == 8 ? 2 : 4;
     const size_t tile_bytes = (size_t)p.tile_dim * p.tile_pitch * cell_bytes;
     // 8-wave workgroups: four per CU fill the 32 wave slots and may use 40 KiB of the 160 KiB LDS each
@@ -2586,6 +2599,13 @@ int rover_height_scan(rover_sim *sim, float *scan, void *stream)
     return ROVER_OK;
 }
 
+// measurement hook (tools/n_sweep.py): 1 = run the generic scan kernel on the step path as well (0 = automatic choice)
+int rover_debug_set_scan_form(rover_sim *sim, int form)
+{
+    if (!sim || form < 0 || form > 1) return ROVER_ERR_INVALID;
+    sim->scan_form = form;
+    return ROVER_OK;
+}
 #ifdef RV_K1_STAMP
 int rover_debug_set_k1_stamps(void *buf)
 {

@@ -7,16 +7,26 @@ sys.path.insert(0, ROOT)
 from isaac_rover_orbit_amd import terrain as T
 from isaac_rover_orbit_amd.cfg import RoverEnvCfg
 from isaac_rover_orbit_amd.envs import RoverEnv
+if os.environ.get("ABLTAG"):
+    from isaac_rover_orbit_amd import _lib
+    _lib.LIB_PATH = os.path.join(ROOT, "build", "abl", f"librover_abl{os.environ['ABLTAG']}.so")
 ter = T.make_procedural_terrain((2048, 2048))
 out = []
 CASES = [(1024, "group"), (4096, "group"), (4096, "lane"), (16384, "group"), (32768, "group"), (32768, "lane"),
          (65536, "group"), (65536, "lane"), (131072, "group"), (131072, "lane")]
-if len(sys.argv) > 1:   # e.g. 1024:group 2048:group
-    CASES = [(int(a.split(":")[0]), a.split(":")[1]) for a in sys.argv[1:]]
-for n, mapping in CASES:
+if len(sys.argv) > 1:   # e.g. 1024:group 2048:group:wave  (third field: scan kernel of the step path, auto | generic)
+    CASES = [tuple(a.split(":")) for a in sys.argv[1:]]
+import ctypes as C
+FORMS = {"auto": 0, "generic": 1}
+for case in CASES:
+    n, mapping, form = int(case[0]), case[1], (case[2] if len(case) > 2 else "auto")
     ter.make_spawns(2 * n)
     cfg = RoverEnvCfg(); cfg.scene.num_envs = n; cfg.terrain.kind = "custom"; cfg.step_mapping = mapping
-    env = RoverEnv(cfg, terrain=ter); env.reset()
+    env = RoverEnv(cfg, terrain=ter)
+    fn = C.CDLL(env._lib._name).rover_debug_set_scan_form
+    fn.argtypes = [C.c_void_p, C.c_int]
+    assert fn(env._h, FORMS[form]) == 0
+    env.reset()
     g = torch.Generator(device="cuda").manual_seed(0)
     acts = torch.rand(16, n, 2, device="cuda", generator=g) * 2 - 1
     for k in range(20): env.step(acts[k % 16])
@@ -27,7 +37,7 @@ for n, mapping in CASES:
     a = b = 0.0
     for k in range(20):
         x, y = env.profile_step(acts[k % 16]); a += x; b += y
-    r = {"num_envs": n, "mapping": mapping, "env_steps_per_s": n * steps / dt, "us_per_step": dt / steps * 1e6,
+    r = {"num_envs": n, "mapping": mapping, "scan_form": form, "env_steps_per_s": n * steps / dt, "us_per_step": dt / steps * 1e6,
          "step_kernel_us": a / 20 * 1e3, "scan_kernel_us": b / 20 * 1e3}
     print(json.dumps(r)); out.append(r)
     env.close(); del env; torch.cuda.empty_cache()
