@@ -29,6 +29,20 @@ class Agent:
         self._initialised += 1
         self.trainer_cfg = copy.copy(trainer_cfg) if trainer_cfg is not None else {}
 
+    def load(self, path):
+        """skrl 1.1.0: a checkpoint is {module name: state_dict or object}; every registered module present in it is restored"""
+        modules = torch.load(path, map_location=self.device, weights_only=False)
+        self.loaded = []
+        for name, data in modules.items():
+            module = getattr(self, "checkpoint_modules", {}).get(name)
+            if module is None:
+                continue
+            if hasattr(module, "load_state_dict"):
+                module.load_state_dict(data)
+                if hasattr(module, "eval"):
+                    module.eval()
+            self.loaded.append(name)
+
     def track_data(self, tag, value):
         self.tracking_data[tag].append(value)
 

@@ -46,6 +46,11 @@ class PPO(Agent):
         self._state_preprocessor = sp(**c["state_preprocessor_kwargs"]) if sp is not None else (lambda x, **kw: x)
         self._value_preprocessor = vp(**c["value_preprocessor_kwargs"]) if vp is not None else (lambda x, **kw: x)
         self.updates = 0
+        self.checkpoint_modules = {"policy": self.policy, "value": self.value, "optimizer": self.optimizer}
+        if sp is not None:
+            self.checkpoint_modules["state_preprocessor"] = self._state_preprocessor
+        if vp is not None:
+            self.checkpoint_modules["value_preprocessor"] = self._value_preprocessor
 
     def init(self, trainer_cfg=None):
         super().init(trainer_cfg)

@@ -24,4 +24,26 @@ class Trainer:
         raise NotImplementedError
 
     def single_agent_eval(self):
-        raise NotImplementedError
+        """skrl 1.1.0 call order for one agent: reset once; per step act (no grad) -> env.step -> render unless headless ->
+        record_transition -> the BASE agent's post_interaction (logging only, no learning) -> carry the next states over
+        (vectorised envs reset themselves)."""
+        import torch
+        assert self.num_simultaneous_agents == 1
+        base = type(self.agents).__mro__[1]
+        states, infos = self.env.reset()
+        for timestep in range(self.initial_timestep, self.timesteps):
+            with torch.no_grad():
+                actions = self.agents.act(states, timestep=timestep, timesteps=self.timesteps)[0]
+                next_states, rewards, terminated, truncated, infos = self.env.step(actions)
+                if not self.headless:
+                    self.env.render()
+                self.agents.record_transition(states=states, actions=actions, rewards=rewards, next_states=next_states,
+                                              terminated=terminated, truncated=truncated, infos=infos, timestep=timestep,
+                                              timesteps=self.timesteps)
+                base.post_interaction(self.agents, timestep=timestep, timesteps=self.timesteps)
+                if self.env.num_envs > 1:
+                    states = next_states
+                elif terminated.any() or truncated.any():
+                    states, infos = self.env.reset()
+                else:
+                    states = next_states

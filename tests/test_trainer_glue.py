@@ -50,3 +50,30 @@ def test_reference_train_script_runs_to_completion(clean_modules, golden_dir):
     g = np.load(f"{golden_dir}/trainer_transcript.npz")
     assert list(g["calls"]) == env.calls and g["actions"].shape == t["actions"].shape
     assert np.allclose(g["actions"][:5], t["actions"][:5], atol=1e-4)
+
+
+def test_reference_eval_script_loads_the_pretrained_agent(clean_modules):
+    """examples/03_inference_pretrained/eval.py, unchanged: ``agent.load(best_agent.pt)`` into the networks the reference's own
+    factory builds (eval.py:146-149), then ``SkrlSequentialLogTrainer.eval`` (skrl_utils.py:150-175 -> skrl's single-agent
+    evaluation loop) drives the env with the Isaac-Sim-trained policy."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_trainer_transcript as gt
+    import torch
+    n, steps = 64, 150
+    env = gt.run_reference_trainer(n, steps, seed=3, script_rel="examples/03_inference_pretrained/eval.py")
+    from skrl.agents.torch.ppo import PPO
+    agent = PPO.instances[-1]
+    assert env.calls == ["reset"] + ["step"] * steps + ["close"]              # eval.py:154-157
+    assert agent.loaded == ["policy", "value", "optimizer"]                   # every module of the checkpoint was restored
+    ckpt = torch.load(os.path.join(REF, "rover_envs/envs/navigation/robots/aau_rover/policies/best_agent.pt"),
+                      map_location="cpu", weights_only=False)
+    for k, v in ckpt["policy"].items():
+        assert torch.equal(agent.policy.state_dict()[k].cpu(), v), k
+    assert agent.updates == 0 and not agent.training                          # evaluation mode: nothing was learned
+    t = env.transcript()
+    assert np.isfinite(t["reward"]).all() and np.abs(t["actions"]).max() <= 1.0
+    # the trained policy drives: it reaches targets within 150 steps, which random or zero actions never do (DESIGN 5)
+    log = t["log"]
+    finished = log[:, 13].sum()
+    successes = log[:, 8].sum()               # Episode Termination/is_success: episodes of the step's reset batch that ended so
+    assert finished > 0 and successes > 0, (finished, successes)

@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
 
 
-def run_reference_trainer(num_envs: int, timesteps: int, seed: int = 7):
+def run_reference_trainer(num_envs: int, timesteps: int, seed: int = 7, script_rel: str = "examples/02_train/train.py"):
     for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "doubles")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -40,7 +40,7 @@ def run_reference_trainer(num_envs: int, timesteps: int, seed: int = 7):
     envs_pkg.RoverEnv = _Recording               # the entry point string "isaac_rover_orbit_amd.envs:RoverEnv" resolves at make()
     os.environ["SKRL_DOUBLE_MAX_TIMESTEPS"] = str(timesteps)
     os.environ.setdefault("EXP_PATH", "/nonexistent/isaac-sim/apps")      # train.py:27-29 only formats it into a string
-    script = os.path.join(REF, "examples", "02_train", "train.py")
+    script = os.path.join(REF, *script_rel.split("/"))
     argv, cwd = sys.argv, os.getcwd()
     sys.path.insert(0, REF)
     with tempfile.TemporaryDirectory() as tmp:
@@ -54,7 +54,7 @@ def run_reference_trainer(num_envs: int, timesteps: int, seed: int = 7):
             sys.argv = argv
             envs_pkg.RoverEnv = real
             os.environ.pop("SKRL_DOUBLE_MAX_TIMESTEPS", None)
-    assert len(made) == 1, "train.py must build exactly one env"
+    assert len(made) == 1, "the script must build exactly one env"
     return made[0]
 
 
