@@ -1973,15 +1973,15 @@ __global__ __launch_bounds__(RV_K2_THREADS) __attribute__((amdgpu_waves_per_eu(8
 __device__ __forceinline__ float to_vgpr(float uniform) { float v; asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(uniform)); return v; }
 __device__ __forceinline__ int to_vgpr(int uniform) { int v; asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(uniform)); return v; }
 
-template <bool Q16, bool TRI>
-__global__ __launch_bounds__(RV_K2_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void rover_scan_step_kernel(
+template <bool Q16, bool TRI, int THREADS>   // THREADS x RPT = 1024 rays at most
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void rover_scan_step_kernel(
     RvParams p, float *__restrict__ out, int row_stride, int col0, const float *__restrict__ log_partial, int n_waves,
     float *__restrict__ log_out, const float *__restrict__ scan_desc)
 {
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x;
     if (blockIdx.x == gridDim.x - 1) {
-        reduce_log_partials<RV_K2_THREADS>(p.cfg, lds, tid, log_partial, n_waves, log_out);
+        reduce_log_partials<THREADS>(p.cfg, lds, tid, log_partial, n_waves, log_out);
         return;
     }
     const rover_config &c = p.cfg;
@@ -1998,13 +1998,19 @@ __global__ __launch_bounds__(RV_K2_THREADS) __attribute__((amdgpu_waves_per_eu(8
     auto pattern_y = [&](int i) { return (float)(-0.5 * (double)c.scan_size_y + (double)c.scan_resolution * (double)i); };
     if (tid >= 128 && tid < 192) inv_tab[tid - 128] = 1.0f / (float)max(tid - 128, 1);
     const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
-    // this thread's two rays (the host sends patterns of more than 2 x 512 rays to the generic kernel).  A thread without a
-    // second (or any) ray of its own repeats its first ray (or ray 0): the duplicate stores write the same bits, and the
-    // ray phase needs no execution masks
-    const int r0 = tid < p.rays ? tid : 0;
-    const int r1 = tid + RV_K2_THREADS < p.rays ? tid + RV_K2_THREADS : r0;
-    const float ox0 = pattern_x(r0 % c.scan_nx), oy0 = pattern_y(r0 / c.scan_nx);
-    const float ox1 = pattern_x(r1 % c.scan_nx), oy1 = pattern_y(r1 / c.scan_nx);
+    // this thread's RPT rays tid + m THREADS (the host sends patterns of more than 1024 rays to the generic kernel).  A thread
+    // without an m-th ray of its own repeats its first ray (or ray 0): the duplicate stores write the same bits, and the ray
+    // phase needs no execution masks
+    constexpr int RPT = 1024 / THREADS;
+    int ray[RPT];
+    float ox[RPT], oy[RPT];
+#pragma unroll
+    for (int m = 0; m < RPT; ++m) {
+        const int r = tid + m * THREADS;
+        ray[m] = r < p.rays ? r : (m == 0 ? 0 : ray[0]);
+        ox[m] = pattern_x(ray[m] % c.scan_nx);
+        oy[m] = pattern_y(ray[m] / c.scan_nx);
+    }
 
     int e = blockIdx.x;
     if (e >= N) return;
@@ -2018,7 +2024,7 @@ __global__ __launch_bounds__(RV_K2_THREADS) __attribute__((amdgpu_waves_per_eu(8
         v4f *dst = reinterpret_cast<v4f *>(tile);
         const int nchunk = th * tw4;
         const float inv_tw4 = inv_tab[tw4];
-        for (int k0 = 0; k0 < nchunk; k0 += RV_K2_THREADS) {
+        for (int k0 = 0; k0 < nchunk; k0 += THREADS) {
             const int k = k0 + tid;
             if (k < nchunk) {
                 const int r = (int)(((float)k + 0.5f) * inv_tw4);  // k / tw4, exact for k < 2^20
@@ -2087,10 +2093,11 @@ __global__ __launch_bounds__(RV_K2_THREADS) __attribute__((amdgpu_waves_per_eu(8
             return pz - hgt - c.scan_height_offset;  // observations.py:45
         };
         auto all_rays = [&](auto fast_tag) {
-            const float o0 = ray_obs(ox0, oy0, fast_tag);
-            const float o1 = ray_obs(ox1, oy1, fast_tag);
-            row[r0] = o0;
-            row[r1] = o1;
+            float o[RPT];
+#pragma unroll
+            for (int m = 0; m < RPT; ++m) o[m] = ray_obs(ox[m], oy[m], fast_tag);
+#pragma unroll
+            for (int m = 0; m < RPT; ++m) row[ray[m]] = o[m];
         };
         if ((pk >> 15) & 1) all_rays(std::true_type{});
         else all_rays(std::false_type{});
@@ -2241,13 +2248,13 @@ static void launch_scan(rover_sim *sim, int grid, hipStream_t st, float *out, in
     const bool q16 = sim->p.height_q != nullptr, tri = sim->p.cfg.scan_surface == 0;
     const int cc = q16 ? 8 : 4;
     const uintptr_t base = q16 ? reinterpret_cast<uintptr_t>(sim->p.height_q) : reinterpret_cast<uintptr_t>(sim->p.height);
-    const bool simple = MODE == 2 && (sim->p.W & (cc - 1)) == 0 && (base & 15) == 0 && sim->p.rays <= 2 * RV_K2_THREADS &&
-                        sim->scan_form != 1;
+    const bool simple = MODE == 2 && (sim->p.W & (cc - 1)) == 0 && (base & 15) == 0 && sim->p.rays <= 1024 && sim->scan_form != 1;
+
 #define RV_LAUNCH_SCAN_QT(Q, T)                                                                                               \
     do {                                                                                                                      \
         if (simple)                                                                                                           \
-            hipLaunchKernelGGL((rover_scan_step_kernel<Q, T>), dim3(grid), dim3(RV_K2_THREADS), sim->lds_bytes, st, sim->p,    \
-                               out, row_stride, col0, log_partial, n_waves, log_out, sim->p.scan_desc);                       \
+            hipLaunchKernelGGL((rover_scan_step_kernel<Q, T, RV_K2_THREADS>), dim3(grid), dim3(RV_K2_THREADS), sim->lds_bytes, \
+                               st, sim->p, out, row_stride, col0, log_partial, n_waves, log_out, sim->p.scan_desc);           \
         else                                                                                                                  \
             hipLaunchKernelGGL((rover_scan_obs_kernel<MODE, Q, T>), dim3(grid), dim3(RV_K2_THREADS), sim->lds_bytes, st,       \
                                sim->p, sim->state, out, row_stride, col0, log_partial, n_waves, log_out, sim->p.scan_desc);   \
@@ -2599,7 +2606,7 @@ int rover_height_scan(rover_sim *sim, float *scan, void *stream)
     return ROVER_OK;
 }
 
-// measurement hook (tools/n_sweep.py): 1 = run the generic scan kernel on the step path as well (0 = automatic choice)
+// measurement hook (tools/n_sweep.py): 0 = automatic choice, 1 = the generic scan kernel on the step path as well
 int rover_debug_set_scan_form(rover_sim *sim, int form)
 {
     if (!sim || form < 0 || form > 1) return ROVER_ERR_INVALID;
