@@ -1960,20 +1960,24 @@ __global__ __launch_bounds__(RV_K2_THREADS) __attribute__((amdgpu_waves_per_eu(8
 
 // ------------------------------------------------------------------------------------------------ K2, step form
 // The scan kernel of rover_step() when the host can promise 16-byte chunk staging (map width a multiple of the chunk,
-// aligned base) and a pattern of at most 2 x 512 rays -- every procedural or imported terrain of a power-of-two width.
-// Same arithmetic as rover_scan_obs_kernel<2, ...>, written for a small SCALAR footprint: 8 waves per SIMD leave 80 SGPRs
-// per wave (800 per SIMD, 16 of them the trap handler's), and the generic kernel keeps three decoded windows plus every
-// uniform of its fallback paths live, which costs ~50 v_readlane / v_writelane spill moves per env.  Here
-//   * the window of the env being cast lives in VGPRs (8 v_mov per env; VGPRs are plentiful: 64 per lane, < 48 used),
-//   * the two windows in flight (tile being staged; descriptor being fetched) stay as the raw 8-dword descriptors,
-//   * each thread's ray offsets (rays tid and tid + 512) are computed once, not per env (no table reads, no index split),
-//   * ONE tile buffer: with four workgroups per CU the copy of one workgroup already overlaps the rays of the others, and a
-//     second buffer measured no faster (tools/n_sweep.py: 19.4 vs 19.6 us at 4096 envs, 116 vs 112 us at 32768).
-// No SGPR spills (was 68), 46 VGPRs.
+// aligned base) and a pattern of at most 1024 rays -- every procedural or imported terrain of a power-of-two width.
+// Same arithmetic as rover_scan_obs_kernel<2, ...>; what differs is what the measurements of round 2 asked for:
+//   * a small SCALAR footprint.  8 waves per SIMD leave 80 SGPRs per wave (800 per SIMD, 16 of them the trap handler's); the
+//     generic kernel keeps three decoded windows plus every uniform of its fallback paths live (68 spill slots, ~50
+//     v_readlane / v_writelane per env).  Here the windows being cast live in VGPRs (8 v_mov per env; VGPRs are plentiful),
+//     the windows staged next stay as raw 8-dword descriptors, and there are no spills;
+//   * each thread's ray offset is computed once, not per env (no table reads, no index split), and a thread without a ray of
+//     its own repeats ray 0, so the ray phase needs no execution masks;
+//   * FEW, FAT workgroups and few synchronisation rounds: 1024 threads (one ray per thread of a 31 x 31 pattern), two per CU,
+//     and EPI = 2 envs per round -- two tiles are staged together, one `s_waitcnt vmcnt(0)` + barrier releases both, every
+//     thread casts its ray in both.  HIP-event time at 4096 / 16384 / 32768 envs: 256 threads 26.8 / 84 us; 512 threads
+//     19.4 / 59 / 112 us; 1024 threads 18.6 / 55 / 104 us; 1024 threads x 2 envs 18.0 / 51 / 97 us (generic: 20.3 / 65 / 124);
+//   * ONE tile per env (no double buffering): the other workgroup of the CU already overlaps copy and cast, and a second
+//     buffer measured no faster at any of these sizes.
 __device__ __forceinline__ float to_vgpr(float uniform) { float v; asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(uniform)); return v; }
 __device__ __forceinline__ int to_vgpr(int uniform) { int v; asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(uniform)); return v; }
 
-template <bool Q16, bool TRI, int THREADS>   // THREADS x RPT = 1024 rays at most
+template <bool Q16, bool TRI, int THREADS, int EPI>   // THREADS x RPT = 1024 rays at most; EPI envs per iteration
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void rover_scan_step_kernel(
     RvParams p, float *__restrict__ out, int row_stride, int col0, const float *__restrict__ log_partial, int n_waves,
     float *__restrict__ log_out, const float *__restrict__ scan_desc)
@@ -1992,6 +1996,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
     typedef float v4f __attribute__((ext_vector_type(4)));
     float *inv_tab = lds + 128;  // same LDS carve as the generic kernel; the ray-offset tables at [0, 128) are not needed
     cell_t *tile_base = reinterpret_cast<cell_t *>(lds + 192);
+    const int tile_cells = p.tile_dim * p.tile_pitch;
     const cell_t *hsrc = Q16 ? reinterpret_cast<const cell_t *>(p.height_q) : reinterpret_cast<const cell_t *>(p.height);
     // ORBIT grid_pattern: arange(-size/2, size/2 + 1e-9, res) evaluated in double, x fastest (App. C)
     auto pattern_x = [&](int j) { return (float)(-0.5 * (double)c.scan_size_x + (double)c.scan_resolution * (double)j); };
@@ -2012,9 +2017,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
         oy[m] = pattern_y(ray[m] / c.scan_nx);
     }
 
-    int e = blockIdx.x;
-    if (e >= N) return;
-    __syncthreads();  // tables
+    // envs of iteration `it`: (blockIdx.x + it n_wg) EPI + j, j < EPI; indices past the end repeat env N - 1 (same bits again)
+    int e0 = blockIdx.x * EPI;
+    if (e0 >= N) return;
+    __syncthreads();  // table
 
     // asynchronous dense copy of a th x tw4 chunk window into LDS (see rover_scan_obs_kernel)
     auto issue_tile = [&](const float4 &d1, cell_t *tile) {
@@ -2036,80 +2042,92 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
         }
     };
     auto load_desc = [&](int env, float4 &d0, float4 &d1) {
-        const float4 *d = reinterpret_cast<const float4 *>(scan_desc + (size_t)env * 8);
+        const float4 *d = reinterpret_cast<const float4 *>(scan_desc + (size_t)min(env, N - 1) * 8);
         d0 = d[0];
         d1 = d[1];
     };
 
-    float4 a0, a1, b0, b1;  // descriptors: a = env e + n_wg (its tile is staged while e is cast), b = the one after
-    load_desc(e, a0, a1);
-    issue_tile(a1, tile_base);
-    // the env being cast: pose and window origin in VGPRs, the packed sizes as one scalar
-    float px = to_vgpr(a0.x), py = to_vgpr(a0.y), pz = to_vgpr(a0.z), cy = to_vgpr(a0.w), sy = to_vgpr(a1.x);
-    int i_lo = to_vgpr(__float_as_int(a1.y)), j_lo = to_vgpr(__float_as_int(a1.z));
-    int pk = __float_as_int(a1.w);
-    if (e + n_wg < N) load_desc(e + n_wg, a0, a1);
+    float4 a0[EPI], a1[EPI];  // descriptors of the envs whose tiles are staged next
+    // the envs being cast: pose and window origin in VGPRs, the packed sizes as one scalar each
+    float px[EPI], py[EPI], pz[EPI], cy[EPI], sy[EPI];
+    int i_lo[EPI], j_lo[EPI], pk[EPI];
+    auto to_cast = [&]() {
+#pragma unroll
+        for (int j = 0; j < EPI; ++j) {
+            px[j] = to_vgpr(a0[j].x); py[j] = to_vgpr(a0[j].y); pz[j] = to_vgpr(a0[j].z); cy[j] = to_vgpr(a0[j].w);
+            sy[j] = to_vgpr(a1[j].x);
+            i_lo[j] = to_vgpr(__float_as_int(a1[j].y)); j_lo[j] = to_vgpr(__float_as_int(a1[j].z));
+            pk[j] = __float_as_int(a1[j].w);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < EPI; ++j) load_desc(e0 + j, a0[j], a1[j]);
+#pragma unroll
+    for (int j = 0; j < EPI; ++j) issue_tile(a1[j], tile_base + j * tile_cells);
+    to_cast();
     for (;;) {
-        cell_t *tile = tile_base;
+        const int e_next = e0 + n_wg * EPI;
+        const bool more = e_next < N;
+        if (more) {   // scalar loads: they arrive under the ray phase
+#pragma unroll
+            for (int j = 0; j < EPI; ++j) load_desc(e_next + j, a0[j], a1[j]);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const int e_next = e + n_wg;
-        const bool more = e_next < N;
-        if (e_next + n_wg < N) load_desc(e_next + n_wg, b0, b1);
-        else { b0 = a0; b1 = a1; }
-        const int th = pk & 0x7FFF;
-        const int pitch = (pk >> 16) * CC;  // cells per staged row
-        float *row = out + (size_t)e * row_stride + col0;
-        auto ray_obs = [&](float ox, float oy, auto fast_tag) -> float {
-            constexpr bool FAST = decltype(fast_tag)::value;
-            const float x = px + (cy * ox - sy * oy);
-            const float y = py + (sy * ox + cy * oy);
-            float hgt;
-            if (FAST) {
-                const float u = (x - p.min_x) * p.inv_res;
-                const float v = (y - p.min_y) * p.inv_res;
-                const int j0 = (int)u, i0 = (int)v;
-                const float fx = u - (float)j0, fy = v - (float)i0;
-                hgt = patch_height<TRI>(tile + (__umul24(i0 - i_lo, pitch) + (j0 - j_lo)), pitch, fx, fy);
-            } else if (x < p.min_x || x > p.x_max || y < p.min_y || y > p.y_max) {
-                return pz - INFINITY - c.scan_height_offset;  // ray leaves the terrain: ORBIT RayCaster reports +inf
-            } else {
-                float u = (x - p.min_x) * p.inv_res;
-                float v = (y - p.min_y) * p.inv_res;
-                u = clampf(u, 0.0f, (float)(p.W - 1));
-                v = clampf(v, 0.0f, (float)(p.H - 1));
-                int j0 = (int)u, i0 = (int)v;
-                if (j0 > p.W - 2) j0 = p.W - 2;
-                if (i0 > p.H - 2) i0 = p.H - 2;
-                const float fx = u - (float)j0, fy = v - (float)i0;
-                const int jl = j0 - j_lo, il = i0 - i_lo;
-                const int tw = min(pitch, p.W - j_lo);
-                const bool in_tile = jl >= 0 && il >= 0 && jl + 1 < tw && il + 1 < th;
-                const int jc = max(0, min(jl, tw - 2)), ic = max(0, min(il, th - 2));
-                hgt = patch_height<TRI>(tile + ic * pitch + jc, pitch, fx, fy);
-                if (!in_tile) return __int_as_float(0x7fc00000);  // a ray outside the staged window is a bug: NaN
-            }
-            if (Q16) hgt *= p.q_scale;
-            return pz - hgt - c.scan_height_offset;  // observations.py:45
-        };
-        auto all_rays = [&](auto fast_tag) {
-            float o[RPT];
 #pragma unroll
-            for (int m = 0; m < RPT; ++m) o[m] = ray_obs(ox[m], oy[m], fast_tag);
+        for (int j = 0; j < EPI; ++j) {
+            const cell_t *tile = tile_base + j * tile_cells;
+            const int th = pk[j] & 0x7FFF;
+            const int pitch = (pk[j] >> 16) * CC;  // cells per staged row
+            float *row = out + (size_t)min(e0 + j, N - 1) * row_stride + col0;
+            auto ray_obs = [&](float rx, float ry, auto fast_tag) -> float {
+                constexpr bool FAST = decltype(fast_tag)::value;
+                const float x = px[j] + (cy[j] * rx - sy[j] * ry);
+                const float y = py[j] + (sy[j] * rx + cy[j] * ry);
+                float hgt;
+                if (FAST) {
+                    const float u = (x - p.min_x) * p.inv_res;
+                    const float v = (y - p.min_y) * p.inv_res;
+                    const int j0 = (int)u, i0 = (int)v;
+                    const float fx = u - (float)j0, fy = v - (float)i0;
+                    hgt = patch_height<TRI>(tile + (__umul24(i0 - i_lo[j], pitch) + (j0 - j_lo[j])), pitch, fx, fy);
+                } else if (x < p.min_x || x > p.x_max || y < p.min_y || y > p.y_max) {
+                    return pz[j] - INFINITY - c.scan_height_offset;  // ray leaves the terrain: ORBIT RayCaster reports +inf
+                } else {
+                    float u = (x - p.min_x) * p.inv_res;
+                    float v = (y - p.min_y) * p.inv_res;
+                    u = clampf(u, 0.0f, (float)(p.W - 1));
+                    v = clampf(v, 0.0f, (float)(p.H - 1));
+                    int j0 = (int)u, i0 = (int)v;
+                    if (j0 > p.W - 2) j0 = p.W - 2;
+                    if (i0 > p.H - 2) i0 = p.H - 2;
+                    const float fx = u - (float)j0, fy = v - (float)i0;
+                    const int jl = j0 - j_lo[j], il = i0 - i_lo[j];
+                    const int tw = min(pitch, p.W - j_lo[j]);
+                    const bool in_tile = jl >= 0 && il >= 0 && jl + 1 < tw && il + 1 < th;
+                    const int jc = max(0, min(jl, tw - 2)), ic = max(0, min(il, th - 2));
+                    hgt = patch_height<TRI>(tile + ic * pitch + jc, pitch, fx, fy);
+                    if (!in_tile) return __int_as_float(0x7fc00000);  // a ray outside the staged window is a bug: NaN
+                }
+                if (Q16) hgt *= p.q_scale;
+                return pz[j] - hgt - c.scan_height_offset;  // observations.py:45
+            };
+            auto all_rays = [&](auto fast_tag) {
+                float o[RPT];
 #pragma unroll
-            for (int m = 0; m < RPT; ++m) row[ray[m]] = o[m];
-        };
-        if ((pk >> 15) & 1) all_rays(std::true_type{});
-        else all_rays(std::false_type{});
+                for (int m = 0; m < RPT; ++m) o[m] = ray_obs(ox[m], oy[m], fast_tag);
+#pragma unroll
+                for (int m = 0; m < RPT; ++m) row[ray[m]] = o[m];
+            };
+            if ((pk[j] >> 15) & 1) all_rays(std::true_type{});
+            else all_rays(std::false_type{});
+        }
         if (!more) break;
-        __syncthreads();  // every ray of this env has read the tile
-        issue_tile(a1, tile_base);
-        px = to_vgpr(a0.x); py = to_vgpr(a0.y); pz = to_vgpr(a0.z); cy = to_vgpr(a0.w); sy = to_vgpr(a1.x);
-        i_lo = to_vgpr(__float_as_int(a1.y)); j_lo = to_vgpr(__float_as_int(a1.z));
-        pk = __float_as_int(a1.w);
-        a0 = b0;
-        a1 = b1;
-        e = e_next;
+        __syncthreads();  // every ray of this iteration has read its tile
+#pragma unroll
+        for (int j = 0; j < EPI; ++j) issue_tile(a1[j], tile_base + j * tile_cells);
+        to_cast();
+        e0 = e_next;
     }
 }
 
@@ -2249,12 +2267,22 @@ static void launch_scan(rover_sim *sim, int grid, hipStream_t st, float *out, in
     const int cc = q16 ? 8 : 4;
     const uintptr_t base = q16 ? reinterpret_cast<uintptr_t>(sim->p.height_q) : reinterpret_cast<uintptr_t>(sim->p.height);
     const bool simple = MODE == 2 && (sim->p.W & (cc - 1)) == 0 && (base & 15) == 0 && sim->p.rays <= 1024 && sim->scan_form != 1;
-
+    const size_t tile_bytes = (size_t)sim->p.tile_dim * sim->p.tile_pitch * (q16 ? 2 : 4);
+    // two envs per iteration when two workgroups with two tiles each fit the CU's LDS (measurement hook: form 2 = one env)
+    const int epi = (sim->scan_form != 2 && 2 * (192 * sizeof(float) + 2 * tile_bytes) <= 160 * 1024) ? 2 : 1;
+    const size_t step_lds = 192 * sizeof(float) + epi * tile_bytes < (1024 + 16) * sizeof(float) ? (1024 + 16) * sizeof(float)
+                                                                                                   : 192 * sizeof(float) + epi * tile_bytes;
+    if (simple) {
+        const int groups = (sim->p.n + epi - 1) / epi, wgs = 2 * sim->n_cu;   // two 1024-thread workgroups per CU
+        grid = (groups < wgs ? groups : wgs) + 1;
+    }
+#define RV_LAUNCH_STEP(Q, T, E)                                                                                               \
+    hipLaunchKernelGGL((rover_scan_step_kernel<Q, T, 1024, E>), dim3(grid), dim3(1024), step_lds, st, sim->p, out, row_stride, \
+                       col0, log_partial, n_waves, log_out, sim->p.scan_desc)
 #define RV_LAUNCH_SCAN_QT(Q, T)                                                                                               \
     do {                                                                                                                      \
-        if (simple)                                                                                                           \
-            hipLaunchKernelGGL((rover_scan_step_kernel<Q, T, RV_K2_THREADS>), dim3(grid), dim3(RV_K2_THREADS), sim->lds_bytes, \
-                               st, sim->p, out, row_stride, col0, log_partial, n_waves, log_out, sim->p.scan_desc);           \
+        if (simple && epi == 2) RV_LAUNCH_STEP(Q, T, 2);                                                                      \
+        else if (simple) RV_LAUNCH_STEP(Q, T, 1);                                                                             \
         else                                                                                                                  \
             hipLaunchKernelGGL((rover_scan_obs_kernel<MODE, Q, T>), dim3(grid), dim3(RV_K2_THREADS), sim->lds_bytes, st,       \
                                sim->p, sim->state, out, row_stride, col0, log_partial, n_waves, log_out, sim->p.scan_desc);   \
@@ -2264,6 +2292,7 @@ static void launch_scan(rover_sim *sim, int grid, hipStream_t st, float *out, in
     else if (tri) RV_LAUNCH_SCAN_QT(false, true);
     else RV_LAUNCH_SCAN_QT(false, false);
 #undef RV_LAUNCH_SCAN_QT
+#undef RV_LAUNCH_STEP
 }
 
 extern "C" {
@@ -2606,10 +2635,11 @@ int rover_height_scan(rover_sim *sim, float *scan, void *stream)
     return ROVER_OK;
 }
 
-// measurement hook (tools/n_sweep.py): 0 = automatic choice, 1 = the generic scan kernel on the step path as well
+// measurement hook (tools/n_sweep.py): 0 = automatic choice, 1 = the generic scan kernel on the step path as well, 2 = the
+// step form with one env per iteration
 int rover_debug_set_scan_form(rover_sim *sim, int form)
 {
-    if (!sim || form < 0 || form > 1) return ROVER_ERR_INVALID;
+    if (!sim || form < 0 || form > 2) return ROVER_ERR_INVALID;
     sim->scan_form = form;
     return ROVER_OK;
 }

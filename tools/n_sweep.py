@@ -14,10 +14,10 @@ ter = T.make_procedural_terrain((2048, 2048))
 out = []
 CASES = [(1024, "group"), (4096, "group"), (4096, "lane"), (16384, "group"), (32768, "group"), (32768, "lane"),
          (65536, "group"), (65536, "lane"), (131072, "group"), (131072, "lane")]
-if len(sys.argv) > 1:   # e.g. 1024:group 2048:group:wave  (third field: scan kernel of the step path, auto | generic)
+if len(sys.argv) > 1:   # e.g. 1024:group 2048:group:wave  (third field: scan kernel of the step path, auto | generic | epi1)
     CASES = [tuple(a.split(":")) for a in sys.argv[1:]]
 import ctypes as C
-FORMS = {"auto": 0, "generic": 1}
+FORMS = {"auto": 0, "generic": 1, "epi1": 2}
 for case in CASES:
     n, mapping, form = int(case[0]), case[1], (case[2] if len(case) > 2 else "auto")
     ter.make_spawns(2 * n)
