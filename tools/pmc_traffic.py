@@ -10,7 +10,7 @@ def per_kernel(d):
         rows = list(csv.DictReader(open(f)))
         for r in rows:
             name = r["Kernel_Name"]
-            key = "rover_scan_obs_kernel" if re.search(r"rover_scan_obs_kernel(<2|ILi2)", name) else \
+            key = "rover_scan_obs_kernel" if re.search(r"rover_scan_step_kernel|rover_scan_obs_kernel(<2|ILi2)", name) else \
                   "rover_step_kernel" if "rover_step_kernel" in name else None
             if key:
                 acc[key][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
@@ -32,7 +32,8 @@ res = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT
                "python3 tools/pmc_run.py 4096 20; per-launch means over launches 3..20, N=4096, 1x MI355X. FETCH_SIZE/WRITE_SIZE "
                "are KiB at the L2's memory side (Infinity-Cache hits included). MI355X_MICROARCH.md: on gfx950 FETCH_SIZE "
                "reports 1/2 of the bytes of a wide coalesced (16 B/lane) read stream -> doubled for rover_scan_obs_kernel (its "
-               "tile staging is 16 B/lane global_load_lds); the step kernel's 4-byte gathers are an uncalibrated width -> raw value.",
+               "tile staging is 16 B/lane global_load_lds; the key stands for the step-path scan kernel, rover_scan_step_kernel since "
+               "round 2); the step kernel's 4-byte gathers are an uncalibrated width -> raw value.",
        "round": 2, "_build": sys.argv[5] if len(sys.argv) > 5 else ""}
 for k, corr in (("rover_scan_obs_kernel", 2.0), ("rover_step_kernel", 1.0)):
     f, w = fetch[k]["FETCH_SIZE"], write[k]["WRITE_SIZE"]
