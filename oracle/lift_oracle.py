@@ -117,6 +117,14 @@ def gravity_torque(q7):
     return tau
 
 
+def inverse_dynamics(q7, qd7, qdd7, gravity=9.81):
+    """tau = M(q) qdd + c(q, qd) + g(q): the model's recursive Newton-Euler pass"""
+    q, qd, qdd = _f32(q7), _f32(qd7), _f32(qdd7)
+    tau = np.zeros(7, np.float32)
+    lib().lfo_inverse_dynamics(_p(q), _p(qd), _p(qdd), C.c_float(gravity), _p(tau))
+    return tau
+
+
 def mass_matrix(q7):
     M = np.zeros(49, np.float32)
     lib().lfo_mass_matrix(_p(_f32(q7)), _p(M))

@@ -135,3 +135,70 @@ def test_lift_mdp_ordering_and_resets(lo):
     assert log[8] >= 0 and np.isfinite(log[:8]).all()
     ep = S[:, lo.EP_LEN].view(np.int32)
     assert ep.max() <= 2
+
+
+def _panda_lagrangian(q, params):
+    """Independent float64 restatement of the arm's rigid-body dynamics from the SAME published parameters (modified-DH
+    table, link masses / centres of mass / principal inertias -- data, restated here) by the Lagrangian route: link frames
+    by homogeneous transforms, geometric Jacobians of every centre of mass, M = sum m Jv^T Jv + Jw^T (R I R^T) Jw and the
+    potential energy.  Nothing of lift_model.h's recursive Newton-Euler code is shared."""
+    A, D, alpha, m, Cm, Ii = params
+    T = np.eye(4)
+    Rs, os_, zs = [], [], []
+    for i in range(7):
+        ca, sa, ct, st = np.cos(alpha[i]), np.sin(alpha[i]), np.cos(q[i]), np.sin(q[i])
+        Ti = np.array([[ct, -st, 0.0, A[i]],
+                       [st * ca, ct * ca, -sa, -sa * D[i]],
+                       [st * sa, ct * sa, ca, ca * D[i]],
+                       [0.0, 0.0, 0.0, 1.0]])
+        T = T @ Ti
+        Rs.append(T[:3, :3].copy()); os_.append(T[:3, 3].copy()); zs.append(T[:3, 2].copy())
+    M = np.zeros((7, 7))
+    U = 0.0
+    for i in range(7):
+        c = os_[i] + Rs[i] @ Cm[i]
+        Jv, Jw = np.zeros((3, 7)), np.zeros((3, 7))
+        for j in range(i + 1):
+            Jv[:, j] = np.cross(zs[j], c - os_[j])
+            Jw[:, j] = zs[j]
+        Iw = Rs[i] @ np.diag(Ii[i]) @ Rs[i].T
+        M += m[i] * Jv.T @ Jv + Jw.T @ Iw @ Jw
+        U += m[i] * 9.81 * c[2]
+    return M, U
+
+
+def test_arm_dynamics_match_an_independent_lagrangian_restatement(lo):
+    """lm_rne (recursive Newton-Euler, float32) against a float64 Lagrangian restatement: mass matrix, gravity torque =
+    dU/dq, and the velocity terms c(q, qd) = Mdot qd - 1/2 d(qd^T M qd)/dq, at random configurations."""
+    params = (np.array([0.0, 0.0, 0.0, 0.0825, -0.0825, 0.0, 0.088]), np.array([0.333, 0.0, 0.316, 0.0, 0.384, 0.0, 0.0]),
+              np.array([0.0, -np.pi / 2, np.pi / 2, np.pi / 2, -np.pi / 2, np.pi / 2, np.pi / 2]),
+              np.array([4.97, 0.647, 3.228, 3.588, 1.226, 1.667, 1.495]),
+              np.array([[0.0039, 0.0021, -0.0476], [-0.0031, -0.0287, 0.0035], [0.0275, 0.0392, -0.0665],
+                        [-0.0532, 0.1044, 0.0275], [-0.0118, 0.0411, -0.0384], [0.0601, -0.0141, -0.0105],
+                        [0.0054, -0.0021, 0.1050]]),
+              np.array([[0.70, 0.71, 0.0091], [0.0080, 0.0281, 0.0260], [0.0372, 0.0362, 0.0108], [0.0259, 0.0196, 0.0283],
+                        [0.0355, 0.0295, 0.0086], [0.0020, 0.0043, 0.0054], [0.0260, 0.0240, 0.0060]]))
+    rng = np.random.RandomState(5)
+    lo_q = np.array([-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973])
+    hi_q = np.array([2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973])
+    eps = 1e-5
+    for _ in range(8):
+        q = rng.uniform(lo_q, hi_q)
+        qd = rng.uniform(-1.5, 1.5, 7)
+        M, _ = _panda_lagrangian(q, params)
+        assert np.abs(lo.mass_matrix(q) - M).max() < 2e-5 * max(1.0, np.abs(M).max())
+        # gravity torque = gradient of the potential energy (central differences in float64)
+        g = np.array([(_panda_lagrangian(q + eps * e, params)[1] - _panda_lagrangian(q - eps * e, params)[1]) / (2 * eps)
+                      for e in np.eye(7)])
+        assert np.abs(lo.gravity_torque(q) - g).max() < 2e-4
+        # Coriolis / centrifugal torque from the derivatives of M
+        dM = [(_panda_lagrangian(q + eps * e, params)[0] - _panda_lagrangian(q - eps * e, params)[0]) / (2 * eps)
+              for e in np.eye(7)]
+        Mdot = sum(dM[k] * qd[k] for k in range(7))
+        c = Mdot @ qd - 0.5 * np.array([qd @ dM[k] @ qd for k in range(7)])
+        c_model = lo.inverse_dynamics(q, qd, np.zeros(7), gravity=0.0)
+        assert np.abs(c_model - c).max() < 5e-4, (c_model, c)
+        # and the full inverse dynamics is linear in the acceleration: tau(qdd) - tau(0) = M qdd
+        qdd = rng.uniform(-2, 2, 7)
+        tau = lo.inverse_dynamics(q, qd, qdd) - lo.inverse_dynamics(q, qd, np.zeros(7))
+        assert np.abs(tau - M @ qdd).max() < 2e-4
