@@ -303,6 +303,48 @@ LM_FN void lm_rne(const lm_chain *ch, const float *qd, const float *qdd, float g
         tau[i] = n[2];
     }
 }
+/* joint-space mass matrix, column by column: column j = the inverse dynamics of a unit acceleration of joint j at rest and
+ * without gravity.  That is lm_rne(ch, 0, e_j, 0) with everything that is identically zero left out -- no angular velocity,
+ * so no centripetal / gyroscopic terms; links below j do not move; rows above j follow from symmetry -- about a third of
+ * the arithmetic of seven full passes. */
+LM_FN void lm_mass_matrix(const lm_chain *ch, float Mm[7][7])
+{
+    const float M[7] = LM_LINK_M, C[7][3] = LM_LINK_C, I[7][3] = LM_LINK_I;
+    for (int j = 0; j < 7; ++j) {
+        float F[7][3], N[7][3];
+        float wd[3] = {0.0f, 0.0f, 1.0f}, a[3] = {0.0f, 0.0f, 0.0f};
+        for (int i = j; i < 7; ++i) {
+            float t[3];
+            if (i > j) {
+                float wdn[3], acc[3];
+                lm_cross(wd, ch->p[i], t);
+                for (int k = 0; k < 3; ++k) acc[k] = a[k] + t[k];
+                lm_rt_mul(ch->R[i], acc, a);
+                lm_rt_mul(ch->R[i], wd, wdn);
+                for (int k = 0; k < 3; ++k) wd[k] = wdn[k];
+            }
+            lm_cross(wd, C[i], t);
+            for (int k = 0; k < 3; ++k) { F[i][k] = M[i] * (a[k] + t[k]); N[i][k] = I[i][k] * wd[k]; }
+        }
+        float f[3] = {0.0f, 0.0f, 0.0f}, n[3] = {0.0f, 0.0f, 0.0f};
+        for (int i = 6; i >= j; --i) {
+            float fi[3], ni[3], t[3];
+            if (i < 6) {
+                float rf[3], rn[3];
+                lm_r_mul(ch->R[i + 1], f, rf);
+                lm_r_mul(ch->R[i + 1], n, rn);
+                lm_cross(ch->p[i + 1], rf, t);
+                for (int k = 0; k < 3; ++k) { fi[k] = rf[k] + F[i][k]; ni[k] = N[i][k] + rn[k] + t[k]; }
+            } else {
+                for (int k = 0; k < 3; ++k) { fi[k] = F[i][k]; ni[k] = N[i][k]; }
+            }
+            lm_cross(C[i], F[i], t);
+            for (int k = 0; k < 3; ++k) { ni[k] += t[k]; f[k] = fi[k]; n[k] = ni[k]; }
+            Mm[i][j] = n[2];
+            Mm[j][i] = n[2];
+        }
+    }
+}
 /* in-place Cholesky solve of the SPD system A x = b (lower triangle of A is overwritten) */
 LM_FN void lm_chol_solve7(float A[7][7], float *b)
 {
@@ -371,16 +413,8 @@ LM_FN void lm_arm_substep(float h, const float *target, float *q, float *qd, lm_
     float Mm[7][7], c[7], zero[7] = {0, 0, 0, 0, 0, 0, 0};
     lm_chain_build(q, ch);
     lm_rne(ch, qd, zero, LM_G, c);
-    for (int j = 0; j < 7; ++j) {
-        float e[7] = {0, 0, 0, 0, 0, 0, 0}, col[7];
-        e[j] = 1.0f;
-        lm_rne(ch, zero, e, 0.0f, col);
-        for (int i = 0; i < 7; ++i) Mm[i][j] = col[i];
-    }
-    for (int i = 0; i < 7; ++i) {
-        Mm[i][i] += LM_ARMATURE;
-        for (int j = 0; j < i; ++j) { const float s = 0.5f * (Mm[i][j] + Mm[j][i]); Mm[i][j] = s; Mm[j][i] = s; }
-    }
+    lm_mass_matrix(ch, Mm);
+    for (int i = 0; i < 7; ++i) Mm[i][i] += LM_ARMATURE;
     float A[7][7], b[7], v[7];
     int sat[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int pass = 0; pass < 2; ++pass) {
@@ -416,18 +450,28 @@ LM_FN void lm_arm_substep(float h, const float *target, float *q, float *qd, lm_
 }
 
 /* ---------------------------------------------------------------------------------------------------- cube contact */
+/* Contact rows live in FIXED slots -- 8 cube corners against the table (normal + 2 friction rows each) and 2 finger pads
+ * (normal, 2 friction rows, torsion) -- visited in that order by every Gauss-Seidel sweep and skipped when inactive.  Static
+ * slots keep the solver in registers on the GPU; a dynamically indexed row list lives in scratch memory, and that cost 2/3
+ * of the step kernel's time. */
 typedef struct {
-    float n[3];      /* row direction (world) acting on the cube at r                    */
-    float rxn[3];    /* r x n                                                             */
-    float meff;      /* effective mass of the row                                         */
-    float target;    /* velocity of the other body along n + stabilisation bias           */
-    float lam, lo, hi;
-    int finger;      /* -1: none; 0 / 1: the row also moves that finger along its axis    */
-    int friction_of; /* -1: normal row (lo = 0, hi = inf); else index of the normal row bounding this row */
-    float mu;
-} lm_row;
-
-#define LM_MAX_ROWS 32
+    int active;
+    float r[3];          /* corner relative to the cube centre (world axes)          */
+    float meff[3];       /* rows: normal (z), friction x, friction y                 */
+    float target;        /* normal row: stabilisation / speculative-contact velocity */
+    float lam[3];
+} lm_corner;
+typedef struct {
+    int active;
+    float n[3][3];       /* row directions: normal, pad axis (x), approach axis (z)  */
+    float rxn[4][3];     /* r x n of the three rows; row 3 (torsion) = closing axis  */
+    float meff[4], target[4], lam[4];
+} lm_pad;
+#if defined(__HIPCC__)
+#define LM_UNROLL _Pragma("unroll")
+#else
+#define LM_UNROLL _Pragma("GCC unroll 8")
+#endif
 
 /* one physics substep of cube + fingers.  obj = S + LIFT_OBJ_POS (pos 3, quat 4, lin 3, ang 3 contiguous). */
 LM_FN void lm_cube_substep(const lift_config *cfg, float h, const lm_hand *hand, const float *finger_target, float *fq, float *fqd,
@@ -448,37 +492,26 @@ LM_FN void lm_cube_substep(const lift_config *cfg, float h, const lm_hand *hand,
     lin[2] -= LM_G * h;
     float Rc[3][3];
     lm_quat_to_mat(quat, Rc);
-    lm_row rows[LM_MAX_ROWS];
-    int nr = 0;
-    /* ---- table: the cube's corners against the plane z = 0 */
+    /* ---- table: the cube's corners against the plane z = 0.  With n a unit axis the row's r x n has a closed form:
+     * z: (r1, -r0, 0), x: (0, r2, -r1), y: (-r2, 0, r0) */
+    lm_corner cr[8];
+    LM_UNROLL
     for (int c = 0; c < 8; ++c) {
         const float lc[3] = {(c & 1) ? LM_CUBE_HALF : -LM_CUBE_HALF, (c & 2) ? LM_CUBE_HALF : -LM_CUBE_HALF,
                              (c & 4) ? LM_CUBE_HALF : -LM_CUBE_HALF};
-        float r[3];
-        lm_r_mul(Rc, lc, r);
+        lm_r_mul(Rc, lc, cr[c].r);
+        const float *r = cr[c].r;
         const float z = pos[2] + r[2];
-        if (z < 0.004f && nr + 3 <= LM_MAX_ROWS) {
-            const float dirs[3][3] = {{0.0f, 0.0f, 1.0f}, {1.0f, 0.0f, 0.0f}, {0.0f, 1.0f, 0.0f}};
-            const int base = nr;
-            for (int d = 0; d < 3; ++d) {
-                lm_row *rw = &rows[nr++];
-                for (int k = 0; k < 3; ++k) rw->n[k] = dirs[d][k];
-                lm_cross(r, rw->n, rw->rxn);
-                rw->meff = 1.0f / (inv_m + inv_I * lm_dot(rw->rxn, rw->rxn));
-                rw->lam = 0.0f;
-                rw->finger = -1;
-                rw->friction_of = d == 0 ? -1 : base;
-                rw->mu = cfg->mu_table;
-                if (d == 0) {
-                    const float push = LM_BAUMGARTE * (-z) / h;
-                    rw->target = z < 0.0f ? (push < 1.0f ? push : 1.0f) : -z / h;
-                } else {
-                    rw->target = 0.0f;
-                }
-            }
-        }
+        cr[c].active = z < 0.004f;
+        cr[c].meff[0] = 1.0f / (inv_m + inv_I * (r[1] * r[1] + r[0] * r[0]));
+        cr[c].meff[1] = 1.0f / (inv_m + inv_I * (r[2] * r[2] + r[1] * r[1]));
+        cr[c].meff[2] = 1.0f / (inv_m + inv_I * (r[2] * r[2] + r[0] * r[0]));
+        const float push = LM_BAUMGARTE * (-z) / h;
+        cr[c].target = z < 0.0f ? (push < 1.0f ? push : 1.0f) : -z / h;
+        cr[c].lam[0] = 0.0f; cr[c].lam[1] = 0.0f; cr[c].lam[2] = 0.0f;
     }
     /* ---- finger pads.  Hand frame: x along the pads, y = closing axis, z = approach axis; finger k sits at y = +-fq[k] */
+    lm_pad pd[2];
     {
         float d[3], ch_[3];
         for (int k = 0; k < 3; ++k) d[k] = pos[k] - hand->tcp[k];
@@ -490,70 +523,95 @@ LM_FN void lm_cube_substep(const lift_config *cfg, float h, const lm_hand *hand,
             ey += fabsf(p) * LM_CUBE_HALF;
         }
         const int between = fabsf(ch_[0]) < LM_CUBE_HALF + LM_PAD_X && fabsf(ch_[2]) < LM_CUBE_HALF + LM_PAD_Z;
-        for (int k = 0; k < 2 && between; ++k) {
+        float yh[3], xh[3], zh[3];
+        for (int i = 0; i < 3; ++i) { xh[i] = hand->R[i][0]; yh[i] = hand->R[i][1]; zh[i] = hand->R[i][2]; }
+        /* contact point: on the pad plane, under the cube centre (clamped to the pad) */
+        const float px = lm_clampf(ch_[0], -LM_PAD_X, LM_PAD_X), pz = lm_clampf(ch_[2], -LM_PAD_Z, LM_PAD_Z);
+        LM_UNROLL
+        for (int k = 0; k < 2; ++k) {
             const float sgn = k == 0 ? 1.0f : -1.0f;             /* finger 0 at +y pushes the cube towards -y */
             const float gap = fq[k] - (sgn * ch_[1] + ey);
-            if (gap < 0.002f && nr + 4 <= LM_MAX_ROWS) {
-                float yh[3], xh[3], zh[3], cp[3], r[3], vpad[3], t[3];
-                for (int i = 0; i < 3; ++i) { xh[i] = hand->R[i][0]; yh[i] = hand->R[i][1]; zh[i] = hand->R[i][2]; }
-                /* contact point: on the pad plane, under the cube centre (clamped to the pad) */
-                const float px = lm_clampf(ch_[0], -LM_PAD_X, LM_PAD_X), pz = lm_clampf(ch_[2], -LM_PAD_Z, LM_PAD_Z);
-                for (int i = 0; i < 3; ++i) {
-                    cp[i] = hand->tcp[i] + xh[i] * px + yh[i] * (sgn * fq[k]) + zh[i] * pz;
-                    r[i] = cp[i] - pos[i];
-                    d[i] = cp[i] - hand->tcp[i];
-                }
-                lm_cross(hand->w, d, t);
-                for (int i = 0; i < 3; ++i) vpad[i] = hand->v[i] + t[i];
-                const int base = nr;
-                for (int q = 0; q < 4; ++q) {
-                    lm_row *rw = &rows[nr++];
-                    rw->lam = 0.0f;
-                    rw->mu = cfg->mu_pad;
-                    rw->finger = -1;
-                    if (q == 0) {            /* normal: along -sgn * yh (into the cube) */
-                        for (int i = 0; i < 3; ++i) rw->n[i] = -sgn * yh[i];
-                        lm_cross(r, rw->n, rw->rxn);
-                        rw->finger = k;
-                        rw->meff = 1.0f / (inv_m + inv_I * lm_dot(rw->rxn, rw->rxn) + fm_inv[k]);
-                        rw->friction_of = -1;
-                        const float push = LM_BAUMGARTE * (-gap) / h;
-                        rw->target = lm_dot(vpad, rw->n) + (gap < 0.0f ? (push < 0.5f ? push : 0.5f) : -gap / h);
-                    } else if (q < 3) {      /* friction along the pad (x) and along the approach axis (z) */
-                        const float *dir = q == 1 ? xh : zh;
-                        for (int i = 0; i < 3; ++i) rw->n[i] = dir[i];
-                        lm_cross(r, rw->n, rw->rxn);
-                        rw->meff = 1.0f / (inv_m + inv_I * lm_dot(rw->rxn, rw->rxn));
-                        rw->friction_of = base;
-                        rw->target = lm_dot(vpad, rw->n);
-                    } else {                 /* torsional friction about the closing axis (pure couple) */
-                        for (int i = 0; i < 3; ++i) { rw->n[i] = 0.0f; rw->rxn[i] = yh[i]; }
-                        rw->meff = 1.0f / inv_I;
-                        rw->friction_of = base;
-                        rw->mu = cfg->mu_pad * LM_TORSION_R;
-                        rw->target = lm_dot(hand->w, yh);
-                    }
-                }
+            lm_pad *P = &pd[k];
+            P->active = between && gap < 0.002f;
+            float cp[3], r[3], vpad[3], t[3];
+            for (int i = 0; i < 3; ++i) {
+                cp[i] = hand->tcp[i] + xh[i] * px + yh[i] * (sgn * fq[k]) + zh[i] * pz;
+                r[i] = cp[i] - pos[i];
+                d[i] = cp[i] - hand->tcp[i];
             }
+            lm_cross(hand->w, d, t);
+            for (int i = 0; i < 3; ++i) vpad[i] = hand->v[i] + t[i];
+            for (int i = 0; i < 3; ++i) { P->n[0][i] = -sgn * yh[i]; P->n[1][i] = xh[i]; P->n[2][i] = zh[i]; }
+            for (int q = 0; q < 3; ++q) lm_cross(r, P->n[q], P->rxn[q]);
+            for (int i = 0; i < 3; ++i) P->rxn[3][i] = yh[i];    /* torsional friction about the closing axis (pure couple) */
+            P->meff[0] = 1.0f / (inv_m + inv_I * lm_dot(P->rxn[0], P->rxn[0]) + fm_inv[k]);
+            P->meff[1] = 1.0f / (inv_m + inv_I * lm_dot(P->rxn[1], P->rxn[1]));
+            P->meff[2] = 1.0f / (inv_m + inv_I * lm_dot(P->rxn[2], P->rxn[2]));
+            P->meff[3] = 1.0f / inv_I;
+            const float push = LM_BAUMGARTE * (-gap) / h;
+            P->target[0] = lm_dot(vpad, P->n[0]) + (gap < 0.0f ? (push < 0.5f ? push : 0.5f) : -gap / h);
+            P->target[1] = lm_dot(vpad, P->n[1]);
+            P->target[2] = lm_dot(vpad, P->n[2]);
+            P->target[3] = lm_dot(hand->w, yh);
+            for (int q = 0; q < 4; ++q) P->lam[q] = 0.0f;
         }
     }
-    /* ---- projected Gauss-Seidel on the velocities */
+    /* ---- projected Gauss-Seidel on the velocities: corners 0..7 (normal, x, y), then pads 0, 1 (normal, x, z, torsion) */
     for (int it = 0; it < cfg->solver_iterations; ++it) {
-        for (int i = 0; i < nr; ++i) {
-            lm_row *rw = &rows[i];
-            float u = lm_dot(rw->n, lin) + lm_dot(rw->rxn, ang);
-            if (rw->finger >= 0) u += fv[rw->finger];           /* the finger closes along the row direction */
-            float lam = rw->lam + (rw->target - u) * rw->meff;
-            if (rw->friction_of < 0) {
+        LM_UNROLL
+        for (int c = 0; c < 8; ++c) {
+            if (!cr[c].active) continue;
+            const float r0 = cr[c].r[0], r1 = cr[c].r[1], r2 = cr[c].r[2];
+            {   /* normal */
+                const float u = lin[2] + (r1 * ang[0] - r0 * ang[1]);
+                float lam = cr[c].lam[0] + (cr[c].target - u) * cr[c].meff[0];
                 if (lam < 0.0f) lam = 0.0f;
-            } else {
-                const float lim = rw->mu * rows[rw->friction_of].lam;
-                lam = lm_clampf(lam, -lim, lim);
+                const float dl = lam - cr[c].lam[0];
+                cr[c].lam[0] = lam;
+                lin[2] += dl * inv_m;
+                ang[0] += r1 * dl * inv_I; ang[1] -= r0 * dl * inv_I;
             }
-            const float dl = lam - rw->lam;
-            rw->lam = lam;
-            for (int k = 0; k < 3; ++k) { lin[k] += rw->n[k] * dl * inv_m; ang[k] += rw->rxn[k] * dl * inv_I; }
-            if (rw->finger >= 0) fv[rw->finger] += dl * fm_inv[rw->finger];   /* the reaction opens the finger */
+            const float lim = cfg->mu_table * cr[c].lam[0];
+            {   /* friction along x */
+                const float u = lin[0] + (r2 * ang[1] - r1 * ang[2]);
+                const float lam = lm_clampf(cr[c].lam[1] + (0.0f - u) * cr[c].meff[1], -lim, lim);
+                const float dl = lam - cr[c].lam[1];
+                cr[c].lam[1] = lam;
+                lin[0] += dl * inv_m;
+                ang[1] += r2 * dl * inv_I; ang[2] -= r1 * dl * inv_I;
+            }
+            {   /* friction along y */
+                const float u = lin[1] + (r0 * ang[2] - r2 * ang[0]);
+                const float lam = lm_clampf(cr[c].lam[2] + (0.0f - u) * cr[c].meff[2], -lim, lim);
+                const float dl = lam - cr[c].lam[2];
+                cr[c].lam[2] = lam;
+                lin[1] += dl * inv_m;
+                ang[2] += r0 * dl * inv_I; ang[0] -= r2 * dl * inv_I;
+            }
+        }
+        LM_UNROLL
+        for (int k = 0; k < 2; ++k) {
+            lm_pad *P = &pd[k];
+            if (!P->active) continue;
+            LM_UNROLL
+            for (int q = 0; q < 4; ++q) {
+                float u = lm_dot(P->rxn[q], ang);
+                if (q < 3) u += lm_dot(P->n[q], lin);
+                if (q == 0) u += fv[k];                         /* the finger closes along the row direction */
+                float lam = P->lam[q] + (P->target[q] - u) * P->meff[q];
+                if (q == 0) {
+                    if (lam < 0.0f) lam = 0.0f;
+                } else {
+                    const float lim = (q == 3 ? cfg->mu_pad * LM_TORSION_R : cfg->mu_pad) * P->lam[0];
+                    lam = lm_clampf(lam, -lim, lim);
+                }
+                const float dl = lam - P->lam[q];
+                P->lam[q] = lam;
+                if (q < 3)
+                    for (int i = 0; i < 3; ++i) lin[i] += P->n[q][i] * dl * inv_m;
+                for (int i = 0; i < 3; ++i) ang[i] += P->rxn[q][i] * dl * inv_I;
+                if (q == 0) fv[k] += dl * fm_inv[k];            /* the reaction opens the finger */
+            }
         }
     }
     /* ---- integrate */
@@ -674,10 +732,14 @@ LM_FN void lift_step_one(const lift_config *c, float *S, const float *action, ui
     lm_chain ch;
     lm_hand hand;
     for (int s = 0; s < c->decimation; ++s) {
+#ifndef LM_ABL_NO_ARM   /* ablation builds (tools/build_diag.py) time the halves of a substep; never defined in the product */
         lm_arm_substep(c->sim_dt, target, S + LIFT_Q, S + LIFT_QD, &ch);
+#endif
         lm_chain_build(S + LIFT_Q, &ch);
         lm_hand_fk(&ch, S + LIFT_QD, c->ee_offset_z, &hand);
+#ifndef LM_ABL_NO_CUBE
         lm_cube_substep(c, c->sim_dt, &hand, ftarget, S + LIFT_Q + 7, S + LIFT_QD + 7, S + LIFT_OBJ_POS);
+#endif
     }
     if (c->decimation <= 0) {
         lm_chain_build(S + LIFT_Q, &ch);
