@@ -214,7 +214,11 @@ def main():
                    "baseline_config": args.config,
                    "num_envs_per_gpu": n, "global_num_envs": shard.global_num_envs, "rays": env.num_rays,
                    "decimation": cfg.decimation, "sim_dt": cfg.sim.dt, "solver_iterations": cfg.solver_iterations,
-                   "contact_forces_materialised": cfg.record_contact_forces, "parallelism": f"env-shard x{world}"},
+                   "contact_forces_materialised": cfg.record_contact_forces, "parallelism": f"env-shard x{world}",
+                   "scan_surface": env.cfg.height_scanner.surface, "spawn_draw": env.cfg.spawn_draw,
+                   "parity": "MDP terms / reset / Ackermann / terrain look-ups pinned by reference fixtures; rover dynamics + contact "
+                             "(PhysX in the reference) and the mesh ray-caster (Warp) are documented models, parity unpinned "
+                             "(DESIGN.md section 4)"},
         "roofline": roofline,
     }
 
