@@ -2032,7 +2032,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
         const float inv_tw4 = inv_tab[tw4];
         for (int k0 = 0; k0 < nchunk; k0 += THREADS) {
             const int k = k0 + tid;
+#if defined(RV_K2_NO_COPY)   // timing experiments only (wrong results; tools/build_diag.py NOCOPY / NORAYS / NOCOPYRAYS)
+            if (k < 0) {
+#else
             if (k < nchunk) {
+#endif
                 const int r = (int)(((float)k + 0.5f) * inv_tw4);  // k / tw4, exact for k < 2^20
                 const int cq = k - (int)__umul24(r, tw4);
                 __builtin_amdgcn_global_load_lds(
@@ -2115,7 +2119,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
             auto all_rays = [&](auto fast_tag) {
                 float o[RPT];
 #pragma unroll
+#ifdef RV_K2_NO_RAYS
+                for (int m = 0; m < RPT; ++m) o[m] = px[j] + ox[m];
+#else
                 for (int m = 0; m < RPT; ++m) o[m] = ray_obs(ox[m], oy[m], fast_tag);
+#endif
 #pragma unroll
                 for (int m = 0; m < RPT; ++m) row[ray[m]] = o[m];
             };

@@ -19,6 +19,8 @@ from isaac_rover_orbit_amd import build as b  # noqa: E402
 VARIANTS = {"STAMP": ("rover_kernels.hip", "-DRV_K2_STAMP"), "K1STAMP": ("rover_kernels.hip", "-DRV_K1_STAMP"),
             "K1STAMP_INK": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_K1_CONSTS_IN_KERNEL"),
             "LIFT_NOARM": ("lift_kernels.hip", "-DLM_ABL_NO_ARM"), "LIFT_NOCUBE": ("lift_kernels.hip", "-DLM_ABL_NO_CUBE"),
+            "NOCOPY": ("rover_kernels.hip", "-DRV_K2_NO_COPY"),
+            "NORAYS": ("rover_kernels.hip", "-DRV_K2_NO_RAYS"), "NOCOPYRAYS": ("rover_kernels.hip", "-DRV_K2_NO_RAYS -DRV_K2_NO_COPY"),
             "K1_INK": ("rover_kernels.hip", "-DRV_K1_CONSTS_IN_KERNEL"),
             "NOSLP": ("rover_kernels.hip", "-fno-slp-vectorize"),
             "NOSLP_STAMP": ("rover_kernels.hip", "-fno-slp-vectorize -DRV_K1_STAMP"),
