@@ -1697,11 +1697,11 @@ __global__ __launch_bounds__(64) void rover_reset_kernel(RvParams p, float *__re
 template <bool TRI, typename cell_t>
 __device__ __forceinline__ float patch_height(const cell_t *q, int pitch, float fx, float fy)
 {
-    // volatile: the four cells are read one by one.  hipcc would otherwise merge the two int16 cells of a row into ONE
-    // ds_read_b32 at a 2-byte-aligned address, and those cost more LDS time than the two reads they replace
-    // (scan kernel 22.5 -> 19.5 us at num_envs = 4096 with the merge suppressed)
-    const volatile cell_t *qv = q;
-    const float h00 = (float)qv[0], h01 = (float)qv[1], h10 = (float)qv[pitch], h11 = (float)qv[pitch + 1];
+    // Four separate 16-bit LDS reads for the int16 tile.  With unaligned access enabled hipcc merges the two cells of a row into
+    // ONE ds_read_b32 at a 2-byte-aligned address, which costs more LDS time than the two reads it replaces (scan kernel 22.5
+    // vs 18.6 us at num_envs = 4096): rover_scan_step_kernel is compiled with target("no-unaligned-access-mode").  (A
+    // `volatile` read also prevents the merge, but turns the reads into serialised FLAT loads.)
+    const float h00 = (float)q[0], h01 = (float)q[1], h10 = (float)q[pitch], h11 = (float)q[pitch + 1];
     if (TRI) {
         const bool lower = fx >= fy;                       // lower triangle: corners 00, 01, 11; upper: 00, 10, 11
         const float pm = lower ? h01 : h10;
@@ -1978,7 +1978,7 @@ __device__ __forceinline__ float to_vgpr(float uniform) { float v; asm("v_mov_b3
 __device__ __forceinline__ int to_vgpr(int uniform) { int v; asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(uniform)); return v; }
 
 template <bool Q16, bool TRI, int THREADS, int EPI>   // THREADS x RPT = 1024 rays at most; EPI envs per iteration
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void rover_scan_step_kernel(
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8), target("no-unaligned-access-mode"))) void rover_scan_step_kernel(
     RvParams p, float *__restrict__ out, int row_stride, int col0, const float *__restrict__ log_partial, int n_waves,
     float *__restrict__ log_out, const float *__restrict__ scan_desc)
 {
