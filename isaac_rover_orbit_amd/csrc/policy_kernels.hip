@@ -228,7 +228,10 @@ __global__ __launch_bounds__(POL_THREADS) void rover_policy_kernel(rover_policy_
         const bool last = li == n_layers - 1;
         // where this layer's activations go: the last encoder layer writes behind the proprioceptive columns of the MLP input
         const int col0 = (d.n_enc > 0 && li == d.n_enc - 1) ? d.prop_dim : 0;
-        float *dst = last ? out + (size_t)row0 * N : cur + col0;
+        // two typed destinations instead of one `last ? global : LDS` pointer: a pointer that may be either is a FLAT pointer,
+        // and every epilogue store through it became a flat_store_dword (115 of them in the ISA)
+        float *dst_out = out + (size_t)row0 * N;   // global: the last layer
+        float *dst_act = cur + col0;               // LDS: every other layer
         const int dst_pitch = last ? N : L.act_pitch;
         const float *arow_ptr = in + arow * in_pitch;
 
@@ -269,7 +272,11 @@ __global__ __launch_bounds__(POL_THREADS) void rover_policy_kernel(rover_policy_
 #pragma unroll
                     for (int w = 0; w < POL_WAVES; ++w) q[w] = part[(w * POL_ROWS + r) * ppitch + c];
                     const float sum = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
-                    if (r < rows && col < N) dst[r * dst_pitch + col] = activate(sum + bias[col], lay.act, d.leaky_slope);
+                    if (r < rows && col < N) {
+                        const float v = activate(sum + bias[col], lay.act, d.leaky_slope);
+                        if (last) dst_out[r * dst_pitch + col] = v;
+                        else dst_act[r * dst_pitch + col] = v;
+                    }
                 }
             }
         } else {
@@ -287,15 +294,19 @@ __global__ __launch_bounds__(POL_THREADS) void rover_policy_kernel(rover_policy_
                         bv[i] = bias[min(16 * (t0 + POL_WAVES * i) + arow, N - 1)];
                     }
                     mfma_groups<NT, (NT >= 3 ? 3 : 6)>(acc, arow_ptr, akq, K, Wt, (size_t)POL_WAVES * G * 64, 0, G, G);
-                    float *pd = dst + 4 * akq * dst_pitch + 16 * t0 + arow;
+                    const int pd_off = 4 * akq * dst_pitch + 16 * t0 + arow;
                     auto epi = [&](auto act_tag) {   // one specialised copy per activation: no per-element branching
                         constexpr int ACT = decltype(act_tag)::value;
+                        auto stores = [&](float *pd) {
 #pragma unroll
-                        for (int i = 0; i < NT; ++i)
+                            for (int i = 0; i < NT; ++i)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if (4 * akq + j < rows && 16 * (t0 + POL_WAVES * i) + arow < N)
-                                    pd[j * dst_pitch + 16 * POL_WAVES * i] = activate(acc[i][j] + bv[i], ACT, d.leaky_slope);
+                                for (int j = 0; j < 4; ++j)
+                                    if (4 * akq + j < rows && 16 * (t0 + POL_WAVES * i) + arow < N)
+                                        pd[j * dst_pitch + 16 * POL_WAVES * i] = activate(acc[i][j] + bv[i], ACT, d.leaky_slope);
+                        };
+                        if (last) stores(dst_out + pd_off);
+                        else stores(dst_act + pd_off);
                     };
                     if (lay.act == ROVER_ACT_LEAKY_RELU) epi(std::integral_constant<int, ROVER_ACT_LEAKY_RELU>{});
                     else if (lay.act == ROVER_ACT_TANH) epi(std::integral_constant<int, ROVER_ACT_TANH>{});
