@@ -95,6 +95,10 @@ struct RvParams {
 
 // ------------------------------------------------------------------------------------------------ small helpers
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+// The same clamp as ONE v_med3_f32 (instead of two compares, two selects and their wait states).  Bit-identical to clampf
+// for every finite x when lo < hi and lo is not -0 / hi is not +0 with x the other zero: all uses below have lo < 0 < hi or
+// lo = +0 with x never -0 (x is a difference a - b, which is +0 when a == b).
+__device__ __forceinline__ float clamp_med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 __device__ __forceinline__ float dot3(const float *a, const float *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 __device__ __forceinline__ void cross3(const float *a, const float *b, float *o)
 {
@@ -260,8 +264,8 @@ __device__ __forceinline__ void terrain_sample(const RvParams &p, float x, float
     const float inv_res = p.inv_res;   // = 1.0f / p.res, computed once on the host (same IEEE division)
     float u = (x - p.min_x) * inv_res;
     float v = (y - p.min_y) * inv_res;
-    u = clampf(u, 0.0f, (float)(p.W - 1));
-    v = clampf(v, 0.0f, (float)(p.H - 1));
+    u = clamp_med3(u, 0.0f, (float)(p.W - 1));
+    v = clamp_med3(v, 0.0f, (float)(p.H - 1));
     int j0 = (int)u, i0 = (int)v;
     if (j0 > p.W - 2) j0 = p.W - 2;
     if (i0 > p.H - 2) i0 = p.H - 2;
@@ -424,7 +428,7 @@ __device__ __forceinline__ void steer_joint(const StepConsts &k, float target, f
     const float tau = (v - qd0) * k.steer_i_over_h;
     if (tau > RV_STEER_EFFORT) v = qd0 + k.steer_dv_max;
     if (tau < -RV_STEER_EFFORT) v = qd0 - k.steer_dv_max;
-    v = clampf(v, -RV_STEER_VLIM, RV_STEER_VLIM);
+    v = clamp_med3(v, -RV_STEER_VLIM, RV_STEER_VLIM);
     float x = fmaf(k.h, v, q0);
     if (x > RV_STEER_QLIM) { x = RV_STEER_QLIM; v = 0.0f; }
     if (x < -RV_STEER_QLIM) { x = -RV_STEER_QLIM; v = 0.0f; }
@@ -436,14 +440,14 @@ __device__ __forceinline__ void steer_joint(const StepConsts &k, float target, f
 __device__ __forceinline__ void wheel_motor(const StepConsts &k, float target, float lt, float &q, float &qd)
 {
     const float q0 = q, qd0 = qd;
-    const float tgt = clampf(target, -RV_WHEEL_VLIM, RV_WHEEL_VLIM);
+    const float tgt = clamp_med3(target, -RV_WHEEL_VLIM, RV_WHEEL_VLIM);
     const float tau_ext = -RV_WHEEL_CONTACT_RADIUS * lt * k.inv_h;
     const float drive = fmaf(RV_WHEEL_KD, tgt, tau_ext - RV_WHEEL_KP * q0);
     float v = fmaf(k.h, drive, RV_WHEEL_INERTIA * qd0) * k.wheel_den_inv;
     const float tau = fmaf(RV_WHEEL_KD, tgt - v, RV_WHEEL_KP * (0.0f - fmaf(k.h, v, q0)));
     if (tau > RV_WHEEL_EFFORT) v = fmaf(RV_WHEEL_EFFORT + tau_ext, k.wheel_h_over_i, qd0);
     if (tau < -RV_WHEEL_EFFORT) v = fmaf(-RV_WHEEL_EFFORT + tau_ext, k.wheel_h_over_i, qd0);
-    v = clampf(v, -RV_WHEEL_VLIM, RV_WHEEL_VLIM);
+    v = clamp_med3(v, -RV_WHEEL_VLIM, RV_WHEEL_VLIM);
     float x = fmaf(k.h, v, q0);
     if (x > RV_TWO_PI_F) x -= RV_TWO_PI_F;  // PhysX revolute joints report a wrapped position
     if (x < -RV_TWO_PI_F) x += RV_TWO_PI_F;
@@ -502,7 +506,7 @@ __device__ __forceinline__ void wheel_geometry(const RvParams &p, const StepCons
 #pragma unroll
     for (int i = 0; i < 3; ++i) ct.t[i] = fmaf(-fn, ct.n[i], fwd[i]);
     const float tl = dot3f(ct.t, ct.t);
-    const float tinv = 1.0f / sqrtf(tl > 1.0e-12f ? tl : 1.0e-12f);
+    const float tinv = 1.0f / sqrtf(fmaxf(tl, 1.0e-12f));  // = tl > eps ? tl : eps for finite tl
 #pragma unroll
     for (int i = 0; i < 3; ++i) ct.t[i] *= tinv;
     cross3f(ct.n, ct.t, ct.s);
@@ -522,7 +526,7 @@ __device__ __forceinline__ void wheel_geometry(const RvParams &p, const StepCons
         ct.bias = -gap * k.inv_h;  // speculative contact while separated
     } else {
         const float push = RV_BAUMGARTE * (-gap) * k.inv_h;
-        ct.bias = push < RV_MAX_DEPENETRATION_VEL ? push : RV_MAX_DEPENETRATION_VEL;
+        ct.bias = fminf(push, RV_MAX_DEPENETRATION_VEL);   // = push < cap ? push : cap for finite push, one v_min_f32
     }
     // mass splitting: every contact sees 1/6 of the chassis and 1/2 of its bogie; a_* couple the wheel's own rows
     const float *inv_I = k.inv_I;
