@@ -483,12 +483,40 @@ __device__ __forceinline__ ArmConsts make_arm(const float *wb, const float *P, c
     a.ad = dot3f(ax, a.d0);
     return a;
 }
-// contact geometry, Jacobians, split effective masses and bias of ONE wheel
-template <bool WANT_OBST>
+// One contact row of a wheel: angular Jacobian R^T (r x dir) in the body frame, bogie Jacobian dir . (ax x rp) with the
+// unilateral lock of a bogie that sits on a stop (normal row: only against the stop; friction rows: fully), split effective mass
+struct RowQ {
+    float ja[3], jb, m;
+};
+__device__ __forceinline__ RowQ row_quantities(const StepConsts &k, const float R[3][3], const float *r, const float *axrp,
+                                               const float *dir, bool friction_row, bool at_hi, bool at_lo, float b_winv)
+{
+    RowQ o;
+    float x[3];
+    cross3f(r, dir, x);
+    mat_tvecf(R, x, o.ja);
+    float jb = dot3f(dir, axrp);
+    const bool lock = friction_row ? (at_hi || at_lo) : ((at_hi && jb > 0.0f) || (at_lo && jb < 0.0f));
+    if (lock) jb = 0.0f;
+    o.jb = jb;
+    // mass splitting: every contact sees 1/6 of the chassis and 1/2 of its bogie
+    o.m = 1.0f / (RV_SPLIT_C * k.inv_m + RV_SPLIT_C * wdot3(o.ja, k.inv_I) + RV_SPLIT_B * (jb * jb * b_winv));
+    return o;
+}
+// split-mass coupling between two rows of the same wheel (symmetric in its arguments, bit for bit)
+__device__ __forceinline__ float row_coupling(const StepConsts &k, const RowQ &a, const RowQ &b, float b_winv)
+{
+    return RV_SPLIT_C * wdot3x(a.ja, b.ja, k.inv_I) + RV_SPLIT_B * (a.jb * b.jb * b_winv);
+}
+__device__ __forceinline__ float dpp_ror8(float x);
+// contact geometry, Jacobians, split effective masses and bias of ONE wheel.  GROUP_ROLE: the 16-lanes-per-env mapping, where
+// the two role lanes of a wheel slot share the row work: role A derives the normal row, role B the longitudinal one, both
+// the lateral one, and one row_ror:8 exchange hands each lane the row it did not compute (same arithmetic per quantity).
+template <bool WANT_OBST, bool GROUP_ROLE = false>
 __device__ __forceinline__ void wheel_geometry(const RvParams &p, const StepConsts &k, const float R[3][3], const float *pos,
                                                const float *com_w, const ArmConsts &arm, const float *P, const float *ax,
                                                float b_winv, float bq, bool at_hi, bool at_lo, bool steerable, float steer_q,
-                                               Contact &ct)
+                                               Contact &ct, bool role_b = false)
 {
     const float *d0 = arm.d0, *axd = arm.axd;
     const float ad = arm.ad;
@@ -528,30 +556,44 @@ __device__ __forceinline__ void wheel_geometry(const RvParams &p, const StepCons
     float r[3], rp[3], x[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) { r[i] = cp[i] - com_w[i]; rp[i] = cp[i] - piv_w[i]; }
-    cross3f(r, ct.n, x); mat_tvecf(R, x, ct.jn_a);
-    cross3f(r, ct.t, x); mat_tvecf(R, x, ct.jt_a);
-    cross3f(r, ct.s, x); mat_tvecf(R, x, ct.js_a);
-    cross3f(rp, ct.n, x); ct.jn_b = dot3f(ax_w, x);
-    cross3f(rp, ct.t, x); ct.jt_b = dot3f(ax_w, x);
-    cross3f(rp, ct.s, x); ct.js_b = dot3f(ax_w, x);
-    // unilateral lock of a bogie that sits on its +-10 deg stop
-    if ((at_hi && ct.jn_b > 0.0f) || (at_lo && ct.jn_b < 0.0f)) ct.jn_b = 0.0f;
-    if (at_hi || at_lo) { ct.jt_b = 0.0f; ct.js_b = 0.0f; }
+    cross3f(ax_w, rp, x);   // bogie rows: ax . (rp x d) = d . (ax x rp) -- one cross product shared by the three directions
     if (gap > 0.0f) {
         ct.bias = -gap * k.inv_h;  // speculative contact while separated
     } else {
         const float push = RV_BAUMGARTE * (-gap) * k.inv_h;
         ct.bias = fminf(push, RV_MAX_DEPENETRATION_VEL);   // = push < cap ? push : cap for finite push, one v_min_f32
     }
-    // mass splitting: every contact sees 1/6 of the chassis and 1/2 of its bogie; a_* couple the wheel's own rows
-    const float *inv_I = k.inv_I;
-    const float inv_m = k.inv_m;
-    ct.mn = 1.0f / (RV_SPLIT_C * inv_m + RV_SPLIT_C * wdot3(ct.jn_a, inv_I) + RV_SPLIT_B * (ct.jn_b * ct.jn_b * b_winv));
-    ct.mt = 1.0f / (RV_SPLIT_C * inv_m + RV_SPLIT_C * wdot3(ct.jt_a, inv_I) + RV_SPLIT_B * (ct.jt_b * ct.jt_b * b_winv));
-    ct.ms = 1.0f / (RV_SPLIT_C * inv_m + RV_SPLIT_C * wdot3(ct.js_a, inv_I) + RV_SPLIT_B * (ct.js_b * ct.js_b * b_winv));
-    ct.a_nt = RV_SPLIT_C * wdot3x(ct.jn_a, ct.jt_a, inv_I) + RV_SPLIT_B * (ct.jn_b * ct.jt_b * b_winv);
-    ct.a_ns = RV_SPLIT_C * wdot3x(ct.jn_a, ct.js_a, inv_I) + RV_SPLIT_B * (ct.jn_b * ct.js_b * b_winv);
-    ct.a_ts = RV_SPLIT_C * wdot3x(ct.jt_a, ct.js_a, inv_I) + RV_SPLIT_B * (ct.jt_b * ct.js_b * b_winv);
+    if (!GROUP_ROLE) {
+        const RowQ qn = row_quantities(k, R, r, x, ct.n, false, at_hi, at_lo, b_winv);
+        const RowQ qt = row_quantities(k, R, r, x, ct.t, true, at_hi, at_lo, b_winv);
+        const RowQ qs = row_quantities(k, R, r, x, ct.s, true, at_hi, at_lo, b_winv);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { ct.jn_a[i] = qn.ja[i]; ct.jt_a[i] = qt.ja[i]; ct.js_a[i] = qs.ja[i]; }
+        ct.jn_b = qn.jb; ct.jt_b = qt.jb; ct.js_b = qs.jb;
+        ct.mn = qn.m; ct.mt = qt.m; ct.ms = qs.m;
+        ct.a_nt = row_coupling(k, qn, qt, b_winv);
+        ct.a_ns = row_coupling(k, qn, qs, b_winv);
+        ct.a_ts = row_coupling(k, qt, qs, b_winv);
+    } else {
+        // this lane's row (n for role A, t for role B), the lateral row, and the other role's row by DPP
+        const float dx[3] = {role_b ? ct.t[0] : ct.n[0], role_b ? ct.t[1] : ct.n[1], role_b ? ct.t[2] : ct.n[2]};
+        const RowQ qx = row_quantities(k, R, r, x, dx, role_b, at_hi, at_lo, b_winv);
+        const RowQ qs = row_quantities(k, R, r, x, ct.s, true, at_hi, at_lo, b_winv);
+        const float a_xs = row_coupling(k, qx, qs, b_winv);
+        RowQ qy;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) qy.ja[i] = dpp_ror8(qx.ja[i]);
+        qy.jb = dpp_ror8(qx.jb);
+        qy.m = dpp_ror8(qx.m);
+        const float a_ys = dpp_ror8(a_xs);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { ct.jn_a[i] = role_b ? qy.ja[i] : qx.ja[i]; ct.jt_a[i] = role_b ? qx.ja[i] : qy.ja[i]; ct.js_a[i] = qs.ja[i]; }
+        ct.jn_b = role_b ? qy.jb : qx.jb; ct.jt_b = role_b ? qx.jb : qy.jb; ct.js_b = qs.jb;
+        ct.mn = role_b ? qy.m : qx.m; ct.mt = role_b ? qx.m : qy.m; ct.ms = qs.m;
+        ct.a_nt = row_coupling(k, qx, qy, b_winv);
+        ct.a_ns = role_b ? a_ys : a_xs;
+        ct.a_ts = role_b ? a_xs : a_ys;
+    }
 }
 
 // ---- solver arithmetic (operation for operation the one of oracle/rover_oracle.c, see the comment there) ---------------
@@ -999,7 +1041,7 @@ __device__ __forceinline__ void physics_substep_group(const RvParams &p, const S
     float bd = g.bqd * g.bogie_keep;
     const bool at_hi = bq >= RV_BOGIE_QLIM - 1.0e-5f, at_lo = bq <= -RV_BOGIE_QLIM + 1.0e-5f;
     Contact ct;
-    wheel_geometry<RECORD_FORCE>(p, K, R, g.pos, com_w, g.arm, g.P, g.ax, g.b_winv, bq, at_hi, at_lo, g.steerable, g.sq, ct);
+    wheel_geometry<RECORD_FORCE, true>(p, K, R, g.pos, com_w, g.arm, g.P, g.ax, g.b_winv, bq, at_hi, at_lo, g.steerable, g.sq, ct, g.role_b);
     K1_STAMP(3 + 3 * sidx);
     ct.ln = RV_WARM_START * g.lam;
     ct.lt = 0.0f;
