@@ -203,8 +203,10 @@ __device__ __forceinline__ float u01(uint32_t u) { return (float)(u >> 8) * (1.0
 
 // ------------------------------------------------------------------------------------------------ (a2) Ackermann
 // AckermannAction2.process_actions / ackermann, ackermann_actions.py:226-322 (quirks B-4, B-5 kept)
-__device__ __forceinline__ void ackermann_one(const rover_config &c, const float *raw, float *processed, float *steer,
-                                              float *wheel)
+// rim speeds (before the division by the wheel radius) and steering angles; ackermann_one() below adds the six divisions, the
+// 16-lanes-per-env step kernel divides only the speed of the lane's own wheel
+__device__ __forceinline__ void ackermann_core(const rover_config &c, const float *raw, float *processed, float *steer,
+                                               float *rim /* ML, FL, RL, RR, MR, FR */)
 {
     processed[0] = raw[0] * c.scale_lin + c.offset_lin;
     processed[1] = raw[1] * c.scale_ang + c.offset_ang;
@@ -233,12 +235,19 @@ __device__ __forceinline__ void ackermann_one(const rover_config &c, const float
     const float v_MR = point ? pt : (az ? lin : (r_MR * ang)) * direction;
     const float th = rv_atan2f(wl, r_FL) * turn;
     const float q = RV_PI_F / 4.0f;
-    wheel[0] = v_ML / c.wheel_radius; wheel[1] = v_FL / c.wheel_radius; wheel[2] = v_RL / c.wheel_radius;
-    wheel[3] = v_RR / c.wheel_radius; wheel[4] = v_MR / c.wheel_radius; wheel[5] = v_FR / c.wheel_radius;
+    rim[0] = v_ML; rim[1] = v_FL; rim[2] = v_RL; rim[3] = v_RR; rim[4] = v_MR; rim[5] = v_FR;
     steer[0] = point ? -q : th;  // FL
     steer[1] = point ? q : th;   // RL
     steer[2] = point ? -q : th;  // RR
     steer[3] = point ? q : th;   // FR
+}
+__device__ __forceinline__ void ackermann_one(const rover_config &c, const float *raw, float *processed, float *steer,
+                                              float *wheel)
+{
+    float rim[6];
+    ackermann_core(c, raw, processed, steer, rim);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) wheel[i] = rim[i] / c.wheel_radius;
 }
 
 // ------------------------------------------------------------------------------------------------ terrain look-ups
@@ -1545,17 +1554,17 @@ __global__ __launch_bounds__(RV_K1G_THREADS) void rover_step_kernel_group(RvPara
     for (int i = ROVER_TIME_LEFT; i < ROVER_LAMBDA_N; ++i) S[i] = state[(size_t)i * N + e];
     S[ROVER_RESET_COUNT] = state[(size_t)ROVER_RESET_COUNT * N + e];
     {
-        float processed[2], steer[4], wheel[6];
-        ackermann_one(c, act, processed, steer, wheel);
-        const float steer_m[4] = {steer[0], steer[3], steer[1], steer[2]};                      // FL, FR, RL, RR
-        const float wheel_m[6] = {wheel[1], wheel[5], wheel[0], wheel[4], wheel[2], wheel[3]};  // FL,FR,CL,CR,RL,RR
-        float st = steer_m[0], wt = wheel_m[0];
+        float processed[2], steer[4], rim[6];
+        ackermann_core(c, act, processed, steer, rim);
+        const float steer_m[4] = {steer[0], steer[3], steer[1], steer[2]};              // FL, FR, RL, RR
+        const float rim_m[6] = {rim[1], rim[5], rim[0], rim[4], rim[2], rim[3]};        // FL, FR, CL, CR, RL, RR
+        float st = steer_m[0], rv = rim_m[0];
 #pragma unroll
         for (int i = 1; i < 4; ++i) st = (id.si == i) ? steer_m[i] : st;
 #pragma unroll
-        for (int i = 1; i < 6; ++i) wt = (id.k == i) ? wheel_m[i] : wt;
+        for (int i = 1; i < 6; ++i) rv = (id.k == i) ? rim_m[i] : rv;
         g.steer_t = st;
-        g.wheel_t = wt;
+        g.wheel_t = rv / c.wheel_radius;   // one division per lane instead of six (same quotient)
     }
     // rover_env.py:64-72 decimation loop
     float Fw[3] = {0.0f, 0.0f, 0.0f};
