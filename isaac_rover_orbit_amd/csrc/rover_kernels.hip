@@ -355,9 +355,10 @@ __device__ __forceinline__ float collision_measure(const float *F /* 13 x 3 */)
 }
 
 // rewards.py:14-137, terminations.py:14-64, ORBIT mdp.time_out; rew = unweighted term values
+// no_force: the caller knows that every entry of F is +0 (wave-uniform), so the collision measure is exactly 0
 __device__ __forceinline__ void mdp_terms_one(const rover_config &c, const float *cmd_b, const float *action,
                                               const float *prev_action, int ep_len, const float *F, float *rew,
-                                              bool *term)
+                                              bool *term, bool no_force = false)
 {
     const float L = (float)c.max_episode_length;
     const float d = sqrtf(cmd_b[0] * cmd_b[0] + cmd_b[1] * cmd_b[1]);
@@ -375,7 +376,7 @@ __device__ __forceinline__ void mdp_terms_one(const rover_config &c, const float
     }
     rew[3] = (fabsf(angle) > 2.0f) ? fabsf(angle) / L : 0.0f;
     rew[4] = (action[0] < 0.0f) ? (float)(1.0 / (double)c.max_episode_length) : 0.0f;
-    const bool coll = collision_measure(F) > 1.0f;  // hard-coded 1, `threshold` ignored (B-8)
+    const bool coll = no_force ? false : collision_measure(F) > 1.0f;  // hard-coded 1, `threshold` ignored (B-8)
     rew[5] = coll ? 1.0f : 0.0f;
     rew[6] = (d > c.far_threshold) ? 1.0f : 0.0f;
     term[0] = ep_len >= c.max_episode_length;
@@ -1580,7 +1581,8 @@ __global__ __launch_bounds__(RV_K1G_THREADS) void rover_step_kernel_group(RvPara
     float F[ROVER_NUM_BODIES * 3];
 #pragma unroll
     for (int i = 0; i < ROVER_NUM_BODIES * 3; ++i) F[i] = 0.0f;
-    if (__ballot(Fw[0] != 0.0f || Fw[1] != 0.0f || Fw[2] != 0.0f) != 0ull) {
+    const bool any_force = __ballot(Fw[0] != 0.0f || Fw[1] != 0.0f || Fw[2] != 0.0f) != 0ull;
+    if (any_force) {
         constexpr int BODY_SLOT[6] = {1, 3, 0, 2, 4, 5};  // bodies 7..12 = CL, CR, FL, FR, RL, RR -> solver slot
         const int base = lane & ~15;
 #pragma unroll
@@ -1611,7 +1613,7 @@ __global__ __launch_bounds__(RV_K1G_THREADS) void rover_step_kernel_group(RvPara
     S[ROVER_EP_LEN] = __int_as_float(ep_len);
     float rew[ROVER_NUM_REW];
     bool term[ROVER_NUM_TERM];
-    mdp_terms_one(c, S + ROVER_CMD_B, S + ROVER_ACTION, S + ROVER_PREV_ACTION, ep_len, F, rew, term);
+    mdp_terms_one(c, S + ROVER_CMD_B, S + ROVER_ACTION, S + ROVER_PREV_ACTION, ep_len, F, rew, term, !any_force);
     K1_STAMP(24);
     const bool time_out = term[0];
     const bool term_any = term[1] | term[2] | term[3];
@@ -1678,8 +1680,10 @@ __global__ __launch_bounds__(RV_K1G_THREADS) void rover_step_kernel_group(RvPara
     }
     if (lane < 14) {
         float vsel = 0.0f;
+        if (any_reset) {   // otherwise every lg[] is the +0 it was initialised to
 #pragma unroll
-        for (int i = 0; i < 14; ++i) vsel = (lane == i) ? lg[i] : vsel;
+            for (int i = 0; i < 14; ++i) vsel = (lane == i) ? lg[i] : vsel;
+        }
         log_partial[(size_t)wave * ROVER_LOG_WORDS + lane] = vsel;
     }
     if (writer) {
