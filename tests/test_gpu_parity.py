@@ -348,6 +348,29 @@ def test_config4_dense_scanner_rough_terrain(oracle):
     env.close()
 
 
+@pytest.mark.parametrize("quantize,res,grid_m,n", [(False, 0.2, 4.0, 203), (True, 0.25, 4.0, 77), (False, 0.1, 3.0, 1), (True, 0.1, 0.2, 130)])
+def test_scan_step_kernel_forms(oracle, quantize, res, grid_m, n):
+    """The step-path scan kernel in its less common forms: fp32 tiles too large for two envs per round (one env per round),
+    int16 tiles near the LDS limit, a single env (the second env of the round repeats it), a 3 x 3 pattern (most threads
+    repeat ray 0), odd env counts (the last round has one env) -- closed loop, bit-exact against the oracle."""
+    from isaac_rover_orbit_amd.cfg import RoverEnvCfg
+    from isaac_rover_orbit_amd.envs import RoverEnv
+    ter = small_procedural()
+    ter.make_spawns(2 * max(n, 8))
+    cfg = RoverEnvCfg()
+    cfg.scene.num_envs = n
+    cfg.terrain.kind = "custom"
+    cfg.use_int16_terrain = quantize
+    cfg.height_scanner.resolution, cfg.height_scanner.size = res, (grid_m, grid_m)
+    env = RoverEnv(cfg, terrain=ter)
+    assert env.num_rays <= 1024
+    rng = np.random.RandomState(n)
+    actions = rng.uniform(-1, 1, (10, n, 2)).astype(np.float32)
+    flips = rollout_compare(oracle, env, 10, actions, 0.0, 0.0, resync=False)
+    assert flips == 0
+    env.close()
+
+
 def test_sharding_invariance_gpu(oracle):
     """Two shards with env_id_offset reproduce the corresponding rows of one big env (RNG keyed by global id)."""
     ter = small_procedural()
