@@ -180,6 +180,18 @@ int rover_profile_step(rover_sim *sim, const float *action, float *obs, float *r
  * rover_profile_step carries; bench.py subtracts it.  Synchronises -- measurement only. */
 int rover_profile_event_overhead(rover_sim *sim, void *stream, int32_t reps, float *ms);
 
+/* Tracing (the reference has none on this path -- ORBIT's own timers live upstream): with markers enabled
+ * rover_step pushes one roctx range "rover_step" per call with the ranges "K1 <kernel>" and "K2 scan + observation rows"
+ * around its two launches, so that `rocprofv3 --marker-trace --kernel-trace` output lines up with env steps.  The roctx
+ * library is resolved with dlopen at the first enabling call (ROVER_ERR_UNSUPPORTED when none is installed).  Host only. */
+int rover_set_markers(rover_sim *sim, int32_t enabled);
+
+/* Names of the two kernels rover_step launches for the current configuration / terrain, exactly as rocprofv3's kernel trace
+ * prints them minus the "(anonymous namespace)::" qualifier and the parameter list (e.g. "rover_step_kernel_group",
+ * "rover_scan_step_kernel<true, true, 1024, 2>"): the keys of bench.py's roofline block and of profiles/hbm_traffic.json.
+ * Both buffers hold `cap` bytes.  Host only. */
+int rover_kernel_names(const rover_sim *sim, char *step_kernel, char *scan_kernel, size_t cap);
+
 /* Unit entry points used by the parity tests (same kernels' device functions, one env per lane):
  *   rover_ackermann      -- AckermannAction2.process_actions + ackermann (ackermann_actions.py:226-322)
  *                           steer (n,4) [FL,RL,RR,FR], wheel (n,6) [ML,FL,RL,RR,MR,FR] as the reference stacks them

@@ -33,7 +33,8 @@ def needs_build() -> bool:
     if not os.path.exists(OUTPUT):
         return True
     t = os.path.getmtime(OUTPUT)
-    return any(os.path.getmtime(f) > t for f in SOURCES + HEADERS)
+    # an installed (non-editable) copy may lack include/*.h: a prebuilt library is then used as it is
+    return any(os.path.getmtime(f) > t for f in SOURCES + HEADERS if os.path.exists(f))
 
 
 def build_extension(force: bool = False, verbose: bool = False) -> str:

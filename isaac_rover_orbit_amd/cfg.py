@@ -163,6 +163,7 @@ class RoverEnvCfg:
     step_mapping: str = "auto"              # "auto" | "lane" (one env per lane) | "group" (sixteen lanes per env)
     record_contact_forces: bool = True       # materialise contact_sensor.data.force_matrix_w every step
     use_int16_terrain: bool = True           # stage the exact int16 copy of the heightfield in the scan kernel when it exists
+    roctx_markers: bool = False              # roctx ranges around the two launches of every step (rocprofv3 --marker-trace)
     # multi-GPU sharding: this process simulates global env ids [env_id_offset, env_id_offset + num_envs)
     env_id_offset: int = 0
     global_num_envs: int | None = None

@@ -7,12 +7,14 @@
 //                             integration} -> counters -> terminations -> rewards -> in-lane reset (Philox) ->
 //                             command update; writes the observation head and a 32-byte scan descriptor per env.
 //                             Wave-level butterfly reductions produce the per-wave partials of extras["log"].
-//   K2  rover_scan_obs_kernel PERSISTENT 512-thread workgroups (as many as the chip holds), each walking envs
-//                             b, b + n_wg, ...: the yaw-rotated 3 x 3 m terrain window of the NEXT env is copied
-//                             global -> LDS asynchronously (global_load_lds_dwordx4, dense int16 or fp32 tile, two
-//                             buffers) while the 31 x 31 vertical rays of the current env are evaluated by bilinear
-//                             gather from LDS and written to the 965-float observation row with coalesced stores;
-//                             one extra workgroup reduces the log partials in a fixed order (deterministic).
+//   K2  rover_scan_step_kernel<Q16, TRI, 1024, EPI>  PERSISTENT 1024-thread workgroups (two per CU), each walking PAIRS of
+//                             envs (EPI = 2): the yaw-rotated 3 x 3 m terrain windows of both envs are copied global -> LDS
+//                             asynchronously (global_load_lds_dwordx4, dense int16 or fp32 tiles, ONE buffer per env), one
+//                             wait + barrier, then every thread casts its vertical ray in both envs against the TRIANGLE
+//                             of the heightfield cell it falls in (four LDS corner reads, two fma) and the 965-float
+//                             observation rows are written with coalesced stores; one extra workgroup reduces the log
+//                             partials in a fixed order (deterministic).  rover_scan_obs_kernel<MODE, Q16, TRI> is the
+//                             generic 512-thread form (reset path, unit entries, odd map widths, > 1024 rays).
 // There is no matrix-shaped work on this path (gather / integrate / scatter) => no MFMA; the bound is HBM/latency.
 //
 // Reference behaviour being replaced (file:line in /root/reference): RoverEnv.step entrypoints/rover_env.py:42-102;
@@ -28,6 +30,8 @@
 #include <cstring>
 #include <new>
 #include <type_traits>
+
+#include <dlfcn.h>
 
 #include "../../include/rover_hip.h"
 #include "rover_model.hpp"
@@ -2320,7 +2324,10 @@ struct rover_sim {
     int n_cu;          // compute units of the device
     int scan_wgs;      // persistent scan workgroups: what the device holds at once
     int scan_form;     // measurement hook: 1 = the generic scan kernel on the step path too
+    bool markers;      // roctx ranges around the launches of rover_step (rover_set_markers)
 };
+
+
 
 static void configure_tile(rover_sim *sim, int chunk_cells);
 
@@ -2340,24 +2347,43 @@ static void next_batch(rover_sim *sim)
     ++sim->counter;
 }
 
+// Which scan kernel a launch of mode `mode` (0 unit scan, 1 reset, 2 step) uses: the spill-free step form (`simple`) with
+// one or two envs per synchronisation round, or the generic kernel.  Shared by launch_scan and rover_kernel_names.
+struct ScanForm {
+    bool q16, tri, simple;
+    int epi, grid;
+    size_t step_lds;
+};
+static ScanForm scan_form_of(const rover_sim *sim, int mode)
+{
+    ScanForm f;
+    f.grid = (sim->p.n < sim->scan_wgs ? sim->p.n : sim->scan_wgs) + (mode == 2 ? 1 : 0);
+    f.q16 = sim->p.height_q != nullptr;
+    f.tri = sim->p.cfg.scan_surface == 0;
+    const int cc = f.q16 ? 8 : 4;
+    const uintptr_t base = f.q16 ? reinterpret_cast<uintptr_t>(sim->p.height_q) : reinterpret_cast<uintptr_t>(sim->p.height);
+    f.simple = mode == 2 && (sim->p.W & (cc - 1)) == 0 && (base & 15) == 0 && sim->p.rays <= 1024 && sim->scan_form != 1;
+    const size_t tile_bytes = (size_t)sim->p.tile_dim * sim->p.tile_pitch * (f.q16 ? 2 : 4);
+    // two envs per iteration when two workgroups with two tiles each fit the CU's LDS (measurement hook: form 2 = one env)
+    f.epi = (sim->scan_form != 2 && 2 * (192 * sizeof(float) + 2 * tile_bytes) <= 160 * 1024) ? 2 : 1;
+    f.step_lds = 192 * sizeof(float) + f.epi * tile_bytes < (1024 + 16) * sizeof(float) ? (1024 + 16) * sizeof(float)
+                                                                                         : 192 * sizeof(float) + f.epi * tile_bytes;
+    if (f.simple) {
+        const int groups = (sim->p.n + f.epi - 1) / f.epi, wgs = 2 * sim->n_cu;   // two 1024-thread workgroups per CU (one per CU: 19.7 vs 17.8 us)
+        f.grid = (groups < wgs ? groups : wgs) + 1;
+    }
+    return f;
+}
+
 template <int MODE>
 static void launch_scan(rover_sim *sim, int grid, hipStream_t st, float *out, int row_stride, int col0, const float *log_partial,
                         int n_waves, float *log_out)
 {
-    grid = (sim->p.n < sim->scan_wgs ? sim->p.n : sim->scan_wgs) + (MODE == 2 ? 1 : 0);
-    const bool q16 = sim->p.height_q != nullptr, tri = sim->p.cfg.scan_surface == 0;
-    const int cc = q16 ? 8 : 4;
-    const uintptr_t base = q16 ? reinterpret_cast<uintptr_t>(sim->p.height_q) : reinterpret_cast<uintptr_t>(sim->p.height);
-    const bool simple = MODE == 2 && (sim->p.W & (cc - 1)) == 0 && (base & 15) == 0 && sim->p.rays <= 1024 && sim->scan_form != 1;
-    const size_t tile_bytes = (size_t)sim->p.tile_dim * sim->p.tile_pitch * (q16 ? 2 : 4);
-    // two envs per iteration when two workgroups with two tiles each fit the CU's LDS (measurement hook: form 2 = one env)
-    const int epi = (sim->scan_form != 2 && 2 * (192 * sizeof(float) + 2 * tile_bytes) <= 160 * 1024) ? 2 : 1;
-    const size_t step_lds = 192 * sizeof(float) + epi * tile_bytes < (1024 + 16) * sizeof(float) ? (1024 + 16) * sizeof(float)
-                                                                                                   : 192 * sizeof(float) + epi * tile_bytes;
-    if (simple) {
-        const int groups = (sim->p.n + epi - 1) / epi, wgs = 2 * sim->n_cu;   // two 1024-thread workgroups per CU (one per CU: 19.7 vs 17.8 us)
-        grid = (groups < wgs ? groups : wgs) + 1;
-    }
+    const ScanForm f = scan_form_of(sim, MODE);
+    grid = f.grid;
+    const bool q16 = f.q16, tri = f.tri, simple = f.simple;
+    const int epi = f.epi;
+    const size_t step_lds = f.step_lds;
 #define RV_LAUNCH_STEP(Q, T, E)                                                                                               \
     hipLaunchKernelGGL((rover_scan_step_kernel<Q, T, 1024, E>), dim3(grid), dim3(1024), step_lds, st, sim->p, out, row_stride, \
                        col0, log_partial, n_waves, log_out, sim->p.scan_desc)
@@ -2376,6 +2402,35 @@ static void launch_scan(rover_sim *sim, int grid, hipStream_t st, float *out, in
 #undef RV_LAUNCH_SCAN_QT
 #undef RV_LAUNCH_STEP
 }
+
+// ---- roctx ranges around the two launches of a step (tracing): resolved lazily with dlopen so that the
+// library carries no link-time dependency on a profiler; `rocprofv3 --marker-trace` then shows one "rover_step" range per
+// env step with the "K1 ..." / "K2 ..." ranges inside.  Off unless rover_set_markers(sim, 1) was called.
+typedef int (*roctx_push_fn)(const char *);
+typedef int (*roctx_pop_fn)(void);
+static roctx_push_fn g_roctx_push = nullptr;
+static roctx_pop_fn g_roctx_pop = nullptr;
+static int g_roctx_state = 0;   // 0 = not tried, 1 = resolved, -1 = unavailable
+static bool roctx_resolve()
+{
+    if (g_roctx_state == 0) {
+        g_roctx_state = -1;
+        const char *names[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"};
+        for (const char *nm : names) {
+            void *h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            g_roctx_push = reinterpret_cast<roctx_push_fn>(dlsym(h, "roctxRangePushA"));
+            g_roctx_pop = reinterpret_cast<roctx_pop_fn>(dlsym(h, "roctxRangePop"));
+            if (g_roctx_push && g_roctx_pop) { g_roctx_state = 1; break; }
+        }
+    }
+    return g_roctx_state == 1;
+}
+struct MarkerRange {
+    bool on;
+    MarkerRange(const rover_sim *sim, const char *name) : on(sim->markers && roctx_resolve()) { if (on) g_roctx_push(name); }
+    ~MarkerRange() { if (on) g_roctx_pop(); }
+};
 
 extern "C" {
 
@@ -2464,6 +2519,9 @@ int rover_set_terrain(rover_sim *sim, const float *height, const float *obstacle
     if (!sim) return fail(ROVER_ERR_INVALID, "sim is NULL");
     if (!height || !obstacle || !safe_mask || !spawns) return fail(ROVER_ERR_INVALID, "terrain pointer is NULL");
     if (H < 2 || W < 2 || resolution <= 0.0f || n_spawns < 1) return fail(ROVER_ERR_INVALID, "bad terrain shape");
+    // spawn_draw = 1: row = (a * gid + b) mod n_spawns is a bijection of the global ids only while gid < n_spawns
+    if (sim->p.cfg.spawn_draw == 1 && (int64_t)n_spawns < (int64_t)sim->p.env_id_offset + sim->p.n)
+        return fail(ROVER_ERR_INVALID, "spawn_draw = 1 (distinct rows per reset batch) needs n_spawns >= env_id_offset + num_envs");
     RvParams &p = sim->p;
     p.height = height; p.lookup = height; p.obstacle = obstacle; p.safe_mask = safe_mask; p.spawns = spawns;
     p.H = H; p.W = W; p.n_spawns = n_spawns; p.res = resolution; p.min_x = min_x; p.min_y = min_y;
@@ -2614,14 +2672,45 @@ int rover_step(rover_sim *sim, const float *action, float *obs, float *reward, u
     hipStream_t st = static_cast<hipStream_t>(stream);
     next_batch(sim);
     const RvParams &p = sim->p;
-    if (sim->group_mapping)
-        hipLaunchKernelGGL(rover_step_kernel_group, dim3(sim->step_blocks), dim3(RV_K1G_THREADS), 0, st, p, sim->state, action, obs, reward,
-                           terminated, truncated, force, sim->log_partial);
-    else
-        hipLaunchKernelGGL(rover_step_kernel, dim3(sim->step_blocks), dim3(64), 0, st, p, sim->state, action, obs, reward,
-                           terminated, truncated, force, sim->log_partial);
-    launch_scan<2>(sim, p.n + 1, st, obs, p.obs_w, 4, sim->log_partial, sim->n_waves, log);
+    MarkerRange whole(sim, "rover_step");
+    {
+        MarkerRange k1(sim, sim->group_mapping ? "K1 rover_step_kernel_group" : "K1 rover_step_kernel");
+        if (sim->group_mapping)
+            hipLaunchKernelGGL(rover_step_kernel_group, dim3(sim->step_blocks), dim3(RV_K1G_THREADS), 0, st, p, sim->state, action, obs, reward,
+                               terminated, truncated, force, sim->log_partial);
+        else
+            hipLaunchKernelGGL(rover_step_kernel, dim3(sim->step_blocks), dim3(64), 0, st, p, sim->state, action, obs, reward,
+                               terminated, truncated, force, sim->log_partial);
+    }
+    {
+        MarkerRange k2(sim, "K2 scan + observation rows");
+        launch_scan<2>(sim, p.n + 1, st, obs, p.obs_w, 4, sim->log_partial, sim->n_waves, log);
+    }
     HIP_TRY(hipGetLastError());
+    return ROVER_OK;
+}
+
+int rover_set_markers(rover_sim *sim, int32_t enabled)
+{
+    if (!sim) return fail(ROVER_ERR_INVALID, "sim is NULL");
+    if (enabled && !roctx_resolve()) return fail(ROVER_ERR_UNSUPPORTED, "no roctx library (librocprofiler-sdk-roctx / libroctx64) could be loaded");
+    sim->markers = enabled != 0;
+    return ROVER_OK;
+}
+
+int rover_kernel_names(const rover_sim *sim, char *step_kernel, char *scan_kernel, size_t cap)
+{
+    // The names rocprofv3's kernel trace prints for the two launches of rover_step with the CURRENT configuration and
+    // terrain (without the "(anonymous namespace)::" qualifier and the parameter list): keys of bench.py's roofline block
+    // and of profiles/hbm_traffic.json.
+    if (!sim || !step_kernel || !scan_kernel || cap < 8) return fail(ROVER_ERR_INVALID, "bad argument");
+    if (!sim->have_terrain) return fail(ROVER_ERR_STATE, "rover_set_terrain has not been called");
+    snprintf(step_kernel, cap, "%s", sim->group_mapping ? "rover_step_kernel_group" : "rover_step_kernel");
+    const ScanForm f = scan_form_of(sim, 2);
+    if (f.simple)
+        snprintf(scan_kernel, cap, "rover_scan_step_kernel<%s, %s, 1024, %d>", f.q16 ? "true" : "false", f.tri ? "true" : "false", f.epi);
+    else
+        snprintf(scan_kernel, cap, "rover_scan_obs_kernel<2, %s, %s>", f.q16 ? "true" : "false", f.tri ? "true" : "false");
     return ROVER_OK;
 }
 
@@ -2781,6 +2870,6 @@ int rover_model_constants(float *out, int32_t cap)
 int rover_state_words(void) { return ROVER_STATE_WORDS; }
 size_t rover_config_bytes(void) { return sizeof(rover_config); }
 const char *rover_last_error(void) { return g_err; }
-const char *rover_version(void) { return "isaac_rover_orbit_amd 0.1.0 (gfx950)"; }
+const char *rover_version(void) { return "isaac_rover_orbit_amd 0.3.0 (gfx950)"; }
 
 }  // extern "C"

@@ -52,29 +52,33 @@ __global__ void rasterize_kernel(const int4 *__restrict__ bbox, const float *__r
     }
 }
 
-// one thread per triangle: the height of its PLANE at every grid node its xy-projection covers (first hit of a vertical
-// ray from above = max over the covering triangles).  fp64 barycentric weights in exactly the operation order of
-// terrain.mesh_surface_heights (the host restatement), rounded to fp32 once; float max through integer atomics.
-__global__ void surface_kernel(const double *__restrict__ tri /* n_faces x 9 */, const int4 *__restrict__ nbox, int n_faces,
-                               float *__restrict__ hm, int H, int W, double min_x, double min_y, double res)
+// one WAVE per triangle: the height of its PLANE at every grid node its xy-projection covers (first hit of a vertical
+// ray from above = max over the covering triangles); the 64 lanes walk the triangle's node box in row-major order, so a
+// small triangle costs one trip and a ground plane made of two huge triangles is spread over 64 lanes x coalesced rows
+// instead of one lane walking millions of nodes (round-2 advisor finding).  fp64 barycentric weights in exactly the
+// operation order of terrain.mesh_surface_heights (the host restatement), rounded to fp32 once; float max through integer
+// atomics => independent of the visiting order.
+__global__ __launch_bounds__(256) void surface_kernel(const double *__restrict__ tri /* n_faces x 9 */, const int4 *__restrict__ nbox,
+                                                      int n_faces, float *__restrict__ hm, int H, int W, double min_x, double min_y,
+                                                      double res)
 {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (f >= n_faces) return;
     const double *t = tri + (size_t)f * 9;
     const double ax = t[0], ay = t[1], az = t[2], bx = t[3], by = t[4], bz = t[5], cx = t[6], cy = t[7], cz = t[8];
     const double den = (by - cy) * (ax - cx) + (cx - bx) * (ay - cy);
     if (den == 0.0) return;
     const int4 b = nbox[f];  // min_i, max_i, min_j, max_j (nodes, already clamped to the grid by the host)
-    for (int j = b.z; j <= b.w; ++j) {
-        const double py = min_y + res * (double)j;
-        for (int i = b.x; i <= b.y; ++i) {
-            const double px = min_x + res * (double)i;
-            const double w0 = ((by - cy) * (px - cx) + (cx - bx) * (py - cy)) / den;
-            const double w1 = ((cy - ay) * (px - cx) + (ax - cx) * (py - cy)) / den;
-            const double w2 = 1.0 - w0 - w1;
-            if (w0 >= -1e-9 && w1 >= -1e-9 && w2 >= -1e-9)
-                atomic_max_f32(hm + (size_t)j * W + i, (float)(w0 * az + w1 * bz + w2 * cz));
-        }
+    if (b.y < b.x || b.w < b.z) return;
+    const long long bw = (long long)b.y - b.x + 1, cells = bw * ((long long)b.w - b.z + 1);
+    for (long long c = lane; c < cells; c += 64) {
+        const int j = b.z + (int)(c / bw), i = b.x + (int)(c % bw);
+        const double py = min_y + res * (double)j, px = min_x + res * (double)i;
+        const double w0 = ((by - cy) * (px - cx) + (cx - bx) * (py - cy)) / den;
+        const double w1 = ((cy - ay) * (px - cx) + (ax - cx) * (py - cy)) / den;
+        const double w2 = 1.0 - w0 - w1;
+        if (w0 >= -1e-9 && w1 >= -1e-9 && w2 >= -1e-9)
+            atomic_max_f32(hm + (size_t)j * W + i, (float)(w0 * az + w1 * bz + w2 * cz));
     }
 }
 
@@ -197,7 +201,7 @@ int rover_terrain_surface(const double *tri, const int32_t *node_box, int32_t n_
     const size_t n = (size_t)H * W;
     hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, height, n, -99.0f);
     if (n_faces > 0)
-        hipLaunchKernelGGL(surface_kernel, dim3((n_faces + 127) / 128), dim3(128), 0, st, tri,
+        hipLaunchKernelGGL(surface_kernel, dim3((n_faces + 3) / 4), dim3(256), 0, st, tri,
                            reinterpret_cast<const int4 *>(node_box), n_faces, height, H, W, min_x, min_y, resolution);
     HIP_TRY(hipGetLastError());
     return ROVER_OK;

@@ -239,6 +239,11 @@ class RoverEnv(RLTaskEnv):
         n_global = self.cfg.global_num_envs or self.num_envs
         if terrain.spawn_locations is None:
             terrain.make_spawns(2 * n_global, seed=tc.spawn_seed)   # terrain_utils.py:123-124: n_spawns = 2 * num_envs
+        if self.cfg.spawn_draw == "distinct" and len(terrain.spawn_locations) < n_global:
+            # the affine row bijection (a * gid + b) mod n_spawns only separates envs while gid < n_spawns
+            # (randomizations.py:22 draws a randperm prefix, which needs len(table) >= number of envs as well)
+            raise ValueError(f"spawn_draw='distinct' needs a spawn table with at least global_num_envs = {n_global} rows "
+                             f"(got {len(terrain.spawn_locations)}); use spawn_draw='independent' or a larger table")
         with torch.cuda.device(self.device):
             dev = self.device
             self._height_dev = torch.from_numpy(terrain.height).to(dev)
@@ -303,6 +308,8 @@ class RoverEnv(RLTaskEnv):
         self.action_space = _spaces.Box(-np.inf, np.inf, (n, 2), np.float32)
         self._step_args = None
         self._closed = False
+        if getattr(self.cfg, "roctx_markers", False):
+            self.set_markers(True)
 
     # ------------------------------------------------------------------------------------------------------------
     @property
@@ -363,6 +370,9 @@ class RoverEnv(RLTaskEnv):
         """``_reset_idx`` of the masked envs with the reference's recorded torch draws injected in place of the Philox
         draws (``rover_reset_with_draws``; parity protocol for reset outcomes, tests/golden/reset.npz)."""
         dev, n = self.device, self.num_envs
+        rows = np.asarray(spawn_row)
+        if rows.size and (rows.min() < 0 or rows.max() >= int(self._spawns_dev.shape[0])):
+            raise ValueError(f"spawn_row must index the spawn table (0 <= row < {int(self._spawns_dev.shape[0])})")
         mask_d = None if mask is None else torch.as_tensor(np.ascontiguousarray(mask, dtype=np.uint8), device=dev)
         row_d = torch.as_tensor(np.ascontiguousarray(spawn_row, dtype=np.int32), device=dev)
         yaw_d = torch.as_tensor(np.ascontiguousarray(yaw_u, dtype=np.float32), device=dev)
@@ -426,6 +436,16 @@ class RoverEnv(RLTaskEnv):
         _lib.check(self._lib.rover_profile_event_overhead(self._h, self._stream(), int(reps), C.byref(ms)),
                    "rover_profile_event_overhead")
         return ms.value
+
+    def kernel_names(self) -> tuple[str, str]:
+        """Names of the two kernels ``step()`` launches, as rocprofv3's kernel trace prints them (``rover_kernel_names``)."""
+        a, b = C.create_string_buffer(128), C.create_string_buffer(128)
+        _lib.check(self._lib.rover_kernel_names(self._h, a, b, 128), "rover_kernel_names")
+        return a.value.decode(), b.value.decode()
+
+    def set_markers(self, enabled: bool = True):
+        """roctx ranges around the launches of every ``step()`` (``rocprofv3 --marker-trace``); ``cfg.roctx_markers``."""
+        _lib.check(self._lib.rover_set_markers(self._h, int(bool(enabled))), "rover_set_markers")
 
     def __getattr__(self, name):
         # lazily built pointer caches (kept out of __init__ so that tensors can be swapped in tests)
@@ -507,7 +527,9 @@ class RoverEnv(RLTaskEnv):
         """Everything needed to continue bit-for-bit: state words, the last observation, the episodic log vector."""
         return {"state": self.get_state().cpu(), "obs": self.obs_buf["policy"].detach().cpu().clone(),
                 "log": self._log.detach().cpu().clone(), "num_envs": self.num_envs,
-                "common_step_counter": int(self.common_step_counter), "call_counter": self.call_counter}
+                "common_step_counter": int(self.common_step_counter), "call_counter": self.call_counter,
+                # the Philox key: an env re-seeded with seed() / reset(seed=) must be restored with ITS key
+                "seed_lo": int(self._native_cfg.seed_lo), "seed_hi": int(self._native_cfg.seed_hi)}
 
     def load_state_dict(self, sd: dict):
         """Restore a ``state_dict()`` of an env of the same size and configuration; returns the observation dict."""
@@ -517,7 +539,10 @@ class RoverEnv(RLTaskEnv):
         self._log.copy_(sd["log"].to(self._log.device))
         self._obs[self._cur].copy_(sd["obs"].to(self.device))
         self.common_step_counter = int(sd.get("common_step_counter", 0))
+        if "seed_lo" in sd:
+            self.seed(int(sd["seed_lo"]) | (int(sd["seed_hi"]) << 32))
         _lib.check(self._lib.rover_set_counter(self._h, int(sd.get("call_counter", 0))), "rover_set_counter")
+        self._sync_counter()                                   # the struct mirror follows the handle
         self.obs_buf = self._obs_dicts[self._cur]
         return self.obs_buf
 

@@ -85,6 +85,8 @@ class EpisodeRecorder:
         n = len(b["observations"])
         if n == 0:
             return
+        if n > self.max_rows:
+            raise ValueError(f"an episode of {n} rows does not fit a file of max_rows = {self.max_rows}")
         if self.current_row + n > self.max_rows:
             self._close_file()
             self._new_file()

@@ -537,6 +537,75 @@ def test_checkpoint_resume_is_exact():
     env_a.close(); env_b.close()
 
 
+def test_checkpoint_of_a_reseeded_env_restores_the_key():
+    """seed(s) changes the Philox key; state_dict() carries it, so a FRESH env restored from the checkpoint draws the same
+    resets (advisor finding of round 2: only the call counter used to be saved)."""
+    ter = small_procedural()
+    env_a = make_env(200, ter)
+    env_a.reset(seed=1234567)
+    rng = np.random.RandomState(9)
+    acts = [torch.from_numpy(rng.uniform(-1, 1, (200, 2)).astype(np.float32)).cuda() for _ in range(12)]
+    for a in acts[:4]:
+        env_a.step(a)
+    sd = env_a.state_dict()
+    assert sd["seed_lo"] == 1234567 and sd["call_counter"] == 5
+    env_b = make_env(200, ter)                       # default key (seed 0)
+    env_b.load_state_dict(sd)
+    assert env_b._native_cfg.seed_lo == 1234567 and env_b._native_cfg.counter_lo == 5
+    S = state_np(env_a)
+    S[:, 51] = np.array([749], dtype=np.int32).view(np.float32)        # every env times out in the next step -> 200 resets
+    env_a.set_state(torch.from_numpy(S)); env_b.set_state(torch.from_numpy(S))
+    for a in acts[4:]:
+        oa, ra, ta, ua, _ = env_a.step(a)
+        ob, rb, tb, ub, _ = env_b.step(a)
+        assert torch.equal(oa["policy"], ob["policy"]) and torch.equal(ra, rb)
+    assert torch.equal(env_a.get_state(), env_b.get_state())
+    env_c = make_env(200, ter)                       # control: the default key gives different spawn rows
+    env_c.load_state_dict({k: v for k, v in sd.items() if not k.startswith("seed_")})
+    env_c.set_state(torch.from_numpy(S))
+    env_c.step(acts[4])
+    env_a2 = make_env(200, ter); env_a2.load_state_dict(sd); env_a2.set_state(torch.from_numpy(S)); env_a2.step(acts[4])
+    assert not torch.equal(env_c.get_state()[:, :3], env_a2.get_state()[:, :3])
+    for e in (env_a, env_b, env_c, env_a2):
+        e.close()
+
+
+def test_kernel_names_markers_and_spawn_table_check():
+    """Measurement hygiene: the names bench.py keys its roofline block with are the ones rocprofv3 prints; roctx markers can
+    be switched on (ranges are no-ops without a profiler attached); a spawn table shorter than the env count is rejected
+    for the without-replacement draw."""
+    ter = small_procedural()
+    env = make_env(64, ter)
+    k1, k2 = env.kernel_names()
+    assert k1 == "rover_step_kernel_group" and k2 == "rover_scan_step_kernel<true, true, 1024, 2>"
+    env.set_markers(True)
+    env.reset()
+    o1 = env.step(torch.zeros(64, 2, device="cuda"))[0]["policy"].clone()
+    env.set_markers(False)
+    env.close()
+    from isaac_rover_orbit_amd.cfg import RoverEnvCfg
+    from isaac_rover_orbit_amd.envs import RoverEnv
+    cfg = RoverEnvCfg(); cfg.scene.num_envs = 64; cfg.terrain.kind = "custom"; cfg.step_mapping = "lane"
+    cfg.height_scanner.surface = "bilinear"; cfg.use_int16_terrain = False
+    env = RoverEnv(cfg, terrain=ter)
+    assert env.kernel_names() == ("rover_step_kernel", "rover_scan_step_kernel<false, false, 1024, 2>")
+    env.close()
+    import copy
+    short = copy.copy(ter)
+    short.spawn_locations = ter.spawn_locations[:10].copy()
+    cfg = RoverEnvCfg(); cfg.scene.num_envs = 64; cfg.terrain.kind = "custom"
+    with pytest.raises(ValueError, match="spawn table"):
+        RoverEnv(cfg, terrain=short)
+    cfg.spawn_draw = "independent"
+    env = RoverEnv(cfg, terrain=short)
+    env.reset()
+    with pytest.raises(ValueError, match="spawn_row"):
+        env.reset_with_draws(None, np.full(64, 10, np.int32), np.zeros(64, np.float32),
+                             np.zeros((64, env._native_cfg.max_target_tries), np.float32), np.zeros(64, np.float32))
+    env.close()
+    assert torch.isfinite(o1[:, :4]).all()
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
 def test_random_configurations_match_oracle(oracle, seed):
     """Config fuzz: ray pattern (3 x 3 ... 45 x 37 rays, 0.05-0.25 m spacing: one to three rays per thread, windows from

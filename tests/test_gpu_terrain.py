@@ -116,3 +116,22 @@ def test_argument_errors_are_reported():
     assert lib.rover_terrain_rock_mask(None, 10, 10, 0.3, None, None, None, None) != 0
     assert b"NULL" in lib.rover_last_error()
     assert lib.rover_terrain_scratch_bytes(0, 5) == 0
+
+
+def test_mesh_surface_with_huge_triangles():
+    """A ground plane made of two triangles that cover the whole 1500 x 1300 node grid (one lane used to walk all of its
+    nodes) plus a small pyramid on top: still bit-identical to the host restatement, and fast (a wave per triangle)."""
+    import time
+    from isaac_rover_orbit_amd import terrain as T, terrain_hip as TH
+    X, Y = 75.0, 65.0
+    verts = np.array([[0, 0, 0.1], [X, 0, 0.3], [0, Y, -0.2], [X, Y, 0.0],
+                      [30.0, 30.0, 0.0], [31.0, 30.0, 0.0], [30.5, 31.0, 0.0], [30.5, 30.4, 0.8]], np.float64)
+    faces = np.array([[0, 1, 2], [1, 3, 2], [4, 5, 7], [5, 6, 7], [6, 4, 7]], np.int64)
+    shape = (1301, 1501)
+    ref = T.mesh_surface_heights(verts, faces, shape, 0.0, 0.0)
+    TH.mesh_surface_heights(verts, faces, shape, 0.0, 0.0)          # warm-up (module load)
+    t0 = time.perf_counter()
+    dev = TH.mesh_surface_heights(verts, faces, shape, 0.0, 0.0).cpu().numpy()
+    dt = time.perf_counter() - t0
+    assert np.array_equal(dev, ref) and (ref > -99).all() and ref.max() > 0.7
+    assert dt < 0.5, f"surface kernel took {dt:.3f} s for two grid-sized triangles"

@@ -37,3 +37,27 @@ def test_recorder_layout_and_rollover(tmp_path):
     assert len(ends) >= 1 and ends[0] + 1 == written[0]
     with pytest.raises(ValueError):
         EpisodeRecorder(str(tmp_path / "x.h5"), 1, 1, 1)
+
+
+def test_recorder_rejects_an_episode_longer_than_a_file(tmp_path):
+    from isaac_rover_orbit_amd.trace import EpisodeRecorder
+    rec = EpisodeRecorder(str(tmp_path / "tiny"), 1, 2, 1, max_rows=5, backend="npz")
+    for t in range(6):
+        rec.append_to_buffer(np.zeros((1, 2), np.float32), np.zeros((1, 1), np.float32), np.zeros(1, np.float32), np.array([False]))
+    with pytest.raises(ValueError, match="max_rows"):
+        rec.append_to_buffer(np.zeros((1, 2), np.float32), np.zeros((1, 1), np.float32), np.zeros(1, np.float32), np.array([True]))
+
+
+def test_recorder_hdf5_branch(tmp_path):
+    """The reference's on-disk format proper (hdf_recorder.py:32-51); runs where h5py is installed."""
+    h5py = pytest.importorskip("h5py")
+    from isaac_rover_orbit_amd.trace import EpisodeRecorder, load_trace
+    rec = EpisodeRecorder(str(tmp_path / "run"), 2, 3, 1, max_rows=16, backend="h5")
+    for t in range(10):
+        rec.append_to_buffer(np.full((2, 3), t, np.float32), np.zeros((2, 1), np.float32), np.ones(2, np.float32),
+                             np.array([t % 4 == 3, t == 9]))
+    files = rec.close()
+    assert all(f.endswith(".h5") for f in files)
+    with h5py.File(files[0], "r") as f:
+        assert set(f.keys()) >= {"observations", "actions", "rewards", "terminated"} and f.attrs["number_of_steps"] > 0
+    assert sum(load_trace(f)["number_of_steps"] for f in files) == 20

@@ -4,15 +4,31 @@ TCC_MISS_sum) of tools/pmc_run.py.  Usage: pmc_traffic.py <dir_fetch> <dir_write
 import csv, glob, json, re, sys, collections
 
 
+def short_name(name):
+    """rocprofv3's kernel name without return type, '(anonymous namespace)::' qualifiers and the parameter list:
+    'void (anonymous namespace)::rover_scan_step_kernel<true, true, 1024, 2>((anonymous namespace)::RvParams, ...)' ->
+    'rover_scan_step_kernel<true, true, 1024, 2>' -- the same string rover_kernel_names() returns."""
+    name = name.replace("(anonymous namespace)::", "")
+    name = re.sub(r"^void\s+", "", name)
+    depth, out = 0, []
+    for ch in name:
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            break
+        out.append(ch)
+    return "".join(out).strip()
+
+
 def per_kernel(d):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         rows = list(csv.DictReader(open(f)))
         for r in rows:
-            name = r["Kernel_Name"]
-            key = "rover_scan_obs_kernel" if re.search(r"rover_scan_step_kernel|rover_scan_obs_kernel(<2|ILi2)", name) else \
-                  "rover_step_kernel" if "rover_step_kernel" in name else None
-            if key:
+            key = short_name(r["Kernel_Name"])
+            if key.startswith(("rover_scan_step_kernel", "rover_scan_obs_kernel<2", "rover_step_kernel", "lift_step_kernel")):
                 acc[key][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
     out = {}
     for k, d2 in acc.items():
@@ -31,11 +47,13 @@ fetch, write, tcc = per_kernel(sys.argv[1]), per_kernel(sys.argv[2]), per_kernel
 res = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum (three separate passes) -- "
                "python3 tools/pmc_run.py 4096 20; per-launch means over launches 3..20, N=4096, 1x MI355X. FETCH_SIZE/WRITE_SIZE "
                "are KiB at the L2's memory side (Infinity-Cache hits included). MI355X_MICROARCH.md: on gfx950 FETCH_SIZE "
-               "reports 1/2 of the bytes of a wide coalesced (16 B/lane) read stream -> doubled for rover_scan_obs_kernel (its "
-               "tile staging is 16 B/lane global_load_lds; the key stands for the step-path scan kernel, rover_scan_step_kernel since "
-               "round 2); the step kernel's 4-byte gathers are an uncalibrated width -> raw value.",
-       "round": 2, "_build": sys.argv[5] if len(sys.argv) > 5 else ""}
-for k, corr in (("rover_scan_obs_kernel", 2.0), ("rover_step_kernel", 1.0)):
+               "reports 1/2 of the bytes of a wide coalesced (16 B/lane) read stream -> doubled for the scan kernels (their "
+               "tile staging is 16 B/lane global_load_lds); the step kernels' 4-byte gathers are an uncalibrated width -> raw "
+               "value.  Keys = kernel names exactly as rocprofv3 prints them (minus qualifiers / parameter list) = "
+               "rover_kernel_names().",
+       "round": 3, "_build": sys.argv[5] if len(sys.argv) > 5 else ""}
+for k in sorted(set(fetch) & set(write) & set(tcc)):
+    corr = 2.0 if k.startswith("rover_scan") else 1.0
     f, w = fetch[k]["FETCH_SIZE"], write[k]["WRITE_SIZE"]
     h, m = tcc[k].get("TCC_HIT_sum", 0.0), tcc[k].get("TCC_MISS_sum", 0.0)
     res[k] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "fetch_correction": corr,
