@@ -11,6 +11,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 ter = T.make_procedural_terrain((2048, 2048)); ter.make_spawns(2 * n)
 cfg = RoverEnvCfg(); cfg.scene.num_envs = n; cfg.terrain.kind = "custom"
+cfg.roctx_markers = len(sys.argv) > 3 and sys.argv[3] == "markers"     # rocprofv3 --marker-trace: one range per env step
 env = RoverEnv(cfg, terrain=ter); env.reset()
 g = torch.Generator(device="cuda").manual_seed(0)
 acts = torch.rand(steps, n, 2, device="cuda", generator=g) * 2 - 1
