@@ -28,6 +28,7 @@ EXPORTS = [
     "rover_policy_default_desc", "rover_policy_packed_floats", "rover_policy_pack", "rover_policy_forward",  # rover_policy.h
     "rover_lift_default_config", "rover_lift_config_bytes", "rover_lift_state_words", "rover_lift_create", "rover_lift_destroy",
     "rover_lift_workspace_bytes", "rover_lift_bind", "rover_lift_reset", "rover_lift_step", "rover_lift_terms",   # rover_lift.h
+    "rover_lift_model_constants", "rover_lift_set_seed", "rover_lift_profile_step", "rover_lift_kernel_name",
 ]
 POLICY_MAX_LAYERS = 8
 ACT_NONE, ACT_LEAKY_RELU, ACT_TANH = 0, 1, 2
@@ -52,13 +53,13 @@ class RoverHipError(RuntimeError):
 
 
 LIFT_NUM_REW, LIFT_OBS, LIFT_ACT, LIFT_STATE_WORDS, LIFT_LOG_WORDS = 6, 36, 8, 64, 16
-# lift state word offsets (csrc/lift_model.h)
+# lift state word offsets (include/rover_lift.h)
 LIFT_Q, LIFT_QD, LIFT_OBJ_POS, LIFT_OBJ_QUAT, LIFT_OBJ_LIN, LIFT_OBJ_ANG, LIFT_CMD = 0, 9, 18, 21, 25, 28, 31
 LIFT_TIME_LEFT, LIFT_EP_LEN, LIFT_ACTION, LIFT_PREV_ACTION, LIFT_EP_SUM, LIFT_RESET_COUNT = 38, 39, 40, 48, 56, 62
 
 
 class LiftConfig(C.Structure):
-    """Mirror of ``struct lift_config`` (csrc/lift_model.h)."""
+    """Mirror of ``struct lift_config`` (include/rover_lift.h)."""
     _fields_ = [
         ("sim_dt", C.c_float), ("decimation", C.c_int32), ("max_episode_length", C.c_int32), ("max_episode_length_s", C.c_float),
         ("action_scale", C.c_float), ("finger_open", C.c_float), ("finger_close", C.c_float),
@@ -167,6 +168,11 @@ def load():
     lib.rover_lift_bind.argtypes = [vp, vp, vp, C.c_size_t]
     lib.rover_lift_reset.argtypes = [vp, vp, vp]
     lib.rover_lift_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.rover_lift_model_constants.argtypes = [vp, i32]
+    lib.rover_lift_set_seed.argtypes = [vp, C.c_uint32, C.c_uint32]
+    lib.rover_lift_profile_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.rover_lift_kernel_name.argtypes = [vp, C.c_char_p, C.c_size_t]
+    lib.rover_lift_debug_set_lanes.argtypes = [vp, i32]
     lib.rover_lift_terms.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.rover_last_error.restype = C.c_char_p
     lib.rover_version.restype = C.c_char_p

@@ -12,7 +12,7 @@ import sys
 _PKG = os.path.dirname(os.path.abspath(__file__))
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("rover_kernels.hip", "terrain_kernels.hip", "policy_kernels.hip", "lift_kernels.hip")]
 HEADERS = [os.path.join(_PKG, "csrc", "rover_model.hpp"), os.path.join(_PKG, "csrc", "rover_internal.hpp"),
-           os.path.join(_PKG, "csrc", "lift_model.h"), os.path.join(os.path.dirname(_PKG), "include", "rover_lift.h"),
+           os.path.join(os.path.dirname(_PKG), "include", "rover_lift.h"),
            os.path.join(os.path.dirname(_PKG), "include", "rover_hip.h"),
            os.path.join(os.path.dirname(_PKG), "include", "rover_terrain.h"),
            os.path.join(os.path.dirname(_PKG), "include", "rover_policy.h")]

@@ -5,7 +5,8 @@ Reference: gym id ``FrankaCubeLift-v0`` = ORBIT ``RLTaskEnv`` on ``FrankaCubeLif
 (``rover_envs/envs/manipulation/config/franka/__init__.py:6-14``, ``joint_pos_env_cfg.py:25-82``,
 ``manipulation_env_cfg.py:93-235``, ``mdp/rewards.py``, ``mdp/observations.py``).  ``step()`` is two HIP launches through the
 C ABI of ``include/rover_lift.h``; the model that stands in for PhysX (7-DOF arm dynamics, gripper, cube / table / finger
-contact) is defined in ``csrc/lift_model.h`` -- parity of that layer is unpinned.  No CPU fallback.
+contact) is specified in DESIGN.md section 9 and implemented in ``csrc/lift_kernels.hip`` (eight lanes per env) -- parity of
+that layer is unpinned.  No CPU fallback.
 """
 from __future__ import annotations
 
@@ -158,7 +159,20 @@ class FrankaCubeLiftEnv(RLTaskEnv):
     def object_pos_w(self):
         return self.state[_lib.LIFT_OBJ_POS:_lib.LIFT_OBJ_POS + 3].t()
 
+    def seed(self, seed: int = -1) -> int:
+        """gymnasium / ORBIT ``env.seed``: re-keys the counter-based RNG of every reset that follows (``rover_lift_set_seed``).
+        A negative seed keeps the current key."""
+        seed = int(seed)
+        if seed >= 0:
+            self.cfg.seed = seed
+            lo, hi = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+            self._native_cfg.seed_lo, self._native_cfg.seed_hi = lo, hi
+            _lib.check(self._lib.rover_lift_set_seed(self._h, lo, hi), "rover_lift_set_seed")
+        return int(self.cfg.seed)
+
     def reset(self, seed=None, options=None):
+        if seed is not None:
+            self.seed(seed)
         obs = self._obs[self._cur]
         _lib.check(self._lib.rover_lift_reset(self._h, _ptr(obs), self._stream()), "rover_lift_reset")
         self.obs_buf = {"policy": obs}
@@ -176,6 +190,45 @@ class FrankaCubeLiftEnv(RLTaskEnv):
         self.common_step_counter += 1
         self.obs_buf = {"policy": self._obs[k]}
         return self.obs_buf, self._rew[k], self._term[k].view(torch.bool), self._trunc[k].view(torch.bool), self.extras
+
+    def profile_step(self, action: torch.Tensor):
+        """``step`` with HIP-event timing: returns ``(ms_step_kernel, ms_log_kernel)``, event overhead included.  Syncs."""
+        action = action.to(device=self.device, dtype=torch.float32).contiguous()
+        if action.shape != (self.num_envs, _lib.LIFT_ACT):
+            raise ValueError(f"action must have shape ({self.num_envs}, {_lib.LIFT_ACT}), got {tuple(action.shape)}")
+        self._cur ^= 1
+        k = self._cur
+        a, b = C.c_float(0.0), C.c_float(0.0)
+        _lib.check(self._lib.rover_lift_profile_step(self._h, _ptr(action), _ptr(self._obs[k]), _ptr(self._rew[k]), _ptr(self._term[k]),
+                                                     _ptr(self._trunc[k]), _ptr(self._log), self._stream(), C.byref(a), C.byref(b)),
+                   "rover_lift_profile_step")
+        self.common_step_counter += 1
+        self.obs_buf = {"policy": self._obs[k]}
+        return a.value, b.value
+
+    def kernel_name(self) -> str:
+        """Name of the step kernel as rocprofv3's kernel trace prints it (``rover_lift_kernel_name``)."""
+        buf = C.create_string_buffer(64)
+        _lib.check(self._lib.rover_lift_kernel_name(self._h, buf, 64), "rover_lift_kernel_name")
+        return buf.value.decode()
+
+    # checkpoint / resume: the state words + the RNG key are the whole environment (counter-based Philox)
+    def state_dict(self) -> dict:
+        return {"state": self.get_state().cpu(), "obs": self.obs_buf["policy"].detach().cpu().clone(),
+                "log": self._log.detach().cpu().clone(), "num_envs": self.num_envs,
+                "common_step_counter": int(self.common_step_counter),
+                "seed_lo": int(self._native_cfg.seed_lo), "seed_hi": int(self._native_cfg.seed_hi)}
+
+    def load_state_dict(self, sd: dict):
+        if int(sd["num_envs"]) != self.num_envs or tuple(sd["state"].shape) != (self.num_envs, _lib.LIFT_STATE_WORDS):
+            raise ValueError("checkpoint was taken from an env of a different size")
+        self.set_state(sd["state"])
+        self._log.copy_(sd["log"].to(self.device))
+        self._obs[self._cur].copy_(sd["obs"].to(self.device))
+        self.common_step_counter = int(sd.get("common_step_counter", 0))
+        self.seed(int(sd["seed_lo"]) | (int(sd["seed_hi"]) << 32))
+        self.obs_buf = {"policy": self._obs[self._cur]}
+        return self.obs_buf
 
     def terms(self, obj_pos, ee_pos, root_state, cmd):
         """The reference's own term functions on caller rows (``rover_lift_terms``): lifted, reach, goal, goal_fine, obj_pos_b."""

@@ -1,15 +1,30 @@
 /*
  * lift_oracle.c -- TEST INFRASTRUCTURE.  NOT PART OF THE PRODUCT PATH.
  *
- * CPU checker of the FrankaCubeLift-v0 path.  Two layers:
- *   1. lfo_terms(): an INDEPENDENT plain-C restatement of the term arithmetic the reference owns
- *      (rover_envs/envs/manipulation/mdp/rewards.py:20-67, mdp/observations.py:19-31), pinned by tests/golden/lift_terms.npz
- *      (generated by evaluating the reference's own torch code, tools/gen_golden.py::gen_lift_terms).
- *   2. lfo_step() / lfo_reset(): the reduced arm + cube + gripper MODEL.  The model is defined once, in
- *      isaac_rover_orbit_amd/csrc/lift_model.h (plain C), and compiled here with gcc: the GPU tests compare the HIP build of
- *      that header with this CPU build bit for bit.  There is nothing in the reference to restate for this layer -- it
- *      delegates it to PhysX -- so its parity is UNPINNED; what this layer catches is GPU-side breakage (indexing, spills,
- *      contraction), not modelling errors (those are the plausibility tests' job, tests/test_lift_oracle.py).
+ * Scalar CPU oracle of the FrankaCubeLift-v0 path (BASELINE config 5).  Written on its own: it includes
+ * nothing from isaac_rover_orbit_amd/ and shares no source with the HIP kernel (csrc/lift_kernels.hip maps one env onto
+ * eight lanes; here every env is a plain sequential loop).  What the two have in common is the SPECIFICATION: DESIGN.md
+ * section 9 (model) and the reference files cited below (MDP), including the order of every floating-point operation,
+ * so that the GPU tests can demand bit equality.
+ *
+ * Pinned / unpinned.
+ *   - The term arithmetic the reference owns -- rover_envs/envs/manipulation/mdp/rewards.py:20-67, mdp/observations.py:19-31 --
+ *     is pinned by tests/golden/lift_terms.npz (recorded from the reference's own torch code by tools/gen_golden.py).
+ *   - The managers' ordering and the generic ORBIT terms (manipulation_env_cfg.py:93-235, joint_pos_env_cfg.py:25-82:
+ *     JointPositionAction, BinaryJointPositionAction, joint_pos_rel, joint_vel_rel, generated_commands, last_action,
+ *     action_rate_l2, joint_vel_l2, time_out, base_height, reset_scene_to_default, reset_root_state_uniform,
+ *     UniformPoseCommand) are restated from their documented behaviour (ORBIT is not in /root/reference).
+ *   - The simulator (PhysX in the reference; Franka / cube / table are remote Nucleus assets) is a documented MODEL:
+ *     PARITY UNPINNED.  Plausibility is tested separately (tests/test_lift_oracle.py, incl. a float64 Lagrangian
+ *     re-derivation of the arm dynamics).
+ *
+ * Model in one paragraph (DESIGN.md section 9 has the details).  Arm: 7 revolute joints, modified-DH kinematics of the
+ * Franka Emika Panda, M(q) qdd + c(q, qd) = tau.  EIGHT inverse-dynamics passes of the recursive Newton-Euler algorithm per
+ * substep: pass j < 7 with (qd, qdd, g) = (0, e_j, 0) gives column j of M, pass 7 with (qd, 0, 9.81) gives c.  Implicit PD
+ * actuators: (M + h Kd + h^2 Kp) v+ = M v + h (Kp (q* - q) - c), Cholesky; joints whose PD torque exceeds the effort
+ * limit are re-solved with the limit as a constant torque; velocity / position limits by clamping.  Gripper: two prismatic
+ * fingers with implicit PD.  Cube: 6-DOF body, contacts = 8 corners against the table plane z = 0 (normal + 2 friction
+ * rows) and two finger pads (normal, 2 friction, torsion), projected Gauss-Seidel on velocities, Baumgarte stabilisation.
  */
 #include <math.h>
 #include <stdint.h>
@@ -18,109 +33,827 @@
 #include <omp.h>
 #endif
 
-#include "../isaac_rover_orbit_amd/csrc/lift_model.h"
+/* ------------------------------------------------------------------------------------------------ layout, config */
+enum {
+    W_Q = 0, W_QD = 9, W_OBJ_POS = 18, W_OBJ_QUAT = 21, W_OBJ_LIN = 25, W_OBJ_ANG = 28, W_CMD = 31, W_TIME_LEFT = 38,
+    W_EP_LEN = 39, W_ACTION = 40, W_PREV_ACTION = 48, W_EP_SUM = 56, W_RESET_COUNT = 62, N_WORDS = 64
+};
+enum { N_REW = 6, N_TERM = 2, N_OBS = 36, N_ACT = 8, N_LOG = 16 };
 
-/* ---- layer 1: independent restatement of the reference's term functions ------------------------------------------- */
-static void quat_apply_ref(const float *q, const float *v, float *o)
+typedef struct lfo_config {           /* field-for-field the C ABI's struct lift_config (include/rover_lift.h) */
+    float sim_dt;
+    int32_t decimation;
+    int32_t max_episode_length;
+    float max_episode_length_s;
+    float action_scale;
+    float finger_open, finger_close;
+    float rew_weight[N_REW];
+    float reach_std, goal_std, goal_fine_std, minimal_height;
+    float drop_height;
+    float cmd_lo[3], cmd_hi[3];
+    float cmd_resample_time;
+    float obj_init[3];
+    float obj_range_lo[3], obj_range_hi[3];
+    float ee_offset_z;
+    uint32_t seed_lo, seed_hi;
+    int32_t solver_iterations;
+    float mu_table, mu_pad;
+} lfo_config;
+
+/* ------------------------------------------------------------------------------------------------ model constants */
+#define GRAV 9.81f
+#define CUBE_HALF 0.02f         /* 0.8 x DexCube (joint_pos_env_cfg.py:53-54): 4 cm edge */
+#define CUBE_MASS 0.064f
+#define PAD_HALF_X 0.010f
+#define PAD_HALF_Z 0.009f
+#define FINGER_MASS 0.05f
+#define FINGER_KP 2000.0f       /* FRANKA_PANDA_CFG "panda_hand" actuator */
+#define FINGER_KD 100.0f
+#define FINGER_EFFORT 200.0f
+#define FINGER_VLIM 0.2f
+#define FINGER_TRAVEL 0.04f
+#define ARM_KP 80.0f            /* FRANKA_PANDA_CFG "panda_shoulder" / "panda_forearm" */
+#define ARM_KD 4.0f
+#define ARMATURE 0.02f
+#define BAUMGARTE 0.2f
+#define TORSION_R 0.008f
+#define FLANGE_D 0.107f
+#define TABLE_MARGIN 0.004f
+#define PAD_MARGIN 0.002f
+
+/* modified DH (Craig): link i is reached from link i-1 by Rx(alpha) Tx(a) Rz(theta) Tz(d); alpha in {0, +-pi/2}.
+ * kind: 0 -> alpha = 0, +1 -> alpha = +pi/2, -1 -> alpha = -pi/2 */
+static const int DH_KIND[7] = {0, -1, 1, 1, -1, 1, 1};
+static const float DH_A[7] = {0.0f, 0.0f, 0.0f, 0.0825f, -0.0825f, 0.0f, 0.088f};
+static const float DH_D[7] = {0.333f, 0.0f, 0.316f, 0.0f, 0.384f, 0.0f, 0.0f};
+static const float LINK_MASS[7] = {4.97f, 0.647f, 3.228f, 3.588f, 1.226f, 1.667f, 1.495f};
+static const float LINK_COM[7][3] = {{0.0039f, 0.0021f, -0.0476f}, {-0.0031f, -0.0287f, 0.0035f}, {0.0275f, 0.0392f, -0.0665f},
+                                     {-0.0532f, 0.1044f, 0.0275f}, {-0.0118f, 0.0411f, -0.0384f}, {0.0601f, -0.0141f, -0.0105f},
+                                     {0.0054f, -0.0021f, 0.1050f}};
+static const float LINK_INERTIA[7][3] = {{0.70f, 0.71f, 0.0091f}, {0.0080f, 0.0281f, 0.0260f}, {0.0372f, 0.0362f, 0.0108f},
+                                         {0.0259f, 0.0196f, 0.0283f}, {0.0355f, 0.0295f, 0.0086f}, {0.0020f, 0.0043f, 0.0054f},
+                                         {0.0260f, 0.0240f, 0.0060f}};
+static const float Q_LO[7] = {-2.8973f, -1.7628f, -2.8973f, -3.0718f, -2.8973f, -0.0175f, -2.8973f};
+static const float Q_HI[7] = {2.8973f, 1.7628f, 2.8973f, -0.0698f, 2.8973f, 3.7525f, 2.8973f};
+static const float QD_LIM[7] = {2.175f, 2.175f, 2.175f, 2.175f, 2.61f, 2.61f, 2.61f};
+static const float EFFORT[7] = {87.0f, 87.0f, 87.0f, 87.0f, 12.0f, 12.0f, 12.0f};
+static const float Q_DEFAULT[9] = {0.0f, -0.569f, 0.0f, -2.810f, 0.0f, 3.037f, 0.741f, 0.04f, 0.04f};   /* FRANKA_PANDA_CFG.init_state */
+
+/* origin of link i in link i-1 coordinates: (a, -sin(alpha) d, cos(alpha) d) */
+static void link_offset(int i, float p[3])
 {
-    /* ORBIT utils.math.quat_apply: t = 2 (q_v x v); v + w t + q_v x t */
+    p[0] = DH_A[i];
+    p[1] = DH_KIND[i] == 0 ? 0.0f : (DH_KIND[i] > 0 ? -DH_D[i] : DH_D[i]);
+    p[2] = DH_KIND[i] == 0 ? DH_D[i] : 0.0f;
+}
+
+/* ------------------------------------------------------------------------------------------------ scalar helpers */
+static float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+/* sin and cos together: Cody-Waite reduction by pi/2 in three steps + the Cephes single-precision minimax polynomials */
+static void sincos_poly(float x, float *s_out, float *c_out)
+{
+    const float k = floorf(x * 0.63661977236758134f + 0.5f);
+    float r = x - k * 1.5703125f;
+    r = r - k * 4.837512969970703125e-4f;
+    r = r - k * 7.54978995489188e-8f;
+    const int quadrant = ((int)k) & 3;
+    const float z = r * r;
+    const float ps = r + r * z * (-1.6666654611e-1f + z * (8.3321608736e-3f + z * (-1.9515295891e-4f)));
+    const float pc = 1.0f - 0.5f * z + z * z * (4.166664568298827e-2f + z * (-1.388731625493765e-3f + z * 2.443315711809948e-5f));
+    const float a = (quadrant & 1) ? pc : ps, b = (quadrant & 1) ? ps : pc;
+    *s_out = (quadrant & 2) ? -a : a;
+    *c_out = ((quadrant + 1) & 2) ? -b : b;
+}
+
+/* 1 / sqrt(x), x > 0: exponent-halving first guess + three Newton steps (<= ~2 ulp) */
+static float rsqrt_newton(float x)
+{
+    union { float f; uint32_t u; } v;
+    v.f = x;
+    v.u = 0x5f3759dfu - (v.u >> 1);
+    float y = v.f;
+    const float hx = 0.5f * x;
+    for (int it = 0; it < 3; ++it) {
+        const float t = hx * y;
+        y = y * fmaf(-t, y, 1.5f);
+    }
+    return y;
+}
+
+/* exp and tanh as explicit fp32 sequences (Cephes expf / tanhf) */
+static float exp_poly(float x)
+{
+    if (x > 88.0f) x = 88.0f;
+    if (x < -87.0f) x = -87.0f;
+    const float n = floorf(x * 1.44269504088896341f + 0.5f);
+    float r = x - n * 0.693359375f;
+    r = r - n * -2.12194440e-4f;
+    const float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = p * r + 1.3981999507e-3f;
+    p = p * r + 8.3334519073e-3f;
+    p = p * r + 4.1665795894e-2f;
+    p = p * r + 1.6666665459e-1f;
+    p = p * r + 5.0000001201e-1f;
+    p = p * z + r + 1.0f;
+    union { float f; int32_t i; } scale;
+    scale.i = ((int32_t)n + 127) << 23;
+    return p * scale.f;
+}
+static float tanh_poly(float x)
+{
+    const float a = fabsf(x);
+    float t;
+    if (a < 0.625f) {
+        const float z = a * a;
+        t = ((((-5.70498872745e-3f * z + 2.06390887954e-2f) * z - 5.37397155531e-2f) * z + 1.33314422036e-1f) * z - 3.33332819422e-1f) * z * a + a;
+    } else {
+        t = 1.0f - 2.0f / (exp_poly(2.0f * a) + 1.0f);
+    }
+    return x < 0.0f ? -t : t;
+}
+
+/* a x b with fused second terms */
+static void cross3(const float a[3], const float b[3], float o[3])
+{
+    o[0] = fmaf(a[1], b[2], -(a[2] * b[1]));
+    o[1] = fmaf(a[2], b[0], -(a[0] * b[2]));
+    o[2] = fmaf(a[0], b[1], -(a[1] * b[0]));
+}
+static float dot3(const float a[3], const float b[3]) { return fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0])); }
+
+/* u k1 - v k2 where k1, k2 are MODEL CONSTANTS: a term whose constant is exactly zero is left out (the kernel drops it at
+ * compile time); both zero -> +0 */
+static float diff_of_products_const(float u, float k1, float v, float k2)
+{
+    if (k1 != 0.0f && k2 != 0.0f) return fmaf(u, k1, -(v * k2));
+    if (k1 != 0.0f) return u * k1;
+    if (k2 != 0.0f) return -(v * k2);
+    return 0.0f;
+}
+/* v x k, k a constant vector with possibly zero components */
+static void cross_const(const float v[3], const float k[3], float o[3])
+{
+    o[0] = diff_of_products_const(v[1], k[2], v[2], k[1]);
+    o[1] = diff_of_products_const(v[2], k[0], v[0], k[2]);
+    o[2] = diff_of_products_const(v[0], k[1], v[1], k[0]);
+}
+/* k x v */
+static void const_cross(const float k[3], const float v[3], float o[3])
+{
+    o[0] = diff_of_products_const(v[2], k[1], v[1], k[2]);
+    o[1] = diff_of_products_const(v[0], k[2], v[2], k[0]);
+    o[2] = diff_of_products_const(v[1], k[0], v[0], k[1]);
+}
+
+/* Rotation of link i relative to link i-1, R = Rx(alpha) Rz(theta), written out for the three values of alpha:
+ *   alpha = 0      [[c, -s, 0], [ s,  c,  0], [ 0,  0, 1]]
+ *   alpha = +pi/2  [[c, -s, 0], [ 0,  0, -1], [ s,  c, 0]]
+ *   alpha = -pi/2  [[c, -s, 0], [ 0,  0,  1], [-s, -c, 0]]
+ * to_child(): R^T v (parent -> link coordinates); to_parent(): R v. */
+static void to_child(int kind, float s, float c, const float v[3], float o[3])
+{
+    if (kind == 0) {
+        o[0] = fmaf(c, v[0], s * v[1]);
+        o[1] = fmaf(c, v[1], -(s * v[0]));
+        o[2] = v[2];
+    } else if (kind > 0) {
+        o[0] = fmaf(c, v[0], s * v[2]);
+        o[1] = fmaf(c, v[2], -(s * v[0]));
+        o[2] = -v[1];
+    } else {
+        o[0] = fmaf(c, v[0], -(s * v[2]));
+        o[1] = -fmaf(c, v[2], s * v[0]);
+        o[2] = v[1];
+    }
+}
+static void to_parent(int kind, float s, float c, const float v[3], float o[3])
+{
+    const float x = fmaf(c, v[0], -(s * v[1])), y = fmaf(s, v[0], c * v[1]);
+    o[0] = x;
+    if (kind == 0) { o[1] = y; o[2] = v[2]; }
+    else if (kind > 0) { o[1] = -v[2]; o[2] = y; }
+    else { o[1] = v[2]; o[2] = -y; }
+}
+
+/* ------------------------------------------------------------------------------------------------ arm dynamics */
+/* One inverse-dynamics pass of the recursive Newton-Euler algorithm: tau = M(q) qdd + c(q, qd) + g(q) for the base at
+ * rest with the acceleration (0, 0, gravity) (i.e. gravity pulling along -z).  sn / cs = sin / cos of the joint angles. */
+static void newton_euler(const float sn[7], const float cs[7], const float qd[7], const float qdd[7], float gravity, float tau[7])
+{
+    float F[7][3], N[7][3];
+    float w_par[3] = {0.0f, 0.0f, 0.0f}, wd_par[3] = {0.0f, 0.0f, 0.0f}, a_par[3] = {0.0f, 0.0f, gravity};
+    for (int i = 0; i < 7; ++i) {                      /* outward: velocities and accelerations, link by link */
+        float p[3], rw[3], rwd[3], w[3], wd[3], t1[3], t2[3], t3[3], acc[3], a[3];
+        link_offset(i, p);
+        to_child(DH_KIND[i], sn[i], cs[i], w_par, rw);
+        w[0] = rw[0]; w[1] = rw[1]; w[2] = rw[2] + qd[i];
+        to_child(DH_KIND[i], sn[i], cs[i], wd_par, rwd);
+        wd[0] = fmaf(rw[1], qd[i], rwd[0]);            /* rw x (qd z) = (rw.y qd, -rw.x qd, 0) */
+        wd[1] = fmaf(-rw[0], qd[i], rwd[1]);
+        wd[2] = rwd[2] + qdd[i];
+        cross_const(wd_par, p, t1);
+        cross_const(w_par, p, t2);
+        cross3(w_par, t2, t3);
+        for (int k = 0; k < 3; ++k) acc[k] = (a_par[k] + t1[k]) + t3[k];
+        to_child(DH_KIND[i], sn[i], cs[i], acc, a);
+        cross_const(wd, LINK_COM[i], t1);              /* acceleration of the centre of mass */
+        cross_const(w, LINK_COM[i], t2);
+        cross3(w, t2, t3);
+        for (int k = 0; k < 3; ++k) F[i][k] = LINK_MASS[i] * ((a[k] + t1[k]) + t3[k]);
+        const float Iw[3] = {LINK_INERTIA[i][0] * w[0], LINK_INERTIA[i][1] * w[1], LINK_INERTIA[i][2] * w[2]};
+        cross3(w, Iw, t1);
+        for (int k = 0; k < 3; ++k) N[i][k] = fmaf(LINK_INERTIA[i][k], wd[k], t1[k]);
+        for (int k = 0; k < 3; ++k) { w_par[k] = w[k]; wd_par[k] = wd[k]; a_par[k] = a[k]; }
+    }
+    float f[3] = {0.0f, 0.0f, 0.0f}, n[3] = {0.0f, 0.0f, 0.0f};
+    for (int i = 6; i >= 0; --i) {                     /* inward: forces and moments */
+        float fi[3], ni[3], t[3];
+        if (i < 6) {
+            float rf[3], rn[3], p[3];
+            link_offset(i + 1, p);
+            to_parent(DH_KIND[i + 1], sn[i + 1], cs[i + 1], f, rf);
+            to_parent(DH_KIND[i + 1], sn[i + 1], cs[i + 1], n, rn);
+            const_cross(p, rf, t);
+            for (int k = 0; k < 3; ++k) { fi[k] = rf[k] + F[i][k]; ni[k] = (N[i][k] + rn[k]) + t[k]; }
+        } else {
+            for (int k = 0; k < 3; ++k) { fi[k] = F[i][k]; ni[k] = N[i][k]; }
+        }
+        const_cross(LINK_COM[i], F[i], t);
+        for (int k = 0; k < 3; ++k) { n[k] = ni[k] + t[k]; f[k] = fi[k]; }
+        tau[i] = n[2];
+    }
+}
+
+/* the eight passes of a substep: cols[j][i] = tau_i of pass j (column j of the mass matrix), bias[i] = c_i + g_i */
+static void arm_passes(const float sn[7], const float cs[7], const float qd[7], float cols[7][7], float bias[7])
+{
+    const float zero[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (int j = 0; j < 7; ++j) {
+        float unit[7];
+        for (int i = 0; i < 7; ++i) unit[i] = i == j ? 1.0f : 0.0f;
+        newton_euler(sn, cs, zero, unit, 0.0f, cols[j]);
+    }
+    newton_euler(sn, cs, qd, zero, GRAV, bias);
+}
+
+/* Cholesky solve of the SPD system A x = b, lower triangle of A given; the diagonal is inverted with rsqrt_newton */
+static void cholesky_solve7(float A[7][7], const float b[7], float x[7])
+{
+    float L[7][7], dinv[7], y[7];
+    for (int j = 0; j < 7; ++j) {
+        float d2 = A[j][j];
+        for (int k = 0; k < j; ++k) d2 = fmaf(-L[j][k], L[j][k], d2);
+        d2 = d2 > 1.0e-9f ? d2 : 1.0e-9f;
+        dinv[j] = rsqrt_newton(d2);
+        for (int i = j + 1; i < 7; ++i) {
+            float s = A[i][j];
+            for (int k = 0; k < j; ++k) s = fmaf(-L[i][k], L[j][k], s);
+            L[i][j] = s * dinv[j];
+        }
+    }
+    for (int i = 0; i < 7; ++i) {
+        float s = b[i];
+        for (int k = 0; k < i; ++k) s = fmaf(-L[i][k], y[k], s);
+        y[i] = s * dinv[i];
+    }
+    for (int i = 6; i >= 0; --i) {
+        float s = y[i];
+        for (int k = i + 1; k < 7; ++k) s = fmaf(-L[k][i], x[k], s);
+        x[i] = s * dinv[i];
+    }
+}
+
+/* one physics substep of the arm */
+static void arm_substep(float h, const float target[7], float q[7], float qd[7])
+{
+    float sn[7], cs[7], cols[7][7], bias[7], Mv[7];
+    for (int i = 0; i < 7; ++i) sincos_poly(q[i], &sn[i], &cs[i]);
+    arm_passes(sn, cs, qd, cols, bias);
+    /* M[i][j] (i >= j) = cols[j][i]; M qd with the symmetric completion, summed j = 0..6 */
+    for (int i = 0; i < 7; ++i) {
+        float acc = 0.0f;
+        for (int j = 0; j < 7; ++j) {
+            const float m = i >= j ? cols[j][i] : cols[i][j];
+            acc = j == 0 ? m * qd[0] : fmaf(m, qd[j], acc);
+        }
+        Mv[i] = acc;
+    }
+    const float imp = h * ARM_KD + (h * h) * ARM_KP;
+    int sat[7] = {0, 0, 0, 0, 0, 0, 0};
+    float v[7];
+    for (int pass = 0; pass < 2; ++pass) {
+        float A[7][7], b[7];
+        for (int i = 0; i < 7; ++i) {
+            for (int j = 0; j <= i; ++j) A[i][j] = cols[j][i];
+            A[i][i] = A[i][i] + ARMATURE;
+            if (sat[i] == 0) {
+                A[i][i] = A[i][i] + imp;
+                b[i] = fmaf(h, fmaf(ARM_KP, target[i] - q[i], -bias[i]), Mv[i]);
+            } else {
+                b[i] = fmaf(h, (sat[i] > 0 ? EFFORT[i] : -EFFORT[i]) - bias[i], Mv[i]);
+            }
+        }
+        cholesky_solve7(A, b, v);
+        if (pass == 1) break;
+        int any = 0;
+        for (int i = 0; i < 7; ++i) {
+            const float tq = fmaf(ARM_KP, target[i] - fmaf(h, v[i], q[i]), -(ARM_KD * v[i]));
+            if (tq > EFFORT[i]) { sat[i] = 1; any = 1; }
+            if (tq < -EFFORT[i]) { sat[i] = -1; any = 1; }
+        }
+        if (!any) break;
+    }
+    for (int i = 0; i < 7; ++i) {
+        float vi = clampf(v[i], -QD_LIM[i], QD_LIM[i]);
+        float x = fmaf(h, vi, q[i]);
+        if (x > Q_HI[i]) { x = Q_HI[i]; vi = 0.0f; }
+        if (x < Q_LO[i]) { x = Q_LO[i]; vi = 0.0f; }
+        q[i] = x;
+        qd[i] = vi;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ hand kinematics */
+typedef struct {
+    float R[3][3];      /* hand frame -> world (x along the pads, y closing axis, z approach axis) */
+    float tcp[3];       /* tool centre point, world */
+    float v[3], w[3];   /* linear velocity of the tool centre point, angular velocity of the hand */
+} hand_pose_t;
+
+static void hand_kinematics(const float q[7], const float qd[7], float ee_offset_z, hand_pose_t *H)
+{
+    float X[3] = {1.0f, 0.0f, 0.0f}, Y[3] = {0.0f, 1.0f, 0.0f}, Z[3] = {0.0f, 0.0f, 1.0f};   /* columns of the link frame */
+    float pos[3] = {0.0f, 0.0f, 0.0f}, vel[3] = {0.0f, 0.0f, 0.0f}, om[3] = {0.0f, 0.0f, 0.0f};
+    for (int i = 0; i < 7; ++i) {
+        float sn, cs, p[3], pw[3], t[3];
+        sincos_poly(q[i], &sn, &cs);
+        link_offset(i, p);
+        for (int k = 0; k < 3; ++k) {                /* pw = X p0 + Y p1 + Z p2 without the zero-constant terms */
+            float acc = 0.0f;
+            int have = 0;
+            if (p[0] != 0.0f) { acc = X[k] * p[0]; have = 1; }
+            if (p[1] != 0.0f) { acc = have ? fmaf(Y[k], p[1], acc) : Y[k] * p[1]; have = 1; }
+            if (p[2] != 0.0f) { acc = have ? fmaf(Z[k], p[2], acc) : Z[k] * p[2]; have = 1; }
+            pw[k] = acc;
+        }
+        cross3(om, pw, t);
+        for (int k = 0; k < 3; ++k) { pos[k] = pos[k] + pw[k]; vel[k] = vel[k] + t[k]; }
+        /* frame of link i: X' = c X + s U, Y' = c U - s X, with U / Z' picked by alpha */
+        for (int k = 0; k < 3; ++k) {
+            const float U = DH_KIND[i] == 0 ? Y[k] : (DH_KIND[i] > 0 ? Z[k] : -Z[k]);
+            const float Zn = DH_KIND[i] == 0 ? Z[k] : (DH_KIND[i] > 0 ? -Y[k] : Y[k]);
+            const float Xn = fmaf(cs, X[k], sn * U);
+            const float Yn = fmaf(cs, U, -(sn * X[k]));
+            X[k] = Xn; Y[k] = Yn; Z[k] = Zn;
+        }
+        for (int k = 0; k < 3; ++k) om[k] = fmaf(Z[k], qd[i], om[k]);          /* joint axis = local z */
+    }
+    const float r2 = 0.70710678118654752f;           /* hand frame: flange frame turned by -45 deg about z */
+    const float reach = FLANGE_D + ee_offset_z;
+    float rel[3], t[3];
+    for (int k = 0; k < 3; ++k) {
+        H->R[k][0] = (X[k] - Y[k]) * r2;
+        H->R[k][1] = (X[k] + Y[k]) * r2;
+        H->R[k][2] = Z[k];
+        rel[k] = Z[k] * reach;
+        H->tcp[k] = pos[k] + rel[k];
+        H->w[k] = om[k];
+    }
+    cross3(om, rel, t);
+    for (int k = 0; k < 3; ++k) H->v[k] = vel[k] + t[k];
+}
+
+/* ------------------------------------------------------------------------------------------------ cube + gripper */
+typedef struct { int active; float r[3], meff[3], target, lam[3]; } corner_row_t;
+typedef struct { int active; float n[3][3], rxn[4][3], meff[4], target[4], lam[4]; } pad_row_t;
+
+static void cube_substep(const lfo_config *cfg, float h, const hand_pose_t *H, const float finger_target[2], float fq[2], float fqd[2],
+                         float pos[3], float quat[4], float lin[3], float ang[3])
+{
+    const float inv_m = 1.0f / CUBE_MASS;
+    const float inv_I = 1.0f / (CUBE_MASS * (2.0f * CUBE_HALF) * (2.0f * CUBE_HALF) / 6.0f);
+    const float inv_h = 1.0f / h;
+    /* fingers: implicit PD folded into an effective mass and a free velocity */
+    const float f_minv = 1.0f / (FINGER_MASS + h * FINGER_KD + (h * h) * FINGER_KP);
+    float fv[2];
+    for (int k = 0; k < 2; ++k) {
+        const float force = clampf(FINGER_KP * (finger_target[k] - fq[k]), -FINGER_EFFORT, FINGER_EFFORT);
+        fv[k] = fmaf(h, force, FINGER_MASS * fqd[k]) * f_minv;
+    }
+    lin[2] = fmaf(-GRAV, h, lin[2]);
+    /* rotation matrix of the cube */
+    float Rc[3][3];
+    {
+        const float w = quat[0], x = quat[1], y = quat[2], z = quat[3];
+        Rc[0][0] = 1.0f - 2.0f * (y * y + z * z); Rc[0][1] = 2.0f * (x * y - w * z); Rc[0][2] = 2.0f * (x * z + w * y);
+        Rc[1][0] = 2.0f * (x * y + w * z); Rc[1][1] = 1.0f - 2.0f * (x * x + z * z); Rc[1][2] = 2.0f * (y * z - w * x);
+        Rc[2][0] = 2.0f * (x * z - w * y); Rc[2][1] = 2.0f * (y * z + w * x); Rc[2][2] = 1.0f - 2.0f * (x * x + y * y);
+    }
+    /* ---- the 8 corners against the table plane z = 0.  Row directions are world axes: r x n has a closed form */
+    corner_row_t cr[8];
+    for (int c = 0; c < 8; ++c) {
+        const float sx = (c & 1) ? CUBE_HALF : -CUBE_HALF, sy = (c & 2) ? CUBE_HALF : -CUBE_HALF, sz = (c & 4) ? CUBE_HALF : -CUBE_HALF;
+        for (int k = 0; k < 3; ++k) cr[c].r[k] = fmaf(Rc[k][2], sz, fmaf(Rc[k][1], sy, Rc[k][0] * sx));
+        const float r0 = cr[c].r[0], r1 = cr[c].r[1], r2 = cr[c].r[2];
+        const float z = pos[2] + r2;
+        cr[c].active = z < TABLE_MARGIN;
+        cr[c].meff[0] = 1.0f / fmaf(inv_I, fmaf(r1, r1, r0 * r0), inv_m);
+        cr[c].meff[1] = 1.0f / fmaf(inv_I, fmaf(r2, r2, r1 * r1), inv_m);
+        cr[c].meff[2] = 1.0f / fmaf(inv_I, fmaf(r2, r2, r0 * r0), inv_m);
+        const float push = (BAUMGARTE * -z) * inv_h;
+        cr[c].target = z < 0.0f ? (push < 1.0f ? push : 1.0f) : -z * inv_h;
+        cr[c].lam[0] = cr[c].lam[1] = cr[c].lam[2] = 0.0f;
+    }
+    /* ---- the two finger pads; finger k sits at hand-frame y = +fq[0] / -fq[1] */
+    pad_row_t pd[2];
+    {
+        float d[3], cl[3], xh[3], yh[3], zh[3];
+        for (int k = 0; k < 3; ++k) { d[k] = pos[k] - H->tcp[k]; xh[k] = H->R[k][0]; yh[k] = H->R[k][1]; zh[k] = H->R[k][2]; }
+        cl[0] = dot3(xh, d); cl[1] = dot3(yh, d); cl[2] = dot3(zh, d);          /* cube centre in hand coordinates */
+        float ext = 0.0f;                                                     /* half extent of the cube along the closing axis */
+        for (int a = 0; a < 3; ++a) {
+            const float col[3] = {Rc[0][a], Rc[1][a], Rc[2][a]};
+            ext = fmaf(fabsf(dot3(yh, col)), CUBE_HALF, ext);
+        }
+        const int between = fabsf(cl[0]) < CUBE_HALF + PAD_HALF_X && fabsf(cl[2]) < CUBE_HALF + PAD_HALF_Z;
+        const float px = clampf(cl[0], -PAD_HALF_X, PAD_HALF_X), pz = clampf(cl[2], -PAD_HALF_Z, PAD_HALF_Z);
+        for (int k = 0; k < 2; ++k) {
+            const float sgn = k == 0 ? 1.0f : -1.0f;
+            const float gap = fq[k] - (fmaf(sgn, cl[1], ext));
+            pad_row_t *P = &pd[k];
+            P->active = between && gap < PAD_MARGIN;
+            float arm[3], r[3], vpad[3], t[3];
+            for (int i = 0; i < 3; ++i) {
+                arm[i] = fmaf(zh[i], pz, fmaf(yh[i], sgn * fq[k], xh[i] * px));     /* contact point relative to the tcp */
+                r[i] = (H->tcp[i] + arm[i]) - pos[i];
+            }
+            cross3(H->w, arm, t);
+            for (int i = 0; i < 3; ++i) {
+                vpad[i] = H->v[i] + t[i];
+                P->n[0][i] = -sgn * yh[i]; P->n[1][i] = xh[i]; P->n[2][i] = zh[i];
+            }
+            for (int row = 0; row < 3; ++row) cross3(r, P->n[row], P->rxn[row]);
+            for (int i = 0; i < 3; ++i) P->rxn[3][i] = yh[i];               /* torsional friction: a pure couple about y */
+            P->meff[0] = 1.0f / (fmaf(inv_I, dot3(P->rxn[0], P->rxn[0]), inv_m) + f_minv);
+            P->meff[1] = 1.0f / fmaf(inv_I, dot3(P->rxn[1], P->rxn[1]), inv_m);
+            P->meff[2] = 1.0f / fmaf(inv_I, dot3(P->rxn[2], P->rxn[2]), inv_m);
+            P->meff[3] = 1.0f / inv_I;
+            const float push = (BAUMGARTE * -gap) * inv_h;
+            P->target[0] = dot3(vpad, P->n[0]) + (gap < 0.0f ? (push < 0.5f ? push : 0.5f) : -gap * inv_h);
+            P->target[1] = dot3(vpad, P->n[1]);
+            P->target[2] = dot3(vpad, P->n[2]);
+            P->target[3] = dot3(H->w, yh);
+            for (int row = 0; row < 4; ++row) P->lam[row] = 0.0f;
+        }
+    }
+    /* ---- projected Gauss-Seidel: corners 0..7 (normal, friction x, friction y), then pads 0, 1 (normal, x, z, torsion) */
+    for (int it = 0; it < cfg->solver_iterations; ++it) {
+        for (int c = 0; c < 8; ++c) {
+            corner_row_t *C = &cr[c];
+            if (!C->active) continue;
+            const float r0 = C->r[0], r1 = C->r[1], r2 = C->r[2];
+            {
+                const float u = lin[2] + fmaf(r1, ang[0], -(r0 * ang[1]));
+                float lam = fmaf(C->target - u, C->meff[0], C->lam[0]);
+                lam = lam < 0.0f ? 0.0f : lam;
+                const float dl = lam - C->lam[0];
+                C->lam[0] = lam;
+                lin[2] = fmaf(dl, inv_m, lin[2]);
+                const float di = dl * inv_I;
+                ang[0] = fmaf(r1, di, ang[0]);
+                ang[1] = fmaf(-r0, di, ang[1]);
+            }
+            const float lim = cfg->mu_table * C->lam[0];
+            {
+                const float u = lin[0] + fmaf(r2, ang[1], -(r1 * ang[2]));
+                const float lam = clampf(fmaf(-u, C->meff[1], C->lam[1]), -lim, lim);
+                const float dl = lam - C->lam[1];
+                C->lam[1] = lam;
+                lin[0] = fmaf(dl, inv_m, lin[0]);
+                const float di = dl * inv_I;
+                ang[1] = fmaf(r2, di, ang[1]);
+                ang[2] = fmaf(-r1, di, ang[2]);
+            }
+            {
+                const float u = lin[1] + fmaf(r0, ang[2], -(r2 * ang[0]));
+                const float lam = clampf(fmaf(-u, C->meff[2], C->lam[2]), -lim, lim);
+                const float dl = lam - C->lam[2];
+                C->lam[2] = lam;
+                lin[1] = fmaf(dl, inv_m, lin[1]);
+                const float di = dl * inv_I;
+                ang[2] = fmaf(r0, di, ang[2]);
+                ang[0] = fmaf(-r2, di, ang[0]);
+            }
+        }
+        for (int k = 0; k < 2; ++k) {
+            pad_row_t *P = &pd[k];
+            if (!P->active) continue;
+            for (int row = 0; row < 4; ++row) {
+                float u = dot3(P->rxn[row], ang);
+                if (row < 3) u = u + dot3(P->n[row], lin);
+                if (row == 0) u = u + fv[k];                                  /* the finger closes along the row direction */
+                float lam = fmaf(P->target[row] - u, P->meff[row], P->lam[row]);
+                if (row == 0) {
+                    lam = lam < 0.0f ? 0.0f : lam;
+                } else {
+                    const float lim = (row == 3 ? cfg->mu_pad * TORSION_R : cfg->mu_pad) * P->lam[0];
+                    lam = clampf(lam, -lim, lim);
+                }
+                const float dl = lam - P->lam[row];
+                P->lam[row] = lam;
+                const float dm = dl * inv_m, di = dl * inv_I;
+                if (row < 3)
+                    for (int i = 0; i < 3; ++i) lin[i] = fmaf(P->n[row][i], dm, lin[i]);
+                for (int i = 0; i < 3; ++i) ang[i] = fmaf(P->rxn[row][i], di, ang[i]);
+                if (row == 0) fv[k] = fmaf(dl, f_minv, fv[k]);                /* the reaction opens the finger */
+            }
+        }
+    }
+    /* ---- integrate */
+    for (int k = 0; k < 2; ++k) {
+        float v = clampf(fv[k], -FINGER_VLIM, FINGER_VLIM);
+        float x = fmaf(h, v, fq[k]);
+        if (x > FINGER_TRAVEL) { x = FINGER_TRAVEL; v = 0.0f; }
+        if (x < 0.0f) { x = 0.0f; v = 0.0f; }
+        fq[k] = x;
+        fqd[k] = v;
+    }
+    for (int k = 0; k < 3; ++k) pos[k] = fmaf(h, lin[k], pos[k]);
+    {
+        const float qw = quat[0], qx = quat[1], qy = quat[2], qz = quat[3], hh = 0.5f * h;
+        const float nw = fmaf(hh, -fmaf(ang[2], qz, fmaf(ang[1], qy, ang[0] * qx)), qw);
+        const float nx = fmaf(hh, fmaf(-ang[2], qy, fmaf(ang[1], qz, ang[0] * qw)), qx);
+        const float ny = fmaf(hh, fmaf(-ang[0], qz, fmaf(ang[2], qx, ang[1] * qw)), qy);
+        const float nz = fmaf(hh, fmaf(-ang[1], qx, fmaf(ang[0], qy, ang[2] * qw)), qz);
+        const float inv = rsqrt_newton(fmaf(nz, nz, fmaf(ny, ny, fmaf(nx, nx, nw * nw))));
+        quat[0] = nw * inv; quat[1] = nx * inv; quat[2] = ny * inv; quat[3] = nz * inv;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ MDP terms */
+/* ORBIT utils.math.quat_apply (w, x, y, z): v + 2 w (q_v x v) + 2 q_v x (q_v x v), in ORBIT's operation order */
+static void quat_apply(const float q[4], const float v[3], float o[3])
+{
     const float w = q[0], x = q[1], y = q[2], z = q[3];
     const float tx = 2.0f * (y * v[2] - z * v[1]), ty = 2.0f * (z * v[0] - x * v[2]), tz = 2.0f * (x * v[1] - y * v[0]);
     o[0] = v[0] + w * tx + (y * tz - z * ty);
     o[1] = v[1] + w * ty + (z * tx - x * tz);
     o[2] = v[2] + w * tz + (x * ty - y * tx);
 }
+
+/* rewards.py:20-26 object_is_lifted, :29-46 object_ee_distance, :49-67 object_goal_distance; observations.py:19-31
+ * object_position_in_robot_root_frame.  root = robot root pose (position 3, quaternion 4). */
+static void reference_terms(const float obj[3], const float ee[3], const float root_pos[3], const float root_quat[4], const float cmd_pos_b[3],
+                            float reach_std, float goal_std, float goal_fine_std, float minimal_height, float *lifted, float *reach,
+                            float *goal, float *goal_fine, float obj_b[3])
+{
+    *lifted = obj[2] > minimal_height ? 1.0f : 0.0f;
+    const float d[3] = {obj[0] - ee[0], obj[1] - ee[1], obj[2] - ee[2]};
+    *reach = 1.0f - tanh_poly(sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) / reach_std);
+    float des[3];
+    quat_apply(root_quat, cmd_pos_b, des);                                  /* combine_frame_transforms, rewards.py:61 */
+    const float g[3] = {des[0] + root_pos[0] - obj[0], des[1] + root_pos[1] - obj[1], des[2] + root_pos[2] - obj[2]};
+    const float dist = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+    *goal = *lifted * (1.0f - tanh_poly(dist / goal_std));
+    *goal_fine = *lifted * (1.0f - tanh_poly(dist / goal_fine_std));
+    const float qi[4] = {root_quat[0], -root_quat[1], -root_quat[2], -root_quat[3]};
+    const float rel[3] = {obj[0] - root_pos[0], obj[1] - root_pos[1], obj[2] - root_pos[2]};
+    quat_apply(qi, rel, obj_b);                                             /* subtract_frame_transforms, observations.py:27-31 */
+}
+
 void lfo_terms(int n, const float *obj_pos, const float *ee_pos, const float *root_state /* n x 13 */, const float *cmd /* n x 7 */,
                float reach_std, float goal_std, float goal_fine_std, float minimal_height, float *lifted, float *reach,
                float *goal, float *goal_fine, float *obj_pos_b)
 {
-    for (int i = 0; i < n; ++i) {
-        const float *o = obj_pos + 3 * i, *e = ee_pos + 3 * i, *r = root_state + 13 * i, *c = cmd + 7 * i;
-        lifted[i] = o[2] > minimal_height ? 1.0f : 0.0f;                                   /* rewards.py:20-26 */
-        const float d[3] = {o[0] - e[0], o[1] - e[1], o[2] - e[2]};
-        reach[i] = 1.0f - lm_tanhf(sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) / reach_std);   /* :29-46 */
-        float des[3];
-        quat_apply_ref(r + 3, c, des);                                                     /* combine_frame_transforms :61 */
-        const float g[3] = {des[0] + r[0] - o[0], des[1] + r[1] - o[1], des[2] + r[2] - o[2]};
-        const float dist = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
-        goal[i] = lifted[i] * (1.0f - lm_tanhf(dist / goal_std));                           /* :63-67 */
-        goal_fine[i] = lifted[i] * (1.0f - lm_tanhf(dist / goal_fine_std));
-        const float qi[4] = {r[3], -r[4], -r[5], -r[6]};
-        const float rel[3] = {o[0] - r[0], o[1] - r[1], o[2] - r[2]};
-        quat_apply_ref(qi, rel, obj_pos_b + 3 * i);                                        /* observations.py:27-31 */
-    }
+    for (int i = 0; i < n; ++i)
+        reference_terms(obj_pos + 3 * i, ee_pos + 3 * i, root_state + 13 * i, root_state + 13 * i + 3, cmd + 7 * i, reach_std, goal_std,
+                        goal_fine_std, minimal_height, lifted + i, reach + i, goal + i, goal_fine + i, obj_pos_b + 3 * i);
 }
 
-/* ---- layer 2: the shared model, CPU build -------------------------------------------------------------------------- */
-void lfo_default_config(lift_config *c) { lift_default_config(c); }
-int lfo_state_words(void) { return LIFT_STATE_WORDS; }
-int lfo_config_bytes(void) { return (int)sizeof(lift_config); }
+/* ------------------------------------------------------------------------------------------------ RNG, reset */
+static void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+    for (int round = 0; round < 10; ++round) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+static float uniform01(uint32_t u) { return (float)(u >> 8) * (1.0f / 16777216.0f); }
+static uint32_t word_u32(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static float u32_word(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
-void lfo_reset(const lift_config *cfg, int n, int env_id_offset, float *state /* n x 64 AoS */, float *obs)
+/* UniformPoseCommand._resample_command (manipulation_env_cfg.py:163-172): position uniform in the ranges, roll = pitch =
+ * yaw = 0 -> identity quaternion; timer = resampling time */
+static void resample_command(const lfo_config *c, float *S, uint32_t gid, uint32_t count, uint32_t stream)
+{
+    uint32_t r[4];
+    philox4x32_10(gid, count, 1u, stream, c->seed_lo, c->seed_hi, r);
+    for (int k = 0; k < 3; ++k) S[W_CMD + k] = fmaf(uniform01(r[k]), c->cmd_hi[k] - c->cmd_lo[k], c->cmd_lo[k]);
+    S[W_CMD + 3] = 1.0f; S[W_CMD + 4] = 0.0f; S[W_CMD + 5] = 0.0f; S[W_CMD + 6] = 0.0f;
+    S[W_TIME_LEFT] = c->cmd_resample_time;
+}
+/* RLTaskEnv._reset_idx: reset_scene_to_default (:179), reset_root_state_uniform on the object (:181-190), manager resets */
+static void reset_env(const lfo_config *c, float *S, uint32_t gid)
+{
+    const uint32_t count = word_u32(S[W_RESET_COUNT]);
+    uint32_t r[4];
+    philox4x32_10(gid, count, 0u, 0u, c->seed_lo, c->seed_hi, r);
+    for (int i = 0; i < 9; ++i) { S[W_Q + i] = Q_DEFAULT[i]; S[W_QD + i] = 0.0f; }
+    for (int k = 0; k < 3; ++k)
+        S[W_OBJ_POS + k] = c->obj_init[k] + fmaf(uniform01(r[k]), c->obj_range_hi[k] - c->obj_range_lo[k], c->obj_range_lo[k]);
+    S[W_OBJ_QUAT] = 1.0f; S[W_OBJ_QUAT + 1] = 0.0f; S[W_OBJ_QUAT + 2] = 0.0f; S[W_OBJ_QUAT + 3] = 0.0f;
+    for (int k = 0; k < 6; ++k) S[W_OBJ_LIN + k] = 0.0f;
+    for (int i = 0; i < N_ACT; ++i) { S[W_ACTION + i] = 0.0f; S[W_PREV_ACTION + i] = 0.0f; }
+    for (int i = 0; i < N_REW; ++i) S[W_EP_SUM + i] = 0.0f;
+    resample_command(c, S, gid, count, 0u);
+    S[W_EP_LEN] = u32_word(0u);
+    S[W_RESET_COUNT] = u32_word(count + 1u);
+}
+/* ObservationsCfg.PolicyCfg (manipulation_env_cfg.py:101-116): joint_pos_rel 9, joint_vel_rel 9, object position in the
+ * robot root frame 3 (root at the origin, identity), generated_commands 7, last_action 8 */
+static void write_observation(const float *S, float *obs)
+{
+    for (int i = 0; i < 9; ++i) { obs[i] = S[W_Q + i] - Q_DEFAULT[i]; obs[9 + i] = S[W_QD + i]; }
+    const float root_pos[3] = {0.0f, 0.0f, 0.0f}, qi[4] = {1.0f, -0.0f, -0.0f, -0.0f};
+    const float rel[3] = {S[W_OBJ_POS] - root_pos[0], S[W_OBJ_POS + 1] - root_pos[1], S[W_OBJ_POS + 2] - root_pos[2]};
+    quat_apply(qi, rel, obs + 18);
+    for (int i = 0; i < 7; ++i) obs[21 + i] = S[W_CMD + i];
+    for (int i = 0; i < N_ACT; ++i) obs[28 + i] = S[W_ACTION + i];
+}
+
+/* ------------------------------------------------------------------------------------------------ one env step */
+/* RLTaskEnv.step ordering: process_action -> decimation x (apply_action, sim.step) -> episode_length_buf += 1 ->
+ * terminations -> rewards -> _reset_idx -> command_manager.compute -> observations.  lg[10]: episodic sums (6),
+ * termination flags (2), reset flag, pad -- non-zero only when the env resets. */
+static void step_env(const lfo_config *c, float *S, const float *action, uint32_t gid, float *obs, float *reward, uint8_t *terminated,
+                     uint8_t *truncated, float lg[10])
+{
+    for (int i = 0; i < N_ACT; ++i) { S[W_PREV_ACTION + i] = S[W_ACTION + i]; S[W_ACTION + i] = action[i]; }
+    float target[7], finger_target[2];
+    for (int i = 0; i < 7; ++i) target[i] = Q_DEFAULT[i] + c->action_scale * action[i];          /* JointPositionAction, :35-37 */
+    finger_target[0] = finger_target[1] = action[7] < 0.0f ? c->finger_close : c->finger_open;   /* BinaryJointPositionAction, :38-43 */
+    hand_pose_t hand;
+    for (int s = 0; s < c->decimation; ++s) {
+        arm_substep(c->sim_dt, target, S + W_Q, S + W_QD);
+        hand_kinematics(S + W_Q, S + W_QD, c->ee_offset_z, &hand);
+        cube_substep(c, c->sim_dt, &hand, finger_target, S + W_Q + 7, S + W_QD + 7, S + W_OBJ_POS, S + W_OBJ_QUAT, S + W_OBJ_LIN,
+                     S + W_OBJ_ANG);
+    }
+    if (c->decimation <= 0) hand_kinematics(S + W_Q, S + W_QD, c->ee_offset_z, &hand);
+    const int32_t ep_len = (int32_t)word_u32(S[W_EP_LEN]) + 1;
+    S[W_EP_LEN] = u32_word((uint32_t)ep_len);
+    /* terms: the four the reference owns + ORBIT's action_rate_l2, joint_vel_l2, time_out, base_height */
+    const float root_pos[3] = {0.0f, 0.0f, 0.0f}, root_quat[4] = {1.0f, 0.0f, 0.0f, 0.0f};
+    float rew[N_REW], obj_b[3];
+    reference_terms(S + W_OBJ_POS, hand.tcp, root_pos, root_quat, S + W_CMD, c->reach_std, c->goal_std, c->goal_fine_std, c->minimal_height,
+                    &rew[1], &rew[0], &rew[2], &rew[3], obj_b);
+    float rate = 0.0f, jvel = 0.0f;
+    for (int i = 0; i < N_ACT; ++i) { const float d = S[W_ACTION + i] - S[W_PREV_ACTION + i]; rate += d * d; }
+    for (int i = 0; i < 9; ++i) jvel += S[W_QD + i] * S[W_QD + i];
+    rew[4] = rate;
+    rew[5] = jvel;
+    const int time_out = ep_len >= c->max_episode_length;
+    const int dropped = S[W_OBJ_POS + 2] < c->drop_height;
+    const float step_dt = c->sim_dt * (float)c->decimation;
+    float total = 0.0f;
+    for (int i = 0; i < N_REW; ++i) {
+        if (c->rew_weight[i] != 0.0f) {
+            const float val = rew[i] * c->rew_weight[i] * step_dt;
+            total += val;
+            S[W_EP_SUM + i] += val;
+        }
+    }
+    *reward = total;
+    *truncated = (uint8_t)time_out;
+    *terminated = (uint8_t)dropped;
+    for (int i = 0; i < 10; ++i) lg[i] = 0.0f;
+    if (time_out || dropped) {
+        for (int i = 0; i < N_REW; ++i) lg[i] = S[W_EP_SUM + i];
+        lg[6] = (float)time_out;
+        lg[7] = (float)dropped;
+        lg[8] = 1.0f;
+        reset_env(c, S, gid);
+    }
+    S[W_TIME_LEFT] -= step_dt;                        /* CommandTerm.compute: timer, resample, (no body-frame update needed) */
+    if (S[W_TIME_LEFT] <= 0.0f) resample_command(c, S, gid, word_u32(S[W_RESET_COUNT]), 1u);
+    write_observation(S, obs);
+}
+
+/* ------------------------------------------------------------------------------------------------ exported API */
+void lfo_default_config(lfo_config *c)
+{
+    memset(c, 0, sizeof(*c));
+    c->sim_dt = 0.01f; c->decimation = 2; c->max_episode_length = 250; c->max_episode_length_s = 5.0f;    /* :232-234 */
+    c->action_scale = 0.5f; c->finger_open = 0.04f; c->finger_close = 0.0f;                                /* joint_pos_env_cfg.py:35-43 */
+    const float w[N_REW] = {1.0f, 15.0f, 16.0f, 5.0f, 1.0e-3f, 1.0e-4f};                                    /* :120-144 */
+    memcpy(c->rew_weight, w, sizeof(w));
+    c->reach_std = 0.1f; c->goal_std = 0.3f; c->goal_fine_std = 0.05f; c->minimal_height = 0.06f;
+    c->drop_height = -0.05f;                                                                               /* :153 */
+    c->cmd_lo[0] = 0.3f; c->cmd_hi[0] = 0.7f; c->cmd_lo[1] = 0.3f; c->cmd_hi[1] = 0.7f;                    /* :170 */
+    c->cmd_resample_time = 5.0f;
+    c->obj_init[0] = 0.5f; c->obj_init[1] = 0.0f; c->obj_init[2] = 0.055f;                                 /* joint_pos_env_cfg.py:51 */
+    c->obj_range_lo[0] = -0.1f; c->obj_range_hi[0] = 0.1f; c->obj_range_lo[1] = -0.25f; c->obj_range_hi[1] = 0.25f;   /* :185 */
+    c->ee_offset_z = 0.1034f;                                                                              /* joint_pos_env_cfg.py:78 */
+    c->solver_iterations = 8;
+    c->mu_table = 0.6f; c->mu_pad = 0.9f;
+}
+int lfo_state_words(void) { return N_WORDS; }
+int lfo_config_bytes(void) { return (int)sizeof(lfo_config); }
+int lfo_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* model constants in a fixed order, compared with the HIP library's table (rover_lift_model_constants) */
+int lfo_model_constants(float *out, int cap)
+{
+    float t[160];
+    int n = 0;
+    for (int i = 0; i < 7; ++i) { t[n++] = (float)DH_KIND[i]; t[n++] = DH_A[i]; t[n++] = DH_D[i]; t[n++] = LINK_MASS[i]; }
+    for (int i = 0; i < 7; ++i) for (int k = 0; k < 3; ++k) t[n++] = LINK_COM[i][k];
+    for (int i = 0; i < 7; ++i) for (int k = 0; k < 3; ++k) t[n++] = LINK_INERTIA[i][k];
+    for (int i = 0; i < 7; ++i) { t[n++] = Q_LO[i]; t[n++] = Q_HI[i]; t[n++] = QD_LIM[i]; t[n++] = EFFORT[i]; }
+    for (int i = 0; i < 9; ++i) t[n++] = Q_DEFAULT[i];
+    const float scalars[] = {GRAV, CUBE_HALF, CUBE_MASS, PAD_HALF_X, PAD_HALF_Z, FINGER_MASS, FINGER_KP, FINGER_KD, FINGER_EFFORT,
+                             FINGER_VLIM, FINGER_TRAVEL, ARM_KP, ARM_KD, ARMATURE, BAUMGARTE, TORSION_R, FLANGE_D, TABLE_MARGIN, PAD_MARGIN};
+    for (unsigned i = 0; i < sizeof(scalars) / sizeof(scalars[0]); ++i) t[n++] = scalars[i];
+    if (out) for (int i = 0; i < n && i < cap; ++i) out[i] = t[i];
+    return n;
+}
+
+void lfo_reset(const lfo_config *cfg, int n, int env_id_offset, float *state /* n x 64, one row per env */, float *obs)
 {
 #pragma omp parallel for schedule(static)
     for (int e = 0; e < n; ++e) {
-        float *S = state + (size_t)e * LIFT_STATE_WORDS;
-        lift_reset_one(cfg, S, (uint32_t)(env_id_offset + e));
-        if (obs) lift_write_obs(cfg, S, obs + (size_t)e * LIFT_OBS);
+        float *S = state + (size_t)e * N_WORDS;
+        reset_env(cfg, S, (uint32_t)(env_id_offset + e));
+        if (obs) write_observation(S, obs + (size_t)e * N_OBS);
     }
 }
 
-void lfo_step(const lift_config *cfg, int n, int env_id_offset, float *state, const float *action, float *obs, float *reward,
-              uint8_t *terminated, uint8_t *truncated, float *log_out /* LIFT_LOG_WORDS */)
+void lfo_step(const lfo_config *cfg, int n, int env_id_offset, float *state, const float *action, float *obs, float *reward,
+              uint8_t *terminated, uint8_t *truncated, float *log_out /* N_LOG */)
 {
-    float acc[10];
+    double acc[10];                                   /* sums in double: the order of the envs does not matter to 1e-12 */
     memset(acc, 0, sizeof(acc));
 #pragma omp parallel for schedule(static)
     for (int e = 0; e < n; ++e) {
         float lg[10];
-        lift_step_one(cfg, state + (size_t)e * LIFT_STATE_WORDS, action + (size_t)e * LIFT_ACT, (uint32_t)(env_id_offset + e),
-                      obs + (size_t)e * LIFT_OBS, reward + e, terminated + e, truncated + e, lg);
+        step_env(cfg, state + (size_t)e * N_WORDS, action + (size_t)e * N_ACT, (uint32_t)(env_id_offset + e), obs + (size_t)e * N_OBS,
+                 reward + e, terminated + e, truncated + e, lg);
         if (lg[8] != 0.0f) {
 #pragma omp critical
-            for (int i = 0; i < 10; ++i) acc[i] += lg[i];
+            for (int i = 0; i < 10; ++i) acc[i] += (double)lg[i];
         }
     }
     if (log_out) {
-        const float cnt = acc[8];
-        if (cnt > 0.0f) {
-            for (int i = 0; i < LIFT_NUM_REW; ++i) log_out[i] = acc[i] / cnt / cfg->max_episode_length_s;
-            log_out[6] = acc[6];
-            log_out[7] = acc[7];
+        const double cnt = acc[8];
+        if (cnt > 0.0) {
+            for (int i = 0; i < N_REW; ++i) log_out[i] = (float)(acc[i] / cnt / (double)cfg->max_episode_length_s);
+            log_out[6] = (float)acc[6];
+            log_out[7] = (float)acc[7];
         }
-        log_out[8] = cnt;
+        log_out[8] = (float)cnt;
     }
 }
 
-/* probes for the plausibility tests */
-void lfo_hand_pose(const lift_config *cfg, const float *q9, const float *qd9, float *tcp, float *R9, float *v, float *w)
+/* ---- probes for the plausibility tests ------------------------------------------------------------------------ */
+void lfo_hand_pose(const lfo_config *cfg, const float *q9, const float *qd9, float *tcp, float *R9, float *v, float *w)
 {
-    lm_chain ch;
-    lm_hand h;
-    lm_chain_build(q9, &ch);
-    lm_hand_fk(&ch, qd9, cfg->ee_offset_z, &h);
-    for (int i = 0; i < 3; ++i) { tcp[i] = h.tcp[i]; v[i] = h.v[i]; w[i] = h.w[i]; for (int j = 0; j < 3; ++j) R9[3 * i + j] = h.R[i][j]; }
-}
-void lfo_gravity_torque(const float *q7, float *tau7)
-{
-    lm_chain ch;
-    const float z[7] = {0, 0, 0, 0, 0, 0, 0};
-    lm_chain_build(q7, &ch);
-    lm_rne(&ch, z, z, LM_G, tau7);
-}
-void lfo_mass_matrix(const float *q7, float *M49)
-{
-    lm_chain ch;
-    float Mm[7][7];
-    lm_chain_build(q7, &ch);
-    lm_mass_matrix(&ch, Mm);
-    for (int i = 0; i < 7; ++i)
-        for (int j = 0; j < 7; ++j) M49[7 * i + j] = Mm[i][j];
+    hand_pose_t H;
+    hand_kinematics(q9, qd9, cfg->ee_offset_z, &H);
+    for (int i = 0; i < 3; ++i) { tcp[i] = H.tcp[i]; v[i] = H.v[i]; w[i] = H.w[i]; for (int j = 0; j < 3; ++j) R9[3 * i + j] = H.R[i][j]; }
 }
 void lfo_inverse_dynamics(const float *q7, const float *qd7, const float *qdd7, float gravity, float *tau7)
 {
-    lm_chain ch;
-    lm_chain_build(q7, &ch);
-    lm_rne(&ch, qd7, qdd7, gravity, tau7);
+    float sn[7], cs[7];
+    for (int i = 0; i < 7; ++i) sincos_poly(q7[i], &sn[i], &cs[i]);
+    newton_euler(sn, cs, qd7, qdd7, gravity, tau7);
 }
-float lfo_tanhf(float x) { return lm_tanhf(x); }
+void lfo_gravity_torque(const float *q7, float *tau7)
+{
+    const float z[7] = {0, 0, 0, 0, 0, 0, 0};
+    lfo_inverse_dynamics(q7, z, z, GRAV, tau7);
+}
+void lfo_mass_matrix(const float *q7, float *M49)    /* raw passes: M49[7 i + j] = tau_i of pass j (symmetric up to rounding) */
+{
+    float sn[7], cs[7], cols[7][7], bias[7];
+    const float z[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 7; ++i) sincos_poly(q7[i], &sn[i], &cs[i]);
+    arm_passes(sn, cs, z, cols, bias);
+    for (int i = 0; i < 7; ++i)
+        for (int j = 0; j < 7; ++j) M49[7 * i + j] = cols[j][i];
+}
+/* one arm substep / one cube substep on caller rows (unit probes, also used to check the HIP unit entries) */
+void lfo_arm_substep(float h, const float *target7, float *q7, float *qd7) { arm_substep(h, target7, q7, qd7); }
+float lfo_tanhf(float x) { return tanh_poly(x); }

@@ -16,7 +16,7 @@ Q_DEFAULT = np.array([0.0, -0.569, 0.0, -2.810, 0.0, 3.037, 0.741, 0.04, 0.04], 
 
 
 class Config(C.Structure):
-    """Mirror of ``struct lift_config`` (isaac_rover_orbit_amd/csrc/lift_model.h)."""
+    """Mirror of ``struct lfo_config`` (oracle/lift_oracle.c) = ``struct lift_config`` of the C ABI (include/rover_lift.h)."""
     _fields_ = [
         ("sim_dt", C.c_float), ("decimation", C.c_int32), ("max_episode_length", C.c_int32), ("max_episode_length_s", C.c_float),
         ("action_scale", C.c_float), ("finger_open", C.c_float), ("finger_close", C.c_float),
@@ -30,7 +30,7 @@ class Config(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, "lift_oracle.c"), os.path.join(os.path.dirname(_HERE), "isaac_rover_orbit_amd", "csrc", "lift_model.h")]
+    srcs = [os.path.join(_HERE, "lift_oracle.c")]
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liblift_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
@@ -123,6 +123,24 @@ def inverse_dynamics(q7, qd7, qdd7, gravity=9.81):
     tau = np.zeros(7, np.float32)
     lib().lfo_inverse_dynamics(_p(q), _p(qd), _p(qdd), C.c_float(gravity), _p(tau))
     return tau
+
+
+def max_threads() -> int:
+    return int(lib().lfo_max_threads())
+
+
+def model_constants() -> np.ndarray:
+    n = lib().lfo_model_constants(None, 0)
+    out = np.zeros(n, np.float32)
+    lib().lfo_model_constants(_p(out), n)
+    return out
+
+
+def arm_substep(h, target7, q7, qd7):
+    """One arm substep on copies of (q, qd); returns the new (q, qd)."""
+    q, qd = _f32(q7).copy(), _f32(qd7).copy()
+    lib().lfo_arm_substep(C.c_float(h), _p(_f32(target7)), _p(q), _p(qd))
+    return q, qd
 
 
 def mass_matrix(q7):

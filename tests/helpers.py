@@ -126,3 +126,23 @@ def check_reset_against_fixture(state_aos, expect, words):
                  "target xy (terrain_importer.py:168-173)")
     assert_close(S[:, words.TARGET_W + 2], expect["pos_command_w"][:, 2], 0, 0, "target z (get_height_at, terrain_utils.py:62-84)")
     assert_close(S[:, words.HEADING_CMD_W], expect["heading_command_w"], 2.4e-7, 0, "heading command (:93-95)")
+
+
+def gfx950_code_objects(lib_path):
+    """The gfx950 code objects embedded in a HIP shared library: the .hip_fatbin section is a sequence of clang offload bundles
+    (one per translation unit): magic, u64 entry count, entries {u64 offset, u64 size, u64 id length, id}."""
+    import struct
+    data = open(lib_path, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    out, pos = [], data.find(magic)
+    while pos >= 0:
+        n = struct.unpack_from("<Q", data, pos + len(magic))[0]
+        q = pos + len(magic) + 8
+        for _ in range(n):
+            off, size, idlen = struct.unpack_from("<QQQ", data, q)
+            ident = data[q + 24:q + 24 + idlen].decode()
+            q += 24 + idlen
+            if "gfx950" in ident and size > 0:
+                out.append(data[pos + off:pos + off + size])
+        pos = data.find(magic, pos + len(magic))
+    return out

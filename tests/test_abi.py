@@ -54,6 +54,40 @@ def test_default_config_matches_reference_cfg_and_oracle(oracle):
     assert c.offset_lin == c.offset_ang == pytest.approx(-0.0135)
 
 
+def test_lift_model_constants_agree_and_step_kernel_has_no_scratch():
+    """FrankaCubeLift-v0: the HIP library and the separately written oracle carry the same model constants; the step
+    kernel keeps everything in registers (no private segment = no scratch memory) and uses 2176 B of LDS (the lane exchange)."""
+    import subprocess
+    from isaac_rover_orbit_amd import _lib
+    from oracle import lift_oracle as lo
+    lib = _lib.load()
+    n = lib.rover_lift_model_constants(None, 0)
+    hip = np.zeros(n, np.float32)
+    lib.rover_lift_model_constants(hip.ctypes.data_as(C.c_void_p), n)
+    orc = lo.model_constants()
+    assert n == len(orc) > 100 and np.array_equal(hip, orc)
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(readelf):
+        pytest.skip("ROCm llvm tools not installed")
+    import tempfile
+    from helpers import gfx950_code_objects
+    found = 0
+    for blob in gfx950_code_objects(_lib.LIB_PATH):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(blob)
+            f.flush()
+            notes = subprocess.run([readelf, "--notes", f.name], capture_output=True, text=True).stdout
+        # one YAML map per kernel: split at the '- .agpr_count' / '- .args' list heads
+        for entry in re.split(r"\n\s*- \.", notes):
+            m = re.search(r"\.name:\s*(\S*lift_step_kernel\S*)", entry)
+            if not m or ".private_segment_fixed_size" not in entry:
+                continue
+            found += 1
+            assert re.search(r"\.private_segment_fixed_size:\s*0\b", entry), f"{m.group(1)} uses scratch memory"
+            assert re.search(r"\.group_segment_fixed_size:\s*2176\b", entry), f"{m.group(1)}: unexpected LDS size"
+    assert found >= 2, "lift_step_kernel<8> / <16> not found in the code object metadata"
+
+
 def test_errors_are_codes_not_crashes():
     """Error behaviour of the boundary: int codes + rover_last_error(), also on a host without a GPU."""
     from isaac_rover_orbit_amd import _lib

@@ -1,6 +1,7 @@
 """FrankaCubeLift-v0 on the MI355X (BASELINE config 5): the HIP path through the C ABI (include/rover_lift.h)
-against the reference fixture for the term arithmetic the reference owns, and against the CPU build of the model bit for bit
-(state, observations, rewards, flags) over closed-loop rollouts with resets.  extras["log"] means: rtol 1e-5."""
+against the reference fixture for the term arithmetic the reference owns, and against the separately written scalar CPU
+oracle (oracle/lift_oracle.c; shares no source with the kernel) bit for bit -- state, observations, rewards, flags -- over
+closed-loop rollouts with resets, for both lane mappings of the step kernel.  extras["log"] means: rtol 1e-5."""
 import numpy as np
 import pytest
 import torch
@@ -56,10 +57,12 @@ def test_lift_terms_match_reference_fixture(lo, golden_dir):
     env.close()
 
 
-@pytest.mark.parametrize("n,seed", [(64, 0), (333, 5)])
-def test_lift_rollout_matches_oracle(lo, n, seed):
-    """300 closed-loop steps (every env times out once: in-step resets, command resampling), random actions incl. gripper."""
+@pytest.mark.parametrize("n,seed,lanes", [(64, 0, 8), (333, 5, 8), (61, 2, 16)])
+def test_lift_rollout_matches_oracle(lo, n, seed, lanes):
+    """300 closed-loop steps (every env times out once: in-step resets, command resampling), random actions incl. gripper;
+    batch sizes that do not fill the last wave; eight lanes per env and the shadowed sixteen-lane form."""
     env = make_env(n, seed=seed)
+    assert env._lib.rover_lift_debug_set_lanes(env._h, lanes) == 0 and env.kernel_name() == f"lift_step_kernel<{lanes}>"
     ocfg = oracle_cfg(lo, env)
     obs, info = env.reset()
     So = lo.new_state(n)
@@ -83,6 +86,76 @@ def test_lift_rollout_matches_oracle(lo, n, seed):
     assert np.array_equal(env.get_state().cpu().numpy().view(np.int32), So.view(np.int32)), "final state bit exact"
     assert trunc_o.sum() == 0 and So[:, lo.EP_LEN].view(np.int32).max() < 60
     env.close()
+
+
+def test_lift_grasp_and_contacts_match_oracle(lo):
+    """States the random rollout rarely reaches: cube held between closing fingers (both pad row sets active), cube tilted on
+    an edge / a corner (different corner sets per env), cube in free fall, joints at their limits with saturated actuators --
+    40 steps each, bit exact."""
+    n = 96
+    env = make_env(n, seed=11)
+    ocfg = oracle_cfg(lo, env)
+    env.reset()
+    So = lo.new_state(n)
+    lo.reset(ocfg, So)
+    rng = np.random.RandomState(3)
+    S = So.copy()
+    for e in range(n):
+        kind = e % 4
+        if kind == 0:        # in the hand
+            tcp, R, _, _ = lo.hand_pose(ocfg, S[e, :9])
+            S[e, lo.OBJ_POS:lo.OBJ_POS + 3] = tcp + rng.uniform(-0.004, 0.004, 3)
+            S[e, 7:9] = 0.0205 + rng.uniform(0, 0.002, 2)
+        elif kind == 1:      # tilted on the table
+            ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+            ang = rng.uniform(0.2, 0.9)
+            S[e, lo.OBJ_QUAT:lo.OBJ_QUAT + 4] = np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * ax])
+            S[e, lo.OBJ_POS + 2] = 0.03
+            S[e, lo.OBJ_ANG:lo.OBJ_ANG + 3] = rng.uniform(-3, 3, 3)
+        elif kind == 2:      # falling and spinning
+            S[e, lo.OBJ_POS + 2] = rng.uniform(0.1, 0.4)
+            S[e, lo.OBJ_LIN:lo.OBJ_LIN + 6] = rng.uniform(-1, 1, 6)
+        else:                # arm far from the default pose, fast
+            S[e, :7] = np.clip(S[e, :7] + rng.uniform(-1.5, 1.5, 7), [-2.8, -1.7, -2.8, -3.0, -2.8, 0.0, -2.8], [2.8, 1.7, 2.8, -0.1, 2.8, 3.7, 2.8])
+            S[e, 9:16] = rng.uniform(-2, 2, 7)
+    S = S.astype(np.float32)
+    So[:] = S
+    env.set_state(torch.from_numpy(S))
+    pads_seen = 0
+    for k in range(40):
+        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+        a[0::4, 7] = -1.0                     # the grasping envs keep closing
+        a[3::4, :7] *= 3.0                    # far targets: actuators saturate
+        obs, rew, term, trunc, info = env.step(torch.from_numpy(a).to(env.device))
+        obs_o, rew_o, term_o, trunc_o, _ = lo.step(ocfg, So, a)
+        assert_close(obs["policy"].cpu().numpy(), obs_o, 0, 0, f"obs step {k}")
+        assert_close(rew.cpu().numpy(), rew_o, 0, 0, f"reward step {k}")
+        assert np.array_equal(term.cpu().numpy(), term_o.astype(bool))
+        pads_seen += int((So[0::4, 7] < 0.03).sum())
+    assert np.array_equal(env.get_state().cpu().numpy().view(np.int32), So.view(np.int32)), "final state bit exact"
+    assert pads_seen > 100, "the grasp case never engaged the pads"
+    env.close()
+
+
+def test_lift_seed_and_checkpoint(lo):
+    """reset(seed=) re-keys the resets (advisor finding of round 2); state_dict carries the key."""
+    env = make_env(128, seed=1)
+    o1 = env.reset()[0]["policy"].clone()
+    o2 = env.reset(seed=77)[0]["policy"].clone()
+    assert not torch.equal(o1[:, 18:21], o2[:, 18:21])
+    ocfg = oracle_cfg(lo, env)
+    assert ocfg.seed_lo == 77
+    So = lo.new_state(128)
+    So[:, lo.RESET_COUNT] = np.array([1], np.uint32).view(np.float32)           # second reset of every env
+    assert_close(o2.cpu().numpy(), lo.reset(ocfg, So), 0, 0, "obs after reset(seed=77)")
+    sd = env.state_dict()
+    env2 = make_env(128, seed=5)
+    env2.load_state_dict(sd)
+    a = torch.zeros(128, 8, device=env.device)
+    S = env.get_state(); S[:, 39] = torch.tensor([249], dtype=torch.int32).view(torch.float32).item()   # time out next step
+    env.set_state(S); env2.set_state(S)
+    assert torch.equal(env.step(a)[0]["policy"], env2.step(a)[0]["policy"])
+    env.close(); env2.close()
 
 
 def test_lift_boundary_surface():
