@@ -73,7 +73,8 @@ int rover_lift_model_constants(float *out, int32_t cap);
 int rover_lift_create(const lift_config *cfg, int32_t num_envs, int32_t env_id_offset, int32_t device, rover_lift_sim **out);
 int rover_lift_destroy(rover_lift_sim *sim);
 size_t rover_lift_workspace_bytes(const rover_lift_sim *sim);
-/* state: LIFT_STATE_WORDS x num_envs fp32 (SoA); workspace: rover_lift_workspace_bytes() bytes, 128-byte aligned */
+/* state: LIFT_STATE_WORDS x num_envs fp32 (SoA); workspace: rover_lift_workspace_bytes() bytes, 128-byte aligned.  Clears the
+ * workspace's two counters with a synchronous hipMemset (init-time call). */
 int rover_lift_bind(rover_lift_sim *sim, float *state, void *workspace, size_t workspace_bytes);
 
 /* env.seed(seed) / reset(seed=...) (gymnasium contract): new key of the counter-based RNG used by the resets that follow.
@@ -94,10 +95,11 @@ int rover_lift_reset(rover_lift_sim *sim, float *obs, void *stream);
 int rover_lift_step(rover_lift_sim *sim, const float *action, float *obs, float *reward, uint8_t *terminated, uint8_t *truncated,
                     float *log, void *stream);
 
-/* Profiling twin of rover_lift_step: the same launches bracketed by HIP events on `stream`; device time of the step kernel
- * in milliseconds (the log reduction is reported separately).  Synchronises -- measurement only (bench.py --config 5). */
+/* Profiling twin of rover_lift_step: the same launch bracketed by HIP events on `stream`; device time of the step kernel in
+ * milliseconds and, next to it, what an event pair with nothing in between reports (the fixed cost the first figure
+ * carries).  Synchronises -- measurement only (bench.py --config 5). */
 int rover_lift_profile_step(rover_lift_sim *sim, const float *action, float *obs, float *reward, uint8_t *terminated,
-                            uint8_t *truncated, float *log, void *stream, float *ms_step_kernel, float *ms_log_kernel);
+                            uint8_t *truncated, float *log, void *stream, float *ms_step_kernel, float *ms_event_overhead);
 /* Name of the step kernel as rocprofv3 prints it (minus qualifiers / parameter list), e.g. "lift_step_kernel<8>". */
 int rover_lift_kernel_name(const rover_lift_sim *sim, char *step_kernel, size_t cap);
 

@@ -70,6 +70,12 @@ constexpr float K_BAUMGARTE = 0.2f, K_TORSION_R = 0.008f, K_FLANGE_D = 0.107f, K
 
 // ---------------------------------------------------------------------------------------------------- scalar helpers
 LF_DEV float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+// Friction box of the contact sweep: clampf(x, -lim, lim) with lim >= +0 as ONE v_med3_f32.  gfx950 orders -0 < +0 in
+// min / max / med3 (tools/ubench/semantics_probe.hip); with lo = -lim <= hi = lim that gives the value the compare-and-select
+// form above gives for every finite x (the only zero-sign case, lim = +0: x = -0 -> -0, x = +0 -> +0 in both).
+LF_DEV float clamp_sym(float x, float lim) { return __builtin_amdgcn_fmed3f(x, -lim, lim); }
+// l < 0 ? 0 : l as v_max_f32: equal for every l except -0 (the accumulated impulses are sums ending in "+ lam", never -0)
+LF_DEV float nonneg(float l) { return __builtin_fmaxf(l, 0.0f); }
 
 // Cody-Waite reduction by pi/2 + Cephes minimax polynomials
 LF_DEV void sincos_poly(float x, float &s_out, float &c_out)
@@ -478,6 +484,9 @@ LF_DEV void cube_substep(const lift_config &cfg, float h, const CubeConsts &K, c
             const float gap = fq[k] - (fmaf(sgn, cl[1], ext));
             PadRows &P = pd[k];
             P.active = between && gap < K_PAD_MARGIN;
+            // The rows of a pad nobody touches are never read: form them only when some env of the wave needs them
+            // (random actions: almost never -- ~150 instructions per pad and substep).
+            if (!any_active<WAVE>(P.active)) continue;
             float arm[3], r[3], vpad[3], t[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -520,8 +529,7 @@ LF_DEV void cube_substep(const lift_config &cfg, float h, const CubeConsts &K, c
             const float r0 = cr[c][0], r1 = cr[c][1], r2 = cr[c][2];
             {
                 const float u = lin[2] + fmaf(r1, ang[0], -(r0 * ang[1]));
-                float l = fmaf(cr[c][6] - u, cr[c][3], lam[c][0]);
-                l = l < 0.0f ? 0.0f : l;
+                const float l = nonneg(fmaf(cr[c][6] - u, cr[c][3], lam[c][0]));
                 const float dl = l - lam[c][0];
                 lam[c][0] = l;
                 lin[2] = fmaf(dl, inv_m, lin[2]);
@@ -532,7 +540,7 @@ LF_DEV void cube_substep(const lift_config &cfg, float h, const CubeConsts &K, c
             const float lim = cfg.mu_table * lam[c][0];
             {
                 const float u = lin[0] + fmaf(r2, ang[1], -(r1 * ang[2]));
-                const float l = clampf(fmaf(-u, cr[c][4], lam[c][1]), -lim, lim);
+                const float l = clamp_sym(fmaf(-u, cr[c][4], lam[c][1]), lim);
                 const float dl = l - lam[c][1];
                 lam[c][1] = l;
                 lin[0] = fmaf(dl, inv_m, lin[0]);
@@ -542,7 +550,7 @@ LF_DEV void cube_substep(const lift_config &cfg, float h, const CubeConsts &K, c
             }
             {
                 const float u = lin[1] + fmaf(r0, ang[2], -(r2 * ang[0]));
-                const float l = clampf(fmaf(-u, cr[c][5], lam[c][2]), -lim, lim);
+                const float l = clamp_sym(fmaf(-u, cr[c][5], lam[c][2]), lim);
                 const float dl = l - lam[c][2];
                 lam[c][2] = l;
                 lin[1] = fmaf(dl, inv_m, lin[1]);
@@ -562,10 +570,10 @@ LF_DEV void cube_substep(const lift_config &cfg, float h, const CubeConsts &K, c
                 if (row == 0) u = u + fv[k];
                 float l = fmaf(P.target[row] - u, P.meff[row], P.lam[row]);
                 if (row == 0) {
-                    l = l < 0.0f ? 0.0f : l;
+                    l = nonneg(l);
                 } else {
                     const float lim = (row == 3 ? cfg.mu_pad * K_TORSION_R : cfg.mu_pad) * P.lam[0];
-                    l = clampf(l, -lim, lim);
+                    l = clamp_sym(l, lim);
                 }
                 const float dl = l - P.lam[row];
                 P.lam[row] = l;
@@ -763,7 +771,8 @@ __global__ __launch_bounds__(64) void lift_reset_kernel(lift_config c, int n, in
 template <int LPE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void lift_step_kernel(
     lift_config c, int n, int env_id_offset, float *__restrict__ state, const float *__restrict__ action, float *__restrict__ obs,
-    float *__restrict__ reward, uint8_t *__restrict__ terminated, uint8_t *__restrict__ truncated, float *__restrict__ lg_out)
+    float *__restrict__ reward, uint8_t *__restrict__ terminated, uint8_t *__restrict__ truncated, float *lg_out,
+    unsigned *counters, float *__restrict__ log_out)
 {
     static_assert(LPE == 8 || LPE == 16, "eight lanes per env, optionally shadowed");
     constexpr float QDEF[9] = LF_Q_DEFAULT;
@@ -951,32 +960,56 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         reward[e] = total;
         terminated[e] = dropped ? 1 : 0;
         truncated[e] = time_out ? 1 : 0;
+        lg_out[(size_t)8 * n + e] = lg[8];                  // the reset flag of every env, every step
+        if (do_reset) {
 #pragma unroll
-        for (int i = 0; i < 10; ++i) lg_out[(size_t)i * n + e] = lg[i];
+            for (int i = 0; i < 8; ++i) lg_out[(size_t)i * n + e] = lg[i];
+            atomicAdd(&counters[1], 1u);
+        }
     }
-}
-
-// deterministic reduction of the per-env log contributions (10 x n) in a fixed order: one workgroup, strided partials
-__global__ __launch_bounds__(256) void lift_log_kernel(lift_config c, int n, const float *__restrict__ lg, float *__restrict__ log_out)
-{
-    __shared__ float part[10][256];
-    const int t = threadIdx.x;
-    for (int w = 0; w < 10; ++w) {
-        float acc = 0.0f;
-        for (int e = t; e < n; e += 256) acc += lg[(size_t)w * n + e];
-        part[w][t] = acc;
-    }
-    __syncthreads();
-    if (t < 10) {
-        float s = 0.0f;
-        for (int k = 0; k < 256; ++k) s += part[t][k];
-        part[t][0] = s;
-    }
-    __syncthreads();
-    if (t < 9) {
-        const float cnt = part[8][0];
-        if (t == 8) log_out[8] = cnt;
-        else if (cnt > 0.0f) log_out[t] = t < LIFT_NUM_REW ? part[t][0] / cnt / c.max_episode_length_s : part[t][0];
+    // ---- extras["log"]: the wave that finishes LAST reduces the contributions of the envs that reset in this step, in a
+    // fixed order (env e is summed by lane e % 64, lanes are combined by a fixed tree) => deterministic.  Nothing to do in
+    // the common case of a step without resets (one atomic per wave).  Replaces a second launch that cost as much as the
+    // step itself (a single workgroup walking 10 x n floats).
+    __threadfence();
+    unsigned ticket = 0;
+    if (lane == 0) ticket = atomicAdd(&counters[0], 1u);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket == gridDim.x - 1) {
+        __threadfence();
+        const unsigned resets = __hip_atomic_load(&counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (resets != 0u) {
+            float acc[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) acc[i] = 0.0f;
+            for (int j = lane; j < n; j += 64) {
+                const float flag = __hip_atomic_load(&lg_out[(size_t)8 * n + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (flag != 0.0f) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        acc[i] += __hip_atomic_load(&lg_out[(size_t)i * n + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    acc[8] += 1.0f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i)
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) acc[i] += __shfl_xor(acc[i], m, 64);
+            if (lane == 0) {
+                const float cnt = acc[8];
+#pragma unroll
+                for (int i = 0; i < LIFT_NUM_REW; ++i) log_out[i] = acc[i] / cnt / c.max_episode_length_s;
+                log_out[6] = acc[6];
+                log_out[7] = acc[7];
+                log_out[8] = cnt;
+            }
+        } else if (lane == 0) {
+            log_out[8] = 0.0f;
+        }
+        if (lane == 0) {
+            __hip_atomic_store(&counters[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&counters[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -1008,19 +1041,20 @@ struct rover_lift_sim {
     int n, env_id_offset, device;
     int lanes_per_env;      // 8; 16 (shadowed upper half-rows) is a measurement option
     float *state, *lg;
+    unsigned *counters;     // [0] waves finished, [1] envs reset in the step under way; both return to zero with every step
 };
 
 static void launch_step(rover_lift_sim *sim, hipStream_t st, const float *action, float *obs, float *reward, uint8_t *terminated,
-                        uint8_t *truncated)
+                        uint8_t *truncated, float *log)
 {
     const int lpe = sim->lanes_per_env, epw = 64 / lpe;
     const dim3 grid((sim->n + epw - 1) / epw), block(64);
     if (lpe == 16)
         hipLaunchKernelGGL(lift_step_kernel<16>, grid, block, 0, st, sim->cfg, sim->n, sim->env_id_offset, sim->state, action, obs, reward,
-                           terminated, truncated, sim->lg);
+                           terminated, truncated, sim->lg, sim->counters, log);
     else
         hipLaunchKernelGGL(lift_step_kernel<8>, grid, block, 0, st, sim->cfg, sim->n, sim->env_id_offset, sim->state, action, obs, reward,
-                           terminated, truncated, sim->lg);
+                           terminated, truncated, sim->lg, sim->counters, log);
 }
 
 extern "C" {
@@ -1084,13 +1118,19 @@ int rover_lift_create(const lift_config *cfg, int32_t num_envs, int32_t env_id_o
     return ROVER_OK;
 }
 int rover_lift_destroy(rover_lift_sim *sim) { delete sim; return ROVER_OK; }
-size_t rover_lift_workspace_bytes(const rover_lift_sim *sim) { return sim ? (size_t)sim->n * 10 * sizeof(float) : 0; }
+// per-env log contributions (9 x n floats, padded to 128 bytes) + two counters
+static size_t lift_lg_bytes(const rover_lift_sim *sim) { return (((size_t)sim->n * 9 * sizeof(float)) + 127) & ~(size_t)127; }
+size_t rover_lift_workspace_bytes(const rover_lift_sim *sim) { return sim ? lift_lg_bytes(sim) + 128 : 0; }
 int rover_lift_bind(rover_lift_sim *sim, float *state, void *workspace, size_t workspace_bytes)
 {
     if (!sim || !state || !workspace) return rover_internal_fail(ROVER_ERR_INVALID, "NULL argument");
     if (workspace_bytes < rover_lift_workspace_bytes(sim)) return rover_internal_fail(ROVER_ERR_INVALID, "workspace too small");
+    if (reinterpret_cast<uintptr_t>(workspace) & 127) return rover_internal_fail(ROVER_ERR_INVALID, "workspace must be 128-byte aligned");
+    DeviceGuardL guard(sim->device);
     sim->state = state;
     sim->lg = static_cast<float *>(workspace);
+    sim->counters = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + lift_lg_bytes(sim));
+    HIP_TRY(hipMemset(sim->counters, 0, 128));     // init-time, synchronous: the step kernel keeps them at zero afterwards
     return ROVER_OK;
 }
 int rover_lift_set_seed(rover_lift_sim *sim, uint32_t seed_lo, uint32_t seed_hi)
@@ -1126,16 +1166,15 @@ int rover_lift_step(rover_lift_sim *sim, const float *action, float *obs, float 
         return rover_internal_fail(ROVER_ERR_INVALID, "action / obs must be 16-byte aligned");
     DeviceGuardL guard(sim->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    launch_step(sim, st, action, obs, reward, terminated, truncated);
-    hipLaunchKernelGGL(lift_log_kernel, dim3(1), dim3(256), 0, st, sim->cfg, sim->n, sim->lg, log);
+    launch_step(sim, st, action, obs, reward, terminated, truncated, log);
     HIP_TRY(hipGetLastError());
     return ROVER_OK;
 }
 int rover_lift_profile_step(rover_lift_sim *sim, const float *action, float *obs, float *reward, uint8_t *terminated,
-                            uint8_t *truncated, float *log, void *stream, float *ms_step_kernel, float *ms_log_kernel)
+                            uint8_t *truncated, float *log, void *stream, float *ms_step_kernel, float *ms_event_overhead)
 {
     if (!sim || !sim->state) return rover_internal_fail(ROVER_ERR_STATE, "rover_lift_bind has not been called");
-    if (!action || !obs || !reward || !terminated || !truncated || !log || !ms_step_kernel || !ms_log_kernel)
+    if (!action || !obs || !reward || !terminated || !truncated || !log || !ms_step_kernel || !ms_event_overhead)
         return rover_internal_fail(ROVER_ERR_INVALID, "NULL buffer");
     if ((reinterpret_cast<uintptr_t>(action) & 15) || (reinterpret_cast<uintptr_t>(obs) & 15))
         return rover_internal_fail(ROVER_ERR_INVALID, "action / obs must be 16-byte aligned");
@@ -1144,13 +1183,12 @@ int rover_lift_profile_step(rover_lift_sim *sim, const float *action, float *obs
     hipEvent_t ev[3];
     for (int i = 0; i < 3; ++i) HIP_TRY(hipEventCreate(&ev[i]));
     HIP_TRY(hipEventRecord(ev[0], st));
-    launch_step(sim, st, action, obs, reward, terminated, truncated);
+    launch_step(sim, st, action, obs, reward, terminated, truncated, log);
     HIP_TRY(hipEventRecord(ev[1], st));
-    hipLaunchKernelGGL(lift_log_kernel, dim3(1), dim3(256), 0, st, sim->cfg, sim->n, sim->lg, log);
-    HIP_TRY(hipEventRecord(ev[2], st));
+    HIP_TRY(hipEventRecord(ev[2], st));              // empty pair: the fixed cost an event interval carries
     HIP_TRY(hipEventSynchronize(ev[2]));
     HIP_TRY(hipEventElapsedTime(ms_step_kernel, ev[0], ev[1]));
-    HIP_TRY(hipEventElapsedTime(ms_log_kernel, ev[1], ev[2]));
+    HIP_TRY(hipEventElapsedTime(ms_event_overhead, ev[1], ev[2]));
     for (int i = 0; i < 3; ++i) HIP_TRY(hipEventDestroy(ev[i]));
     HIP_TRY(hipGetLastError());
     return ROVER_OK;
