@@ -452,8 +452,8 @@ LF_DEV bool any_active(bool x)
 {
     return WAVE ? __builtin_amdgcn_ballot_w64(x) != 0ull : x;
 }
-template <bool WAVE>
-LF_DEV void cube_substep(const lift_config &cfg, float h, const CubeConsts &K, const HandPose &H, const float (&Rc)[3][3],
+template <bool WAVE, class CFG>
+LF_DEV void cube_substep(const CFG &cfg, float h, const CubeConsts &K, const HandPose &H, const float (&Rc)[3][3],
                          const float (&cr)[8][8], const float *finger_target, float *fq, float *fqd, float *pos, float *quat, float *lin,
                          float *ang)
 {
@@ -484,9 +484,16 @@ LF_DEV void cube_substep(const lift_config &cfg, float h, const CubeConsts &K, c
             const float gap = fq[k] - (fmaf(sgn, cl[1], ext));
             PadRows &P = pd[k];
             P.active = between && gap < K_PAD_MARGIN;
-            // The rows of a pad nobody touches are never read: form them only when some env of the wave needs them
-            // (random actions: almost never -- ~150 instructions per pad and substep).
-            if (!any_active<WAVE>(P.active)) continue;
+        }
+        // The rows of pads nobody touches are never read: form them only when some env of the wave is being grasped
+        // (random actions: almost never -- ~150 instructions per pad and substep).
+        const bool form_pads = any_active<WAVE>(pd[0].active || pd[1].active);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (!form_pads) continue;
+            const float sgn = k == 0 ? 1.0f : -1.0f;
+            const float gap = fq[k] - (fmaf(sgn, cl[1], ext));
+            PadRows &P = pd[k];
             float arm[3], r[3], vpad[3], t[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -522,47 +529,52 @@ LF_DEV void cube_substep(const lift_config &cfg, float h, const CubeConsts &K, c
 #pragma unroll
     for (int c = 0; c < 8; ++c) lam[c][0] = lam[c][1] = lam[c][2] = 0.0f;
     const float inv_m = K.inv_m, inv_I = K.inv_I;
-    for (int it = 0; it < cfg.solver_iterations; ++it) {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            if (!any_active<WAVE>(cr[c][7] != 0.0f)) continue;
-            const float r0 = cr[c][0], r1 = cr[c][1], r2 = cr[c][2];
-            {
-                const float u = lin[2] + fmaf(r1, ang[0], -(r0 * ang[1]));
-                const float l = nonneg(fmaf(cr[c][6] - u, cr[c][3], lam[c][0]));
-                const float dl = l - lam[c][0];
-                lam[c][0] = l;
-                lin[2] = fmaf(dl, inv_m, lin[2]);
-                const float di = dl * inv_I;
-                ang[0] = fmaf(r1, di, ang[0]);
-                ang[1] = fmaf(-r0, di, ang[1]);
-            }
-            const float lim = cfg.mu_table * lam[c][0];
-            {
-                const float u = lin[0] + fmaf(r2, ang[1], -(r1 * ang[2]));
-                const float l = clamp_sym(fmaf(-u, cr[c][4], lam[c][1]), lim);
-                const float dl = l - lam[c][1];
-                lam[c][1] = l;
-                lin[0] = fmaf(dl, inv_m, lin[0]);
-                const float di = dl * inv_I;
-                ang[1] = fmaf(r2, di, ang[1]);
-                ang[2] = fmaf(-r1, di, ang[2]);
-            }
-            {
-                const float u = lin[1] + fmaf(r0, ang[2], -(r2 * ang[0]));
-                const float l = clamp_sym(fmaf(-u, cr[c][5], lam[c][2]), lim);
-                const float dl = l - lam[c][2];
-                lam[c][2] = l;
-                lin[1] = fmaf(dl, inv_m, lin[1]);
-                const float di = dl * inv_I;
-                ang[2] = fmaf(r0, di, ang[2]);
-                ang[0] = fmaf(-r2, di, ang[0]);
-            }
+    // Which row sets this wave has to sweep does not change during the iterations: decided ONCE, wave-uniformly, per face
+    // of the cube (corners 0..3 = the -z face, 4..7 = the +z face) and for the two pads together.  A row set that is swept
+    // although the env's own rows are inactive has zero effective masses = exact no-ops, so the result is the one the
+    // oracle gets by skipping inactive rows one by one.  (A test per corner inside the loop cost ten VALU -> branch round
+    // trips per iteration: 12.5 k of the kernel's 60 k cycles went into sweeps of ~1.4 k instructions.)
+    const bool sweep_lo = any_active<WAVE>(cr[0][7] != 0.0f || cr[1][7] != 0.0f || cr[2][7] != 0.0f || cr[3][7] != 0.0f);
+    const bool sweep_hi = any_active<WAVE>(cr[4][7] != 0.0f || cr[5][7] != 0.0f || cr[6][7] != 0.0f || cr[7][7] != 0.0f);
+    const bool sweep_pads = any_active<WAVE>(pd[0].active || pd[1].active);
+    auto corner = [&](int c) {
+        const float r0 = cr[c][0], r1 = cr[c][1], r2 = cr[c][2];
+        {
+            const float u = lin[2] + fmaf(r1, ang[0], -(r0 * ang[1]));
+            const float l = nonneg(fmaf(cr[c][6] - u, cr[c][3], lam[c][0]));
+            const float dl = l - lam[c][0];
+            lam[c][0] = l;
+            lin[2] = fmaf(dl, inv_m, lin[2]);
+            const float di = dl * inv_I;
+            ang[0] = fmaf(r1, di, ang[0]);
+            ang[1] = fmaf(-r0, di, ang[1]);
         }
+        const float lim = cfg.mu_table * lam[c][0];
+        {
+            const float u = lin[0] + fmaf(r2, ang[1], -(r1 * ang[2]));
+            const float l = clamp_sym(fmaf(-u, cr[c][4], lam[c][1]), lim);
+            const float dl = l - lam[c][1];
+            lam[c][1] = l;
+            lin[0] = fmaf(dl, inv_m, lin[0]);
+            const float di = dl * inv_I;
+            ang[1] = fmaf(r2, di, ang[1]);
+            ang[2] = fmaf(-r1, di, ang[2]);
+        }
+        {
+            const float u = lin[1] + fmaf(r0, ang[2], -(r2 * ang[0]));
+            const float l = clamp_sym(fmaf(-u, cr[c][5], lam[c][2]), lim);
+            const float dl = l - lam[c][2];
+            lam[c][2] = l;
+            lin[1] = fmaf(dl, inv_m, lin[1]);
+            const float di = dl * inv_I;
+            ang[2] = fmaf(r0, di, ang[2]);
+            ang[0] = fmaf(-r2, di, ang[0]);
+        }
+    };
+    auto pads = [&]() {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             PadRows &P = pd[k];
-            if (!any_active<WAVE>(P.active)) continue;
 #pragma unroll
             for (int row = 0; row < 4; ++row) {
                 float u = dot3(P.rxn[row], ang);
@@ -586,6 +598,31 @@ LF_DEV void cube_substep(const lift_config &cfg, float h, const CubeConsts &K, c
                 for (int i = 0; i < 3; ++i) ang[i] = fmaf(P.rxn[row][i], di, ang[i]);
                 if (row == 0) fv[k] = fmaf(dl, K.f_minv, fv[k]);
             }
+        }
+    };
+    // two copies of the iteration loop: the pad rows (66 registers) are only alive in the one that sweeps them
+    if (!sweep_pads) {
+        for (int it = 0; it < cfg.solver_iterations; ++it) {
+            if (sweep_lo) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) corner(c);
+            }
+            if (sweep_hi) {
+#pragma unroll
+                for (int c = 4; c < 8; ++c) corner(c);
+            }
+        }
+    } else {
+        for (int it = 0; it < cfg.solver_iterations; ++it) {
+            if (sweep_lo) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) corner(c);
+            }
+            if (sweep_hi) {
+#pragma unroll
+                for (int c = 4; c < 8; ++c) corner(c);
+            }
+            pads();
         }
     }
 #pragma unroll
@@ -749,6 +786,22 @@ __device__ __forceinline__ float pick8(const float *v, const uint32_t *sel)
     return u2f(r);
 }
 
+// s_memtime phase stamps of wave 0 of every workgroup: diagnostic builds only (tools/build_diag.py LIFTSTAMP, tools/lift_stamps.py)
+#ifdef LF_STAMP
+__device__ unsigned long long *g_lift_stamps;
+__device__ __forceinline__ void lift_stamp(int slot)
+{
+    if (threadIdx.x == 0) {
+        unsigned long long t;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        g_lift_stamps[(size_t)blockIdx.x * 32 + slot] = t;
+    }
+}
+#define LIFT_STAMP(k) lift_stamp(k)
+#else
+#define LIFT_STAMP(k) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------------- kernels
 __global__ __launch_bounds__(64) void lift_reset_kernel(lift_config c, int n, int env_id_offset, float *__restrict__ state,
                                                         float *__restrict__ obs)
@@ -767,12 +820,27 @@ __global__ __launch_bounds__(64) void lift_reset_kernel(lift_config c, int n, in
     for (int i = 0; i < LIFT_OBS; ++i) obs[(size_t)e * LIFT_OBS + i] = o[i];
 }
 
+// The configuration words the substep loop reads, by value (kernel argument SGPRs).  Everything else of lift_config
+// (reward weights, ranges, seeds ...) is read from a device copy at the point of use, after the substeps: as kernel
+// arguments those ~27 words would stay live in SGPRs through the whole kernel and push other scalars into spill lanes.
+struct LiftHot {
+    float sim_dt;
+    int32_t decimation, solver_iterations;
+    float mu_table, mu_pad, ee_offset_z, action_scale, finger_open, finger_close;
+};
+static LiftHot hot_of(const lift_config &c)
+{
+    return LiftHot{c.sim_dt, c.decimation, c.solver_iterations, c.mu_table, c.mu_pad, c.ee_offset_z, c.action_scale, c.finger_open,
+                   c.finger_close};
+}
+
 // RLTaskEnv.step of FrankaCubeLift-v0, LPE lanes per env (8, or 16 with lanes 8..15 of a row shadowing lanes 0..7).
 template <int LPE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void lift_step_kernel(
-    lift_config c, int n, int env_id_offset, float *__restrict__ state, const float *__restrict__ action, float *__restrict__ obs,
-    float *__restrict__ reward, uint8_t *__restrict__ terminated, uint8_t *__restrict__ truncated, float *lg_out,
-    unsigned *counters, float *__restrict__ log_out)
+    LiftHot hc, const lift_config *__restrict__ cfg_dev, int n, int env_id_offset, float *__restrict__ state,
+    const float *__restrict__ action, float *__restrict__ obs,
+    float *__restrict__ reward, uint8_t *__restrict__ terminated, uint8_t *__restrict__ truncated, float *__restrict__ lg_out,
+    unsigned *__restrict__ counters)
 {
     static_assert(LPE == 8 || LPE == 16, "eight lanes per env, optionally shadowed");
     constexpr float QDEF[9] = LF_Q_DEFAULT;
@@ -789,12 +857,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     // State I/O is lane-distributed: lane r of an env moves the words r, r + 8, ..., r + 56 (one wave instruction moves 64
     // DIFFERENT words: 8 envs x 8 consecutive words) and the lanes exchange them through the LDS slot.  The physics half
     // (words 0 .. 31: joints, cube) is loaded now, the manager half (command, timers, actions, episodic sums) only after the
-    // substeps -- it would otherwise sit in registers through the solver.
+    // substeps -- replicated it would sit in 32 registers through the solver; distributed it is 4 (loaded up front).
     const unsigned lane_off = ((unsigned)role * (unsigned)n + (unsigned)e) * 4u;      // byte offset of word `role` of env e
     auto column = [&](float *base, int k) -> float & {                                 // word 8 k + role of env e
         return *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + (size_t)(8 * k) * (size_t)(unsigned)n * 4u + lane_off);
     };
-    float S[LIFT_STATE_WORDS];
+    float S[LIFT_STATE_WORDS], late[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) late[k] = column(state, 4 + k);      // in flight during the physics, exchanged after it
     {
         float mine[4], all[8][4];
 #pragma unroll
@@ -805,17 +875,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
             for (int r = 0; r < 8; ++r) S[8 * k + r] = all[r][k];
     }
-    float target[7], finger_target[2];
+    float target[7], finger_target[2], a[LIFT_ACT];
     {   // JointPositionAction (:35-37), BinaryJointPositionAction (:38-43)
         const float4 a0 = reinterpret_cast<const float4 *>(action + (size_t)e * LIFT_ACT)[0];
         const float4 a1 = reinterpret_cast<const float4 *>(action + (size_t)e * LIFT_ACT)[1];
-        const float a[LIFT_ACT] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
 #pragma unroll
-        for (int i = 0; i < 7; ++i) target[i] = QDEF[i] + c.action_scale * a[i];
-        finger_target[0] = finger_target[1] = a[7] < 0.0f ? c.finger_close : c.finger_open;
+        for (int i = 0; i < 7; ++i) target[i] = QDEF[i] + hc.action_scale * a[i];
+        finger_target[0] = finger_target[1] = a[7] < 0.0f ? hc.finger_close : hc.finger_open;
     }
 
-    const float h = c.sim_dt;
+    const float h = hc.sim_dt;
     const CubeConsts K = cube_consts(h);
     // one-hot lane masks in VGPRs: sel[i] = ~0 in the lane with role i (pass i of the inverse dynamics / joint i / corner i)
     uint32_t sel[8];
@@ -833,9 +903,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
         for (int i = 0; i < 8; ++i) { sn[i] = all[i][0]; cs[i] = all[i][1]; }
     };
+    LIFT_STAMP(0);
     joint_trig();
     HandPose hand;
-    for (int s = 0; s < c.decimation; ++s) {
+    LIFT_STAMP(1);
+    for (int s = 0; s < hc.decimation; ++s) {
         // ---- arm: pass `role` of the eight inverse-dynamics passes, exchanged, then the replicated 7 x 7 solve
         {
             float qd_l[7], qdd_l[7], tau[8], cols[8][8];
@@ -843,11 +915,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             for (int i = 0; i < 7; ++i) { qd_l[i] = u2f(f2u(qd[i]) & sel[7]); qdd_l[i] = u2f(0x3f800000u & sel[i]); }
             newton_euler(sn, cs, qd_l, qdd_l, u2f(f2u(K_GRAV) & sel[7]), tau);
             tau[7] = 0.0f;
+            LIFT_STAMP(2 + 6 * (s & 1));
             gather8<8>(xbuf, slot, role, shadow, tau, cols);
             arm_solve_integrate<true>(h, cols, target, q, qd);
         }
+        LIFT_STAMP(3 + 6 * (s & 1));
         joint_trig();
-        hand_kinematics(sn, cs, qd, c.ee_offset_z, hand);
+        hand_kinematics(sn, cs, qd, hc.ee_offset_z, hand);
+        LIFT_STAMP(4 + 6 * (s & 1));
         // ---- cube: gravity, rows of corner `role`, exchanged, then the replicated Gauss-Seidel sweeps
         {
             float *pos = S + LIFT_OBJ_POS, *quat = S + LIFT_OBJ_QUAT, *lin = S + LIFT_OBJ_LIN, *ang = S + LIFT_OBJ_ANG;
@@ -856,30 +931,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             quat_to_matrix(quat, Rc);
             corner_rows(role, Rc, pos[2], K, mine);      // corner index = role: three per-lane sign selects, uniform code otherwise
             gather8<8>(xbuf, slot, role, shadow, mine, cr);
-            cube_substep<true>(c, h, K, hand, Rc, cr, finger_target, q + 7, qd + 7, pos, quat, lin, ang);
+            LIFT_STAMP(5 + 6 * (s & 1));
+            cube_substep<true>(hc, h, K, hand, Rc, cr, finger_target, q + 7, qd + 7, pos, quat, lin, ang);
         }
+        LIFT_STAMP(7 + 6 * (s & 1));
     }
-    if (c.decimation <= 0) hand_kinematics(sn, cs, qd, c.ee_offset_z, hand);
+    if (hc.decimation <= 0) hand_kinematics(sn, cs, qd, hc.ee_offset_z, hand);
 
     // ---- manager words; ActionManager.process_action (prev_action <- action <- the raw action)
     {
-        float mine[4], all[8][4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) mine[k] = column(state, 4 + k);
-        gather8<4>(xbuf, slot, role, shadow, mine, all);
+        float all[8][4];
+        gather8<4>(xbuf, slot, role, shadow, late, all);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
             for (int r = 0; r < 8; ++r) S[32 + 8 * k + r] = all[r][k];
     }
-    {
-        const float4 a0 = reinterpret_cast<const float4 *>(action + (size_t)e * LIFT_ACT)[0];
-        const float4 a1 = reinterpret_cast<const float4 *>(action + (size_t)e * LIFT_ACT)[1];
-        const float a[LIFT_ACT] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
-        for (int i = 0; i < LIFT_ACT; ++i) { S[LIFT_PREV_ACTION + i] = S[LIFT_ACTION + i]; S[LIFT_ACTION + i] = a[i]; }
-    }
-    // ---- counters, terminations, rewards (replicated in the eight lanes)
+    for (int i = 0; i < LIFT_ACT; ++i) { S[LIFT_PREV_ACTION + i] = S[LIFT_ACTION + i]; S[LIFT_ACTION + i] = a[i]; }
+    LIFT_STAMP(14);
+    // ---- counters, terminations, rewards (replicated in the eight lanes); from here on `c` is the full configuration
+    const lift_config &c = *cfg_dev;
     const int32_t ep_len = (int32_t)f2u(S[LIFT_EP_LEN]) + 1;
     S[LIFT_EP_LEN] = u2f((uint32_t)ep_len);
     const float root_pos[3] = {0.0f, 0.0f, 0.0f}, root_quat[4] = {1.0f, 0.0f, 0.0f, 0.0f};
@@ -905,6 +977,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         }
     }
     const bool do_reset = time_out || dropped;
+    LIFT_STAMP(15);
     float lg[10];
 #pragma unroll
     for (int i = 0; i < 10; ++i) lg[i] = 0.0f;
@@ -932,6 +1005,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
         for (int i = LIFT_CMD; i <= LIFT_TIME_LEFT; ++i) S[i] = resample ? R[i] : S[i];
     }
+    LIFT_STAMP(16);
     // ---- stores.  State: lane 0 lays the 64 words out transposed in the LDS slot ([word % 8][word / 8]), every lane picks
     // up its eight words with two 16-byte reads and stores them (64 different words per wave instruction again).
     {
@@ -967,49 +1041,52 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             atomicAdd(&counters[1], 1u);
         }
     }
-    // ---- extras["log"]: the wave that finishes LAST reduces the contributions of the envs that reset in this step, in a
-    // fixed order (env e is summed by lane e % 64, lanes are combined by a fixed tree) => deterministic.  Nothing to do in
-    // the common case of a step without resets (one atomic per wave).  Replaces a second launch that cost as much as the
-    // step itself (a single workgroup walking 10 x n floats).
-    __threadfence();
-    unsigned ticket = 0;
-    if (lane == 0) ticket = atomicAdd(&counters[0], 1u);
-    ticket = __builtin_amdgcn_readfirstlane(ticket);
-    if (ticket == gridDim.x - 1) {
-        __threadfence();
-        const unsigned resets = __hip_atomic_load(&counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (resets != 0u) {
-            float acc[9];
+    LIFT_STAMP(17);
+}
+
+// extras["log"] of a step: means over the envs that reset in it.  One workgroup; when nobody reset -- the common case -- it
+// reads one counter and leaves (the launch then costs its ~2 us of dispatch, nothing else).  Otherwise a fixed-order
+// reduction: env e is summed by thread e % 1024, the threads are combined by a fixed tree => deterministic.
+// (Measured alternatives: the round-2 form, one workgroup walking all 10 x n floats every step, took 21 us -- as long as
+// the step kernel; folding the reduction into the step kernel behind a "last wave" ticket cost ~5 us per step, because an
+// agent-scope release on this multi-XCD part is an L2 write-back and every wave waits for its atomic's round trip.)
+__global__ __launch_bounds__(1024) void lift_log_kernel(lift_config c, int n, const float *__restrict__ lg, unsigned *counters,
+                                                        float *__restrict__ log_out)
+{
+    __shared__ float part[9][1024];
+    const int t = threadIdx.x;
+    if (counters[1] == 0u) {
+        if (t == 0) log_out[8] = 0.0f;
+        return;
+    }
+    float acc[9];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) acc[i] = 0.0f;
-            for (int j = lane; j < n; j += 64) {
-                const float flag = __hip_atomic_load(&lg_out[(size_t)8 * n + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (flag != 0.0f) {
+    for (int i = 0; i < 9; ++i) acc[i] = 0.0f;
+    for (int e = t; e < n; e += 1024) {
+        if (lg[(size_t)8 * n + e] != 0.0f) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        acc[i] += __hip_atomic_load(&lg_out[(size_t)i * n + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    acc[8] += 1.0f;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 9; ++i)
-#pragma unroll
-                for (int m = 32; m >= 1; m >>= 1) acc[i] += __shfl_xor(acc[i], m, 64);
-            if (lane == 0) {
-                const float cnt = acc[8];
-#pragma unroll
-                for (int i = 0; i < LIFT_NUM_REW; ++i) log_out[i] = acc[i] / cnt / c.max_episode_length_s;
-                log_out[6] = acc[6];
-                log_out[7] = acc[7];
-                log_out[8] = cnt;
-            }
-        } else if (lane == 0) {
-            log_out[8] = 0.0f;
+            for (int i = 0; i < 8; ++i) acc[i] += lg[(size_t)i * n + e];
+            acc[8] += 1.0f;
         }
-        if (lane == 0) {
-            __hip_atomic_store(&counters[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&counters[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) part[i][t] = acc[i];
+    __syncthreads();
+    for (int m = 512; m >= 1; m >>= 1) {
+        if (t < m) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) part[i][t] += part[i][t + m];
         }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const float cnt = part[8][0];
+#pragma unroll
+        for (int i = 0; i < LIFT_NUM_REW; ++i) log_out[i] = part[i][0] / cnt / c.max_episode_length_s;
+        log_out[6] = part[6][0];
+        log_out[7] = part[7][0];
+        log_out[8] = cnt;
+        counters[1] = 0u;
     }
 }
 
@@ -1041,20 +1118,29 @@ struct rover_lift_sim {
     int n, env_id_offset, device;
     int lanes_per_env;      // 8; 16 (shadowed upper half-rows) is a measurement option
     float *state, *lg;
-    unsigned *counters;     // [0] waves finished, [1] envs reset in the step under way; both return to zero with every step
+    unsigned *counters;     // [1] envs reset in the step under way (cleared by the log kernel)
+    lift_config *cfg_dev;   // device copy of cfg (in the workspace), read by the tail of the step kernel
+    bool cfg_dirty;         // host copy changed (rover_lift_set_seed): copy it over before the next launch
 };
 
 static void launch_step(rover_lift_sim *sim, hipStream_t st, const float *action, float *obs, float *reward, uint8_t *terminated,
                         uint8_t *truncated, float *log)
 {
+    if (sim->cfg_dirty) {       // rare (re-seeding): ordered on the launch stream, before the kernel that reads it
+        (void)hipMemcpyAsync(sim->cfg_dev, &sim->cfg, sizeof(lift_config), hipMemcpyHostToDevice, st);
+        (void)hipStreamSynchronize(st);   // the source is the handle's own field: do not let a later set_seed race the copy
+        sim->cfg_dirty = false;
+    }
+    const LiftHot hc = hot_of(sim->cfg);
     const int lpe = sim->lanes_per_env, epw = 64 / lpe;
     const dim3 grid((sim->n + epw - 1) / epw), block(64);
     if (lpe == 16)
-        hipLaunchKernelGGL(lift_step_kernel<16>, grid, block, 0, st, sim->cfg, sim->n, sim->env_id_offset, sim->state, action, obs, reward,
-                           terminated, truncated, sim->lg, sim->counters, log);
+        hipLaunchKernelGGL(lift_step_kernel<16>, grid, block, 0, st, hc, sim->cfg_dev, sim->n, sim->env_id_offset, sim->state, action, obs,
+                           reward, terminated, truncated, sim->lg, sim->counters);
     else
-        hipLaunchKernelGGL(lift_step_kernel<8>, grid, block, 0, st, sim->cfg, sim->n, sim->env_id_offset, sim->state, action, obs, reward,
-                           terminated, truncated, sim->lg, sim->counters, log);
+        hipLaunchKernelGGL(lift_step_kernel<8>, grid, block, 0, st, hc, sim->cfg_dev, sim->n, sim->env_id_offset, sim->state, action, obs,
+                           reward, terminated, truncated, sim->lg, sim->counters);
+    hipLaunchKernelGGL(lift_log_kernel, dim3(1), dim3(1024), 0, st, sim->cfg, sim->n, sim->lg, sim->counters, log);
 }
 
 extern "C" {
@@ -1113,14 +1199,15 @@ int rover_lift_create(const lift_config *cfg, int32_t num_envs, int32_t env_id_o
     rover_lift_sim *s = new (std::nothrow) rover_lift_sim();
     if (!s) return rover_internal_fail(ROVER_ERR_INVALID, "out of host memory");
     s->cfg = *cfg; s->n = num_envs; s->env_id_offset = env_id_offset; s->device = device; s->state = nullptr; s->lg = nullptr;
-    s->lanes_per_env = 8;
+    s->lanes_per_env = 8; s->counters = nullptr; s->cfg_dev = nullptr; s->cfg_dirty = false;
     *out = s;
     return ROVER_OK;
 }
 int rover_lift_destroy(rover_lift_sim *sim) { delete sim; return ROVER_OK; }
 // per-env log contributions (9 x n floats, padded to 128 bytes) + two counters
 static size_t lift_lg_bytes(const rover_lift_sim *sim) { return (((size_t)sim->n * 9 * sizeof(float)) + 127) & ~(size_t)127; }
-size_t rover_lift_workspace_bytes(const rover_lift_sim *sim) { return sim ? lift_lg_bytes(sim) + 128 : 0; }
+// ... + 128 bytes of counters + a device copy of the configuration
+size_t rover_lift_workspace_bytes(const rover_lift_sim *sim) { return sim ? lift_lg_bytes(sim) + 128 + ((sizeof(lift_config) + 127) & ~(size_t)127) : 0; }
 int rover_lift_bind(rover_lift_sim *sim, float *state, void *workspace, size_t workspace_bytes)
 {
     if (!sim || !state || !workspace) return rover_internal_fail(ROVER_ERR_INVALID, "NULL argument");
@@ -1130,7 +1217,10 @@ int rover_lift_bind(rover_lift_sim *sim, float *state, void *workspace, size_t w
     sim->state = state;
     sim->lg = static_cast<float *>(workspace);
     sim->counters = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + lift_lg_bytes(sim));
-    HIP_TRY(hipMemset(sim->counters, 0, 128));     // init-time, synchronous: the step kernel keeps them at zero afterwards
+    sim->cfg_dev = reinterpret_cast<lift_config *>(static_cast<char *>(workspace) + lift_lg_bytes(sim) + 128);
+    HIP_TRY(hipMemset(sim->counters, 0, 128));     // init-time, synchronous: the log kernel keeps them at zero afterwards
+    HIP_TRY(hipMemcpy(sim->cfg_dev, &sim->cfg, sizeof(lift_config), hipMemcpyHostToDevice));
+    sim->cfg_dirty = false;
     return ROVER_OK;
 }
 int rover_lift_set_seed(rover_lift_sim *sim, uint32_t seed_lo, uint32_t seed_hi)
@@ -1138,6 +1228,7 @@ int rover_lift_set_seed(rover_lift_sim *sim, uint32_t seed_lo, uint32_t seed_hi)
     if (!sim) return rover_internal_fail(ROVER_ERR_INVALID, "sim is NULL");
     sim->cfg.seed_lo = seed_lo;
     sim->cfg.seed_hi = seed_hi;
+    sim->cfg_dirty = true;
     return ROVER_OK;
 }
 // measurement hook (tools/lift_time.py): lanes per env of the step kernel, 8 (default) or 16
@@ -1147,6 +1238,12 @@ int rover_lift_debug_set_lanes(rover_lift_sim *sim, int lanes)
     sim->lanes_per_env = lanes;
     return ROVER_OK;
 }
+#ifdef LF_STAMP
+int rover_lift_debug_set_stamps(void *buf)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_lift_stamps), &buf, sizeof(buf)) == hipSuccess ? ROVER_OK : ROVER_ERR_HIP;
+}
+#endif
 int rover_lift_reset(rover_lift_sim *sim, float *obs, void *stream)
 {
     if (!sim || !sim->state) return rover_internal_fail(ROVER_ERR_STATE, "rover_lift_bind has not been called");

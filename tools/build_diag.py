@@ -5,6 +5,7 @@
     STAMP     -DRV_K2_STAMP   s_memtime phase stamps in the scan kernel        (tools/k2_stamps.py)
     K1STAMP   -DRV_K1_STAMP   s_memtime phase stamps in the group step kernel  (tools/k1_stamps.py)
     POLSTAMP  -DPOL_STAMP     s_memtime phase stamps in the policy kernel      (tools/policy_stamps.py)
+    LIFTSTAMP -DLF_STAMP      s_memtime phase stamps in the lift step kernel   (tools/lift_stamps.py)
 
     python tools/build_diag.py [STAMP K1STAMP POLSTAMP]
 """
@@ -18,7 +19,7 @@ from isaac_rover_orbit_amd import build as b  # noqa: E402
 
 VARIANTS = {"STAMP": ("rover_kernels.hip", "-DRV_K2_STAMP"), "K1STAMP": ("rover_kernels.hip", "-DRV_K1_STAMP"),
             "K1STAMP_INK": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_K1_CONSTS_IN_KERNEL"),
-            "LIFT_NOARM": ("lift_kernels.hip", "-DLM_ABL_NO_ARM"), "LIFT_NOCUBE": ("lift_kernels.hip", "-DLM_ABL_NO_CUBE"),
+            "LIFTSTAMP": ("lift_kernels.hip", "-DLF_STAMP"),
             "NOCOPY": ("rover_kernels.hip", "-DRV_K2_NO_COPY"),
             "NORAYS": ("rover_kernels.hip", "-DRV_K2_NO_RAYS"), "NOCOPYRAYS": ("rover_kernels.hip", "-DRV_K2_NO_RAYS -DRV_K2_NO_COPY"),
             "K1_INK": ("rover_kernels.hip", "-DRV_K1_CONSTS_IN_KERNEL"),
