@@ -523,6 +523,36 @@ __device__ __forceinline__ float row_coupling(const StepConsts &k, const RowQ &a
     return RV_SPLIT_C * wdot3x(a.ja, b.ja, k.inv_I) + RV_SPLIT_B * (a.jb * b.jb * b_winv);
 }
 __device__ __forceinline__ float dpp_ror8(float x);
+// Contact report of a LINK body (bogie / steer link; articulation.py:13-27 adds the obstacle mesh as report pair of every
+// sensor body): vertical penalty force at one sample point p0 (body frame, zero bogie angle) that rides on the bogie with
+// pivot P / axis ax at angle bq -- non-zero when the point is below the terrain surface where the obstacle layer is present.
+// Report only (collision_with_obstacles ends the episode in the same step): the dynamics do not see it.
+__device__ __forceinline__ float link_point_force(const RvParams &p, const float R[3][3], const float *pos, const float *P,
+                                                  const float *ax, float bq, const float *p0)
+{
+    float sb, cb;
+    if (fabsf(bq) < 0.75f) rv_sincosf_small(bq, &sb, &cb);
+    else rv_sincosf(bq, &sb, &cb);
+    const float d0[3] = {p0[0] - P[0], p0[1] - P[1], p0[2] - P[2]};
+    float axd[3], pt_b[3], tmp[3];
+    cross3f(ax, d0, axd);
+    const float ad = dot3f(ax, d0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pt_b[i] = P[i] + fmaf(ax[i], ad * (1.0f - cb), fmaf(axd[i], sb, d0[i] * cb));
+    mat_vecf(R, pt_b, tmp);
+    float hgt, gx, gy, obst = 0.0f;
+    terrain_sample<true>(p, pos[0] + tmp[0], pos[1] + tmp[1], hgt, gx, gy, obst);
+    const float pen = hgt - (pos[2] + tmp[2]);
+    return (obst > RV_OBSTACLE_EPS && pen > 0.0f) ? RV_LINK_STIFFNESS * pen : 0.0f;
+}
+// z rows of the seven link bodies from the twelve point forces lf[slot][role]: fixed summation order
+__device__ __forceinline__ void link_body_forces(const float lf[6][2], float *Fz /* 7 */)
+{
+    Fz[0] = (lf[0][1] + lf[1][0]) + lf[1][1];   // FL_Boogie
+    Fz[1] = (lf[2][1] + lf[3][0]) + lf[3][1];   // FR_Boogie
+    Fz[2] = lf[4][1] + lf[5][1];                // R_Boogie
+    Fz[3] = lf[0][0]; Fz[4] = lf[2][0]; Fz[5] = lf[4][0]; Fz[6] = lf[5][0];   // FL, FR, RL, RR steer
+}
 // contact geometry, Jacobians, split effective masses and bias of ONE wheel.  GROUP_ROLE: the 16-lanes-per-env mapping, where
 // the two role lanes of a wheel slot share the row work: role A derives the normal row, role B the longitudinal one, both
 // the lateral one, and one row_ror:8 exchange hands each lane the row it did not compute (same arithmetic per quantity).
@@ -850,6 +880,24 @@ __device__ __forceinline__ void physics_substep(const RvParams &p, const StepCon
             }
         }
     }
+    if (RECORD_FORCE) {   // link bodies (bogies, steer links): pose of the substep's start, like the wheel rows
+        constexpr float LINK_POINT[6][2][3] = RV_LINK_POINT_INIT;
+        float lf[6][2], Fz[7];
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            const int j = s >> 1;
+            const float P[3] = {BOGIE_PIVOT[j][0], BOGIE_PIVOT[j][1], BOGIE_PIVOT[j][2]};
+            const float ax[3] = {BOGIE_AXIS[j][0], BOGIE_AXIS[j][1], BOGIE_AXIS[j][2]};
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float p0[3] = {LINK_POINT[s][r][0], LINK_POINT[s][r][1], LINK_POINT[s][r][2]};
+                lf[s][r] = link_point_force(p, R, S + ROVER_POS, P, ax, bq[j], p0);
+            }
+        }
+        link_body_forces(lf, Fz);
+#pragma unroll
+        for (int b = 0; b < 7; ++b) F[b * 3 + 2] = Fz[b];
+    }
     // ---- 7. integrate
     chassis_integrate(h, R, v, w, com_w, S + ROVER_POS, S + ROVER_QUAT, S + ROVER_LINVEL, S + ROVER_ANGVEL);
 #pragma unroll
@@ -868,6 +916,7 @@ struct GroupLane {
     float steer_t, wheel_t;
     // constants of this lane's slot
     float P[3], ax[3], b_winv, bogie_keep;
+    float lp[3];   // this lane's link-body sample point
     ArmConsts arm;
     f2 minv0, minv1;  // inverse mass pairs of the lane's two channels (negated in idle slot 7, see physics_substep_group)
     bool steerable, wheel_active, role_b;
@@ -1034,7 +1083,8 @@ __device__ __forceinline__ void solver_iterations_group(const StepConsts &K, Con
 
 template <bool RECORD_FORCE>
 __device__ __forceinline__ void physics_substep_group(const RvParams &p, const StepConsts &K, GroupLane &g,
-                                                      float *Fw /* 3: this wheel's force */, int sidx = 0)
+                                                      float *Fw /* 3: this wheel's force, [3]: this lane's link-point force */,
+                                                      int sidx = 0)
 {
     K1_STAMP(2 + 3 * sidx);
     constexpr float COM_B[3] = RV_COM_B_INIT;
@@ -1056,6 +1106,7 @@ __device__ __forceinline__ void physics_substep_group(const RvParams &p, const S
     const bool at_hi = bq >= RV_BOGIE_QLIM - 1.0e-5f, at_lo = bq <= -RV_BOGIE_QLIM + 1.0e-5f;
     Contact ct;
     wheel_geometry<RECORD_FORCE, true>(p, K, R, g.pos, com_w, g.arm, g.P, g.ax, g.b_winv, bq, at_hi, at_lo, g.steerable, g.sq, ct, g.role_b);
+    if (RECORD_FORCE) Fw[3] = link_point_force(p, R, g.pos, g.P, g.ax, bq, g.lp);   // pose of the substep's start, like the wheel rows
     K1_STAMP(3 + 3 * sidx);
     ct.ln = RV_WARM_START * g.lam;
     ct.lt = 0.0f;
@@ -1395,10 +1446,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 struct SlotConst {
     float wb[3], P[3], ax[3];
     int32_t k, j, si, body;   // wheel, bogie, steer joint (-1: none), contact-sensor body row
-    int32_t pad[3];
+    float lp[2][3];           // link-body sample point of the role-A / role-B lane (RV_LINK_POINT_INIT)
+    int32_t pad;
 };
-#define RV_SLOT_ROW(k_, j_, si_, body_) \
-    {{RV_WB_##k_}, {RV_BP_##j_}, {RV_BA_##j_}, k_, j_, si_, body_, {0, 0, 0}}
+#define RV_SLOT_ROW(k_, j_, si_, body_, s_) \
+    {{RV_WB_##k_}, {RV_BP_##j_}, {RV_BA_##j_}, k_, j_, si_, body_, RV_LP_##s_, 0}
+#define RV_LP_0 {{0.44f, 0.3125f, -0.10f}, {0.29675f, 0.3075f, 0.0175f}}
+#define RV_LP_1 {{0.08025f, 0.3055f, -0.0685f}, {0.007f, 0.3085f, -0.12f}}
+#define RV_LP_2 {{0.44f, -0.3125f, -0.10f}, {0.29675f, -0.3075f, 0.0175f}}
+#define RV_LP_3 {{0.08025f, -0.3055f, -0.0685f}, {0.007f, -0.3085f, -0.12f}}
+#define RV_LP_4 {{-0.44f, 0.3125f, -0.10f}, {-0.3825f, 0.19625f, 0.0175f}}
+#define RV_LP_5 {{-0.44f, -0.3125f, -0.10f}, {-0.3825f, -0.19625f, 0.0175f}}
 #define RV_WB_0 0.44f, 0.3925f, -0.16699f
 #define RV_WB_1 0.44f, -0.3925f, -0.16699f
 #define RV_WB_2 0.007f, 0.3885f, -0.16699f
@@ -1413,8 +1471,15 @@ struct SlotConst {
 #define RV_BA_2 1.0f, 0.0f, 0.0f
 // slots [FL, CL, FR, CR, RL, RR, -, -] = wheels [0, 2, 1, 3, 4, 5]; the idle slots 6, 7 shadow slot 5
 __device__ const SlotConst d_SLOT[8] = {
-    RV_SLOT_ROW(0, 0, 0, 9), RV_SLOT_ROW(2, 0, -1, 7), RV_SLOT_ROW(1, 1, 1, 10), RV_SLOT_ROW(3, 1, -1, 8),
-    RV_SLOT_ROW(4, 2, 2, 11), RV_SLOT_ROW(5, 2, 3, 12), RV_SLOT_ROW(5, 2, 3, 12), RV_SLOT_ROW(5, 2, 3, 12)};
+    RV_SLOT_ROW(0, 0, 0, 9, 0), RV_SLOT_ROW(2, 0, -1, 7, 1), RV_SLOT_ROW(1, 1, 1, 10, 2), RV_SLOT_ROW(3, 1, -1, 8, 3),
+    RV_SLOT_ROW(4, 2, 2, 11, 4), RV_SLOT_ROW(5, 2, 3, 12, 5), RV_SLOT_ROW(5, 2, 3, 12, 5), RV_SLOT_ROW(5, 2, 3, 12, 5)};
+static_assert(sizeof(SlotConst) == 80, "SlotConst row");
+// host copy of the sample-point columns of d_SLOT (consistency check against RV_LINK_POINT_INIT in rover_model_constants)
+static float d_SLOT_host_lp(int slot, int role, int i)
+{
+    const float lp[6][2][3] = {RV_LP_0, RV_LP_1, RV_LP_2, RV_LP_3, RV_LP_4, RV_LP_5};
+    return lp[slot][role][i];
+}
 
 struct GroupIds {
     int slot, k, j, si, body;
@@ -1459,6 +1524,8 @@ __device__ __forceinline__ void group_load(const float *__restrict__ state, int 
         g.ax[i] = sc.ax[i];
     }
     g.arm = make_arm(sc.wb, sc.P, sc.ax);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g.lp[i] = id.role_b ? sc.lp[1][i] : sc.lp[0][i];
     {
         // per-lane pick of the bogie constants (same values as K.b_winv[j] / K.bogie_keep[j])
         float bw = K.b_winv[0], bk = K.bogie_keep[0];
@@ -1572,20 +1639,20 @@ __global__ __launch_bounds__(RV_K1G_THREADS) void rover_step_kernel_group(RvPara
         g.wheel_t = rv / c.wheel_radius;   // one division per lane instead of six (same quotient)
     }
     // rover_env.py:64-72 decimation loop
-    float Fw[3] = {0.0f, 0.0f, 0.0f};
+    float Fw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     K1_STAMP(1);
     for (int s = 0; s < c.decimation - 1; ++s) physics_substep_group<false>(p, K, g, nullptr, s);
     if (c.decimation > 0) physics_substep_group<true>(p, K, g, Fw, c.decimation - 1);
     K1_STAMP(20);
-    if (!id.wheel_active) { Fw[0] = 0.0f; Fw[1] = 0.0f; Fw[2] = 0.0f; }
+    if (!id.wheel_active) { Fw[0] = 0.0f; Fw[1] = 0.0f; Fw[2] = 0.0f; Fw[3] = 0.0f; }
     if (active) group_store(state, N, e, id, g);
 
-    // contact report: gather the six Drive-body forces of the env (sensor body order) into every lane -- only in waves
-    // where some wheel stands on the obstacle layer (otherwise every force is the +0 the array already holds)
+    // contact report: gather the six Drive-body forces and the twelve link-point forces of the env (sensor body order) into
+    // every lane -- only in waves where some body touches the obstacle layer (otherwise every force is the +0 the array holds)
     float F[ROVER_NUM_BODIES * 3];
 #pragma unroll
     for (int i = 0; i < ROVER_NUM_BODIES * 3; ++i) F[i] = 0.0f;
-    const bool any_force = __ballot(Fw[0] != 0.0f || Fw[1] != 0.0f || Fw[2] != 0.0f) != 0ull;
+    const bool any_force = __ballot(Fw[0] != 0.0f || Fw[1] != 0.0f || Fw[2] != 0.0f || Fw[3] != 0.0f) != 0ull;
     if (any_force) {
         constexpr int BODY_SLOT[6] = {1, 3, 0, 2, 4, 5};  // bodies 7..12 = CL, CR, FL, FR, RL, RR -> solver slot
         const int base = lane & ~15;
@@ -1593,10 +1660,25 @@ __global__ __launch_bounds__(RV_K1G_THREADS) void rover_step_kernel_group(RvPara
         for (int b = 0; b < 6; ++b)
 #pragma unroll
             for (int i = 0; i < 3; ++i) F[(7 + b) * 3 + i] = __shfl(Fw[i], base + BODY_SLOT[b], 64);
+        float lf[6][2], Fz[7];
+#pragma unroll
+        for (int sl = 0; sl < 6; ++sl) {
+            lf[sl][0] = __shfl(Fw[3], base + sl, 64);
+            lf[sl][1] = __shfl(Fw[3], base + 8 + sl, 64);
+        }
+        link_body_forces(lf, Fz);
+#pragma unroll
+        for (int b = 0; b < 7; ++b) F[b * 3 + 2] = Fz[b];
     }
     if (force && active && id.owner) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) force[(size_t)(id.body * 3 + i) * N + e] = Fw[i];
+    }
+    if (force && active && (lane & 15) < 7) {   // z rows of the seven link bodies (x, y rows stay the caller's zeros)
+        float fz = F[2];
+#pragma unroll
+        for (int b = 1; b < 7; ++b) fz = ((lane & 15) == b) ? F[b * 3 + 2] : fz;
+        force[(size_t)((lane & 15) * 3 + 2) * N + e] = fz;
     }
     K1_STAMP(23);
 
@@ -1725,13 +1807,30 @@ __global__ __launch_bounds__(RV_K1G_THREADS) void rover_physics_kernel_group(RvP
     group_load(state, N, e, id, sc, K, g);
     g.steer_t = steer_t[4 * e + (id.si >= 0 ? id.si : 0)];
     g.wheel_t = wheel_t[6 * e + id.k];
-    float Fw[3] = {0.0f, 0.0f, 0.0f};
+    float Fw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int s = 0; s < substeps - 1; ++s) physics_substep_group<false>(p, K, g, nullptr);
     if (substeps > 0) physics_substep_group<true>(p, K, g, Fw);
+    if (!id.wheel_active) Fw[3] = 0.0f;
     if (active) group_store(state, N, e, id, g);
     if (force && active && id.owner) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) force[(size_t)(id.body * 3 + i) * N + e] = Fw[i];
+    }
+    if (force) {
+        const int base = lane & ~15;
+        float lf[6][2], Fz[7];
+#pragma unroll
+        for (int sl = 0; sl < 6; ++sl) {
+            lf[sl][0] = __shfl(Fw[3], base + sl, 64);
+            lf[sl][1] = __shfl(Fw[3], base + 8 + sl, 64);
+        }
+        link_body_forces(lf, Fz);
+        if (active && (lane & 15) < 7) {
+            float fz = Fz[0];
+#pragma unroll
+            for (int b = 1; b < 7; ++b) fz = ((lane & 15) == b) ? Fz[b] : fz;
+            force[(size_t)((lane & 15) * 3 + 2) * N + e] = fz;
+        }
     }
 }
 
@@ -2849,7 +2948,7 @@ int rover_model_constants(float *out, int32_t cap)
 {
     const float com[3] = RV_COM_B_INIT, inertia[3] = RV_INERTIA_B_INIT, wheel[6][3] = RV_WHEEL_B_INIT;
     const float pivot[3][3] = RV_BOGIE_PIVOT_INIT, axis[3][3] = RV_BOGIE_AXIS_INIT, binertia[3] = RV_BOGIE_INERTIA_INIT;
-    float t[96];
+    float t[160];
     int n = 0;
     t[n++] = RV_M_TOTAL;
     for (int i = 0; i < 3; ++i) t[n++] = com[i];
@@ -2863,6 +2962,13 @@ int rover_model_constants(float *out, int32_t cap)
     t[n++] = RV_WHEEL_INERTIA; t[n++] = RV_WHEEL_KP; t[n++] = RV_WHEEL_KD; t[n++] = RV_WHEEL_EFFORT; t[n++] = RV_WHEEL_VLIM;
     t[n++] = RV_BOGIE_QLIM; t[n++] = RV_BOGIE_DAMPING; t[n++] = RV_BAUMGARTE; t[n++] = RV_MAX_DEPENETRATION_VEL;
     t[n++] = RV_MAX_LINEAR_VEL; t[n++] = RV_GRAVITY; t[n++] = RV_OBSTACLE_EPS; t[n++] = RV_WARM_START; t[n++] = RV_STEER_QLIM;
+    {
+        const float lp[6][2][3] = RV_LINK_POINT_INIT;
+        for (int sl = 0; sl < 6; ++sl) for (int r = 0; r < 2; ++r) for (int i = 0; i < 3; ++i) t[n++] = lp[sl][r][i];
+        for (int sl = 0; sl < 6; ++sl) for (int r = 0; r < 2; ++r) for (int i = 0; i < 3; ++i)
+            if (d_SLOT_host_lp(sl, r, i) != lp[sl][r][i]) return -1;      // the group mapping's table must be the same points
+        t[n++] = RV_LINK_STIFFNESS;
+    }
     if (out) for (int i = 0; i < n && i < cap; ++i) out[i] = t[i];
     return n;
 }

@@ -41,6 +41,22 @@
 #define RV_MAX_LINEAR_VEL 1.5f         // aau_rover_simple.py:25
 #define RV_GRAVITY 9.81f
 #define RV_OBSTACLE_EPS 1.0e-3f
+// Contact report of the seven LINK bodies of the 13-body sensor (rover_env_cfg.py:72-75 matches .*_(Drive|Steer|Boogie|Body):
+// 3 bogies, 4 steer links, 6 drive wheels; the chassis prim "Body" has no underscore and is not a sensor body): twelve sample
+// points on the undersides of the links, body frame at zero bogie angle, one per (solver slot, role) lane of the group
+// mapping.  Slot order FL, CL, FR, CR, RL, RR; per slot {role A point, role B point}.  Derived from the link frames of
+// tests/golden/rover_model.json: steer forks inboard of their wheel at hub height + 0.067 (role A of the steered slots),
+// the front bogie arms (pivot -> steer joint, pivot -> centre hub) and the rear bogie beam (pivot -> rear steer joints).
+#define RV_LINK_POINT_INIT                                                                                             \
+    {{{0.44f, 0.3125f, -0.10f}, {0.29675f, 0.3075f, 0.0175f}},    /* FL: FL_Steer fork | FL_Boogie front arm        */ \
+     {{0.08025f, 0.3055f, -0.0685f}, {0.007f, 0.3085f, -0.12f}},  /* CL: FL_Boogie rear arm | rear arm, lower end   */ \
+     {{0.44f, -0.3125f, -0.10f}, {0.29675f, -0.3075f, 0.0175f}},  /* FR                                            */ \
+     {{0.08025f, -0.3055f, -0.0685f}, {0.007f, -0.3085f, -0.12f}}, /* CR                                            */ \
+     {{-0.44f, 0.3125f, -0.10f}, {-0.3825f, 0.19625f, 0.0175f}},   /* RL: RL_Steer fork | R_Boogie beam, left half   */ \
+     {{-0.44f, -0.3125f, -0.10f}, {-0.3825f, -0.19625f, 0.0175f}}} /* RR: RR_Steer fork | R_Boogie beam, right half  */
+// sensor body row of each sample point (bodies 0..2 = FL / FR / R bogie, 3..6 = FL, FR, RL, RR steer)
+#define RV_LINK_BODY_INIT {{3, 0}, {0, 0}, {4, 1}, {1, 1}, {5, 2}, {6, 2}}
+#define RV_LINK_STIFFNESS 2.0e4f   // N per metre of penetration into the obstacle layer (report only: the episode ends on contact)
 #define RV_WARM_START 0.85f
 
 #define RV_PI_F 3.14159265358979323846f

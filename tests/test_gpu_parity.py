@@ -238,6 +238,58 @@ def test_physics_substeps_match_oracle(oracle, mapping):
     env.close()
 
 
+@pytest.mark.parametrize("mapping", MAPPINGS)
+def test_link_bodies_report_contact(oracle, mapping):
+    """The seven link bodies of the 13-body contact sensor (3 bogies, 4 steer links; rover_env_cfg.py:72-75): rovers placed at
+    random poses over a field of 0.3 - 0.6 m posts narrower than the wheel gauge -- posts pass between the wheels and hit bogie
+    beams / steer forks.  Force rows, collision flags and rewards of both kernel mappings against the oracle, bit for bit;
+    and the reviewer's scenario: a rover straddling a 0.5 m rock that no wheel touches ends its episode on `collision`."""
+    from isaac_rover_orbit_amd import terrain as T
+    rng = np.random.RandomState(21)
+    Hh = W = 1024
+    ob = np.zeros((Hh, W), np.float32)
+    for _ in range(900):
+        i, j = rng.randint(380, 640, 2)
+        ob[i:i + rng.randint(2, 9), j:j + rng.randint(2, 9)] = rng.uniform(0.2, 0.6)
+    ob[470:530, 470:530] = 0.0
+    ob[495:506, 490:505] = 0.5                                            # the belly rock of tests/test_oracle_physics.py at (25, 25), alone
+    zero = np.zeros((Hh, W), np.uint8)
+    ter = T.Terrain(ground=np.zeros((Hh, W), np.float32), obstacle=ob, rock_mask=zero, safe_rock_mask=zero)
+    n = 200
+    env = make_env(n, ter, step_mapping=mapping)
+    env.reset()
+    ocfg, oter = oracle_side(oracle, env)
+    So = state_np(env)
+    So[:, oracle.POS:oracle.POS + 2] = rng.uniform(20.5, 30.5, (n, 2))
+    So[:, oracle.POS + 2] = 0.26878 + rng.uniform(0.0, 0.25, n)           # riding over posts at different heights
+    yaw = rng.uniform(-np.pi, np.pi, n)
+    So[:, oracle.QUAT] = np.cos(yaw / 2); So[:, oracle.QUAT + 1:oracle.QUAT + 3] = 0; So[:, oracle.QUAT + 3] = np.sin(yaw / 2)
+    So[:, oracle.BOGIE_Q:oracle.BOGIE_Q + 3] = rng.uniform(-0.17, 0.17, (n, 3))
+    So[0, oracle.POS:oracle.POS + 3] = [25.0, 25.0, 0.26878]              # env 0: straddles the belly rock, heading +x, level bogies
+    So[0, oracle.QUAT:oracle.QUAT + 4] = [1, 0, 0, 0]
+    So[0, oracle.BOGIE_Q:oracle.BOGIE_Q + 3] = 0
+    So[:, oracle.LINVEL:oracle.LINVEL + 6] = 0
+    So = So.astype(np.float32)
+    env.set_state(torch.from_numpy(So))
+    z4, z6 = np.zeros((n, 4), np.float32), np.zeros((n, 6), np.float32)
+    f = env.physics(torch.from_numpy(z4), torch.from_numpy(z6), 1).cpu().numpy()
+    fo = oracle.physics_step(ocfg, oter, So.copy(), z4, z6, 1)
+    assert_close(f, fo, 0, 0, "contact report incl. link bodies")
+    assert (fo[:, :7, 2] > 0).any(axis=0).all(), "every link body is touched by some env of the batch"
+    assert fo[0, 2, 2] > 1000.0 and np.abs(fo[0, 7:]).max() == 0.0        # env 0: rear bogie beam only
+    # the same through step(): flags, rewards, in-step resets
+    env.set_state(torch.from_numpy(So))
+    Sw = So.copy()
+    a = np.zeros((n, 2), np.float32)
+    obs, rew, term, trunc, info = env.step(torch.from_numpy(a).to(env.device))
+    obs_o, rew_o, term_o, trunc_o, force_o, log_o = oracle.step(ocfg, oter, Sw, a)
+    assert np.array_equal(term.cpu().numpy().astype(np.uint8), term_o) and term_o[0] == 1 and 20 < term_o.sum() < n
+    assert_close(rew.cpu().numpy(), rew_o, 0, 0, "reward")
+    assert_close(env.scene.sensors["contact_sensor"].data.force_matrix_w.cpu().numpy().reshape(n, 13, 3), force_o, 0, 0, "force_matrix_w")
+    assert_close(state_np(env), Sw, 0, 0, "state after the step (collided envs were reset)")
+    env.close()
+
+
 # ------------------------------------------------------------------------------------------------ full step
 def rollout_compare(oracle, env, steps, actions, tol_step, tol_final, resync):
     n = env.num_envs

@@ -203,6 +203,59 @@ def test_collision_only_from_obstacle_layer(oracle):
     assert term[0, 3] == 1 and rew[0, 5] == 1.0
 
 
+def belly_rock_terrain(height):
+    """A flat map with ONE box of the obstacle layer, 0.7 m x 0.5 m, placed so that a rover at (15, 15) heading +x straddles it:
+    x in [14.5, 15.2], |y - 15| <= 0.25 -- between the wheel tracks (inner wheel faces at |y| ~ 0.33), under the rear bogie beam."""
+    from isaac_rover_orbit_amd import terrain as T
+    Hh = W = 600
+    g = np.zeros((Hh, W), np.float32)
+    ob = np.zeros((Hh, W), np.float32)
+    ob[295:306, 290:305] = height
+    zero = np.zeros((Hh, W), np.uint8)
+    ter = T.Terrain(ground=g, obstacle=ob, rock_mask=zero, safe_rock_mask=zero)
+    ter.spawn_locations = np.array([[15.0, 15.0, 0.0]], np.float32)
+    return ter
+
+
+def test_link_bodies_report_contact_with_a_rock_between_the_wheels(oracle):
+    """Round-2 review: only a wheel standing on the obstacle layer produced force, so a rover straddling a 0.5 m rock never
+    ended on `collision`.  The 13 sensor bodies (rover_env_cfg.py:72-75) are 3 bogies + 4 steer links + 6 wheels: a rock under
+    the belly that no wheel touches reaches the rear bogie beam (0.286 m above the ground) and terminates the episode; a 0.2 m
+    rock in the same place passes underneath."""
+    ro = oracle
+    for height, expect in ((0.5, True), (0.2, False)):
+        cfg, t = ro.default_config(), oracle_terrain(ro, belly_rock_terrain(height))
+        S = fresh(ro, 1, (15.0, 15.0), 0.26878)
+        f = ro.physics_step(cfg, t, S, np.zeros((1, 4), np.float32), np.zeros((1, 6), np.float32), 1)
+        assert np.abs(f[0, 7:]).max() == 0.0                              # no wheel stands on the obstacle layer
+        assert np.abs(f[0, :, :2]).max() == 0.0                           # link forces are vertical
+        rows = np.nonzero(f[0, :, 2] > 0)[0]
+        od, oa, rew, term = ro.mdp_terms(cfg, np.zeros((1, 3), np.float32) + 5, np.zeros((1, 2), np.float32),
+                                         np.zeros((1, 2), np.float32), np.zeros(1, np.int32), f)
+        if expect:
+            assert list(rows) == [2] and f[0, 2, 2] > 1000.0              # R_Boogie, ~0.21 m inside the rock at 2e4 N/m x 2 points
+            assert term[0, 3] == 1 and rew[0, 5] == 1.0                   # collision_with_obstacles / collision_penalty
+        else:
+            assert len(rows) == 0 and term[0, 3] == 0
+    # through the whole step: the episode ends on `collision` in the first step and the env is reset
+    cfg, t = ro.default_config(), oracle_terrain(ro, belly_rock_terrain(0.5))
+    S = fresh(ro, 1, (15.0, 15.0), 0.26878)
+    S[:, ro.TARGET_W:ro.TARGET_W + 3] = [20.0, 15.0, 0.0]
+    obs, rew, term, trunc, force, log = ro.step(cfg, t, S, np.zeros((1, 2), np.float32))
+    assert term[0] == 1 and trunc[0] == 0 and force[0, 2, 2] > 1000.0 and log[10] == 1.0
+    # a steer fork: a 0.25 m post just inboard of the front-left wheel
+    from isaac_rover_orbit_amd import terrain as T
+    ter = belly_rock_terrain(0.0)
+    ob = ter.obstacle.copy()
+    ob[305:307, 308:310] = 0.25                                           # x in [15.40, 15.50], y in [15.25, 15.35]: fork at (15.44, 15.3125), wheel at y = 15.3925
+    ter2 = T.Terrain(ground=ter.ground, obstacle=ob, rock_mask=ter.rock_mask, safe_rock_mask=ter.safe_rock_mask)
+    ter2.spawn_locations = ter.spawn_locations
+    cfg, t = ro.default_config(), oracle_terrain(ro, ter2)
+    S = fresh(ro, 1, (15.0, 15.0), 0.26878)
+    f = ro.physics_step(cfg, t, S, np.zeros((1, 4), np.float32), np.zeros((1, 6), np.float32), 1)
+    assert f[0, 3, 2] > 1.0 and np.abs(f[0, 7:]).max() == 0.0             # FL_Steer touches, the wheel beside it does not
+
+
 def test_oracle_is_deterministic_and_shard_invariant(oracle):
     ro = oracle
     ter = small_procedural()
