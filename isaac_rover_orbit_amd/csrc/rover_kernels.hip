@@ -527,8 +527,13 @@ __device__ __forceinline__ float dpp_ror8(float x);
 // sensor body): vertical penalty force at one sample point p0 (body frame, zero bogie angle) that rides on the bogie with
 // pivot P / axis ax at angle bq -- non-zero when the point is below the terrain surface where the obstacle layer is present.
 // Report only (collision_with_obstacles ends the episode in the same step): the dynamics do not see it.
-__device__ __forceinline__ float link_point_force(const RvParams &p, const float R[3][3], const float *pos, const float *P,
-                                                  const float *ax, float bq, const float *p0)
+// Split in two so that the group mapping can issue the point's eight gathers BEFORE the wheel's geometry (their latency
+// then overlaps the wheel's own terrain sample instead of following it): link_point_fetch -> LinkSample, link_point_eval.
+struct LinkSample {
+    float h00, h01, h10, h11, o00, o01, o10, o11, fx, fy, z;
+};
+__device__ __forceinline__ LinkSample link_point_fetch(const RvParams &p, const float R[3][3], const float *pos, const float *P,
+                                                       const float *ax, float bq, const float *p0)
 {
     float sb, cb;
     if (fabsf(bq) < 0.75f) rv_sincosf_small(bq, &sb, &cb);
@@ -540,10 +545,36 @@ __device__ __forceinline__ float link_point_force(const RvParams &p, const float
 #pragma unroll
     for (int i = 0; i < 3; ++i) pt_b[i] = P[i] + fmaf(ax[i], ad * (1.0f - cb), fmaf(axd[i], sb, d0[i] * cb));
     mat_vecf(R, pt_b, tmp);
-    float hgt, gx, gy, obst = 0.0f;
-    terrain_sample<true>(p, pos[0] + tmp[0], pos[1] + tmp[1], hgt, gx, gy, obst);
-    const float pen = hgt - (pos[2] + tmp[2]);
+    // same cell arithmetic as terrain_sample
+    float u = ((pos[0] + tmp[0]) - p.min_x) * p.inv_res;
+    float v = ((pos[1] + tmp[1]) - p.min_y) * p.inv_res;
+    u = clamp_med3(u, 0.0f, (float)(p.W - 1));
+    v = clamp_med3(v, 0.0f, (float)(p.H - 1));
+    int j0 = (int)u, i0 = (int)v;
+    if (j0 > p.W - 2) j0 = p.W - 2;
+    if (i0 > p.H - 2) i0 = p.H - 2;
+    const size_t base = (size_t)i0 * p.W + j0;
+    const float *q = p.height + base, *o = p.obstacle + base;
+    LinkSample s;
+    s.fx = u - (float)j0; s.fy = v - (float)i0; s.z = pos[2] + tmp[2];
+    s.h00 = q[0]; s.h01 = q[1]; s.h10 = q[p.W]; s.h11 = q[p.W + 1];
+    s.o00 = o[0]; s.o01 = o[1]; s.o10 = o[p.W]; s.o11 = o[p.W + 1];
+    return s;
+}
+__device__ __forceinline__ float link_point_eval(const LinkSample &s)
+{
+    const float dx0 = s.h01 - s.h00, dx1 = s.h11 - s.h10;
+    const float hx0 = s.h00 + s.fx * dx0, hx1 = s.h10 + s.fx * dx1;
+    const float hgt = hx0 + s.fy * (hx1 - hx0);
+    const float o0 = s.o00 + s.fx * (s.o01 - s.o00), o1 = s.o10 + s.fx * (s.o11 - s.o10);
+    const float obst = o0 + s.fy * (o1 - o0);
+    const float pen = hgt - s.z;
     return (obst > RV_OBSTACLE_EPS && pen > 0.0f) ? RV_LINK_STIFFNESS * pen : 0.0f;
+}
+__device__ __forceinline__ float link_point_force(const RvParams &p, const float R[3][3], const float *pos, const float *P,
+                                                  const float *ax, float bq, const float *p0)
+{
+    return link_point_eval(link_point_fetch(p, R, pos, P, ax, bq, p0));
 }
 // z rows of the seven link bodies from the twelve point forces lf[slot][role]: fixed summation order
 __device__ __forceinline__ void link_body_forces(const float lf[6][2], float *Fz /* 7 */)
@@ -1105,8 +1136,10 @@ __device__ __forceinline__ void physics_substep_group(const RvParams &p, const S
     float bd = g.bqd * g.bogie_keep;
     const bool at_hi = bq >= RV_BOGIE_QLIM - 1.0e-5f, at_lo = bq <= -RV_BOGIE_QLIM + 1.0e-5f;
     Contact ct;
+    LinkSample ls;
+    if (RECORD_FORCE) ls = link_point_fetch(p, R, g.pos, g.P, g.ax, bq, g.lp);      // pose of the substep's start, like the wheel rows
     wheel_geometry<RECORD_FORCE, true>(p, K, R, g.pos, com_w, g.arm, g.P, g.ax, g.b_winv, bq, at_hi, at_lo, g.steerable, g.sq, ct, g.role_b);
-    if (RECORD_FORCE) Fw[3] = link_point_force(p, R, g.pos, g.P, g.ax, bq, g.lp);   // pose of the substep's start, like the wheel rows
+    if (RECORD_FORCE) Fw[3] = link_point_eval(ls);
     K1_STAMP(3 + 3 * sidx);
     ct.ln = RV_WARM_START * g.lam;
     ct.lt = 0.0f;

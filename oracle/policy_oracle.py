@@ -9,7 +9,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libpolicy_oracle.so")
+# ROVER_ORACLE_DIR: load the library from another directory (the sanitizer builds of `make -C oracle sanitized`)
+_LIB_PATH = os.path.join(os.environ.get("ROVER_ORACLE_DIR") or _HERE, "libpolicy_oracle.so")
 MAX_LAYERS = 8
 ACT_NONE, ACT_LEAKY_RELU, ACT_TANH = 0, 1, 2
 
@@ -25,6 +26,8 @@ class Desc(C.Structure):
 
 
 def build(force: bool = False) -> str:
+    if os.environ.get("ROVER_ORACLE_DIR"):
+        return _LIB_PATH
     src = os.path.join(_HERE, "policy_oracle.c")
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libpolicy_oracle.so"], stdout=subprocess.DEVNULL)

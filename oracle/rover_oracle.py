@@ -12,7 +12,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "librover_oracle.so")
+# ROVER_ORACLE_DIR: load the library from another directory (the sanitizer builds of `make -C oracle sanitized`)
+_LIB_PATH = os.path.join(os.environ.get("ROVER_ORACLE_DIR") or _HERE, "librover_oracle.so")
 
 NUM_REW, NUM_TERM, NUM_BODIES, LOG_WORDS = 7, 4, 13, 16
 
@@ -52,6 +53,8 @@ class Terrain(C.Structure):
 
 
 def build(force: bool = False) -> str:
+    if os.environ.get("ROVER_ORACLE_DIR"):
+        return _LIB_PATH
     src = os.path.join(_HERE, "rover_oracle.c")
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-B", "librover_oracle.so"], stdout=subprocess.DEVNULL)
