@@ -118,6 +118,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-forces", action="store_true", help="do not materialise contact_sensor.force_matrix_w")
+    ap.add_argument("--with-policy", action="store_true",
+                    help="extra leg (outside `value`): the rollout loop a trainer runs -- actor + critic forward passes "
+                         "(fused MFMA kernel, reference architecture, random-init weights) + env.step() on one stream, per-kernel us")
     ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5),
                     help="BASELINE.json config: 2 = headline (31x31 rays @0.1 m, sigma_z 0.15 m); "
                          "4 = dense scanner stress (32x32 rays @0.05 m, sigma_z 0.4 m); "
@@ -317,6 +320,47 @@ def main():
                                    "single_thread_value": n1 * m1 / dt1, "host_cpus": host}
         except Exception as e:  # the baseline must never take the bench down
             out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
+
+    # ---- rollout-loop leg: what a trainer runs per env step -- policy mean, value, env.step -- on ONE stream.
+    #      Random-init weights of the reference architecture (get_models.py:36-62); outside `value`.
+    if args.with_policy and env.num_rays == 961:
+        try:
+            from isaac_rover_orbit_amd.policy import RoverNet
+            rs = np.random.RandomState(7)
+            K, Nn = [961, 80, 64, 256, 160, 128], [80, 60, 256, 160, 128]
+            def net(out_dim, act):
+                ws = [(rs.uniform(-1, 1, (nn, kk)) / np.sqrt(kk)).astype(np.float32) for kk, nn in zip(K, Nn + [out_dim])]
+                bs = [(rs.uniform(-1, 1, nn) / np.sqrt(kk)).astype(np.float32) for kk, nn in zip(K, Nn + [out_dim])]
+                return RoverNet(ws, bs, n_enc=2, final_act=act, device=dev)
+            actor, critic = net(2, "tanh"), net(1, "none")
+            obs = env.obs_buf["policy"]
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            t_act = t_val = t_env = 0.0
+            reps = max(args.profile_steps, 20)
+            for k in range(reps + 5):
+                ev[0].record(); a_pol = actor(obs); ev[1].record(); critic(obs); ev[2].record()
+                obs = env.step(a_pol)[0]["policy"]; ev[3].record()
+                torch.cuda.synchronize()
+                if k >= 5:
+                    t_act += ev[0].elapsed_time(ev[1]); t_val += ev[1].elapsed_time(ev[2]); t_env += ev[2].elapsed_time(ev[3])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(args.steps):
+                a_pol = actor(obs); critic(obs)
+                obs = env.step(a_pol)[0]["policy"]
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / args.steps
+            flops = 2.0 * n * sum(kk * nn for kk, nn in zip(K, Nn + [2]))
+            out["with_policy"] = {"ms_per_step": dt * 1e3, "env_steps_per_s": n / dt,
+                                  "kernels_us_events": {"rover_policy_kernel (actor)": t_act / reps * 1e3 - ev_ms * 1e3,
+                                                        "rover_policy_kernel (critic)": t_val / reps * 1e3 - ev_ms * 1e3,
+                                                        "env.step (K1 + K2)": t_env / reps * 1e3 - ev_ms * 1e3},
+                                  "observations_finite": bool(torch.isfinite(obs).all()),
+                                  "actor_TFLOPs_f32": flops / ((t_act / reps - ev_ms) * 1e-3) / 1e12, "f32_mfma_peak_TFLOPs": 157.0,
+                                  "note": "closed loop: the actor's mean action drives the env (observations with -inf rays are "
+                                          "what the kernel reads; the reference feeds them to torch the same way)"}
+        except Exception as e:  # the extra leg must never take the headline number down
+            out["with_policy"] = {"failed": repr(e)}
 
     env.close()
     if rank == 0:

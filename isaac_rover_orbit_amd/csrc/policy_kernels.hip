@@ -32,6 +32,10 @@ constexpr int POL_WAVES = POL_THREADS / 64;
 constexpr int POL_ROWS = 16;      // observation rows per workgroup = M of the MFMA tile
 constexpr int POL_MAXT = 6;       // accumulator tiles a wave carries at once in a split-K layer
 constexpr int POL_PF = 3;         // k groups of B fragments in flight per wave in a split-K layer (x tiles x 16 B per lane)
+// ... and in a full-K layer of a shape without a compile-time path (mfma_all below), by the number of column tiles carried
+#ifndef POL_PF_FULL
+#define POL_PF_FULL(NT) ((NT) >= 3 ? 3 : 6)
+#endif
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -164,6 +168,30 @@ __device__ __forceinline__ void mfma_groups(v4f (&acc)[NT], const float *arow_pt
     }
 }
 
+// Full-K layer with a COMPILE-TIME number of k groups (the reference architecture's 80 -> 60, 64 -> 256, 256 -> 160, 160 -> 128
+// layers: 5 / 4 / 16 / 10 groups): every B fragment of the wave's tiles is requested up front -- straight-line code, so the
+// waits before each group's MFMAs are counted vmcnt(N) and the first MFMA starts when the first fragment lands.  With the
+// generic queue (3 - 6 groups in flight) a wave's weight stream was latency-bound: 6 KB per L2 round trip x 8 waves ~ 24 B/clk,
+// below the CU's ~33 B/clk L2 port.  (Raising the queue depth of the generic loop instead made things WORSE: its ragged tail
+// has run-time bounds, the compiler waits with vmcnt(0) there, and with everything in the tail nothing overlapped.)
+template <int NT, int GC>
+__device__ __forceinline__ void mfma_all(v4f (&acc)[NT], const float *arow_ptr, int akq, const v4f *Wt, size_t tile_stride)
+{
+    v4f b[GC][NT];
+#pragma unroll
+    for (int g = 0; g < GC; ++g)
+#pragma unroll
+        for (int i = 0; i < NT; ++i) b[g][i] = Wt[i * tile_stride + (size_t)g * 64];
+    const float *ap = arow_ptr + akq;
+#pragma unroll
+    for (int g = 0; g < GC; ++g) {
+        float a[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = ap[16 * g + 4 * j];
+        mfma_one_group<NT>(acc, a, b[g]);
+    }
+}
+
 // Packed weights of one layer: for column tile t (16 outputs), k group g (16 inputs = 4 MFMA k-steps), lane l:
 // a float4 {W[n][k0], W[n][k0 + 4], W[n][k0 + 8], W[n][k0 + 12]} with n = 16 t + (l & 15), k0 = 16 g + (l >> 4);
 // zero outside (N, K).  Index ((t * G + g) * 64 + l) * 4.
@@ -293,7 +321,16 @@ __global__ __launch_bounds__(POL_THREADS) void rover_policy_kernel(rover_policy_
                         acc[i] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
                         bv[i] = bias[min(16 * (t0 + POL_WAVES * i) + arow, N - 1)];
                     }
-                    mfma_groups<NT, (NT >= 3 ? 3 : 6)>(acc, arow_ptr, akq, K, Wt, (size_t)POL_WAVES * G * 64, 0, G, G);
+                    const size_t ts = (size_t)POL_WAVES * G * 64;
+                    if constexpr (NT <= 2) {
+                        if ((K & 15) == 0 && G == 4) mfma_all<NT, 4>(acc, arow_ptr, akq, Wt, ts);
+                        else if ((K & 15) == 0 && G == 5) mfma_all<NT, 5>(acc, arow_ptr, akq, Wt, ts);
+                        else if ((K & 15) == 0 && G == 10) mfma_all<NT, 10>(acc, arow_ptr, akq, Wt, ts);
+                        else if ((K & 15) == 0 && G == 16) mfma_all<NT, 16>(acc, arow_ptr, akq, Wt, ts);
+                        else mfma_groups<NT, POL_PF_FULL(NT)>(acc, arow_ptr, akq, K, Wt, ts, 0, G, G);
+                    } else {
+                        mfma_groups<NT, POL_PF_FULL(NT)>(acc, arow_ptr, akq, K, Wt, ts, 0, G, G);
+                    }
                     const int pd_off = 4 * akq * dst_pitch + 16 * t0 + arow;
                     auto epi = [&](auto act_tag) {   // one specialised copy per activation: no per-element branching
                         constexpr int ACT = decltype(act_tag)::value;
