@@ -1046,14 +1046,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
 // extras["log"] of a step: means over the envs that reset in it.  One workgroup; when nobody reset -- the common case -- it
 // reads one counter and leaves (the launch then costs its ~2 us of dispatch, nothing else).  Otherwise a fixed-order
-// reduction: env e is summed by thread e % 1024, the threads are combined by a fixed tree => deterministic.
+// reduction: env e is summed by thread e % 256, the threads are combined by a fixed tree => deterministic.
 // (Measured alternatives: the round-2 form, one workgroup walking all 10 x n floats every step, took 21 us -- as long as
 // the step kernel; folding the reduction into the step kernel behind a "last wave" ticket cost ~5 us per step, because an
 // agent-scope release on this multi-XCD part is an L2 write-back and every wave waits for its atomic's round trip.)
-__global__ __launch_bounds__(1024) void lift_log_kernel(lift_config c, int n, const float *__restrict__ lg, unsigned *counters,
-                                                        float *__restrict__ log_out)
+__global__ __launch_bounds__(256) void lift_log_kernel(lift_config c, int n, const float *__restrict__ lg, unsigned *counters,
+                                                       float *__restrict__ log_out)
 {
-    __shared__ float part[9][1024];
+    __shared__ float part[4][9];
     const int t = threadIdx.x;
     if (counters[1] == 0u) {
         if (t == 0) log_out[8] = 0.0f;
@@ -1062,7 +1062,7 @@ __global__ __launch_bounds__(1024) void lift_log_kernel(lift_config c, int n, co
     float acc[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) acc[i] = 0.0f;
-    for (int e = t; e < n; e += 1024) {
+    for (int e = t; e < n; e += 256) {
         if (lg[(size_t)8 * n + e] != 0.0f) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] += lg[(size_t)i * n + e];
@@ -1070,21 +1070,24 @@ __global__ __launch_bounds__(1024) void lift_log_kernel(lift_config c, int n, co
         }
     }
 #pragma unroll
-    for (int i = 0; i < 9; ++i) part[i][t] = acc[i];
-    __syncthreads();
-    for (int m = 512; m >= 1; m >>= 1) {
-        if (t < m) {
+    for (int i = 0; i < 9; ++i) {
 #pragma unroll
-            for (int i = 0; i < 9; ++i) part[i][t] += part[i][t + m];
-        }
-        __syncthreads();
+        for (int m = 32; m >= 1; m >>= 1) acc[i] += __shfl_xor(acc[i], m, 64);   // fixed butterfly: deterministic
     }
-    if (t == 0) {
-        const float cnt = part[8][0];
+    if ((t & 63) == 0) {
 #pragma unroll
-        for (int i = 0; i < LIFT_NUM_REW; ++i) log_out[i] = part[i][0] / cnt / c.max_episode_length_s;
-        log_out[6] = part[6][0];
-        log_out[7] = part[7][0];
+        for (int i = 0; i < 9; ++i) part[t >> 6][i] = acc[i];
+    }
+    __syncthreads();
+    if (t == 0) {
+        float tot[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) tot[i] = (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]);
+        const float cnt = tot[8];
+#pragma unroll
+        for (int i = 0; i < LIFT_NUM_REW; ++i) log_out[i] = tot[i] / cnt / c.max_episode_length_s;
+        log_out[6] = tot[6];
+        log_out[7] = tot[7];
         log_out[8] = cnt;
         counters[1] = 0u;
     }
@@ -1140,7 +1143,7 @@ static void launch_step(rover_lift_sim *sim, hipStream_t st, const float *action
     else
         hipLaunchKernelGGL(lift_step_kernel<8>, grid, block, 0, st, hc, sim->cfg_dev, sim->n, sim->env_id_offset, sim->state, action, obs,
                            reward, terminated, truncated, sim->lg, sim->counters);
-    hipLaunchKernelGGL(lift_log_kernel, dim3(1), dim3(1024), 0, st, sim->cfg, sim->n, sim->lg, sim->counters, log);
+    hipLaunchKernelGGL(lift_log_kernel, dim3(1), dim3(256), 0, st, sim->cfg, sim->n, sim->lg, sim->counters, log);
 }
 
 extern "C" {

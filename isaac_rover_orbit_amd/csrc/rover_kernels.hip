@@ -95,6 +95,7 @@ struct RvParams {
     int cpr_log;  // log2 of the chunk slots per staged row (smallest power of two >= tile_pitch / chunk_cells)
     int wq, pq;   // 16-byte chunks per heightfield row / per LDS tile row
     int tile_bufs; // LDS tile buffers of the scan kernel (2 when they fit beside full occupancy, else 1)
+    int ray_blocks; // step-form scan kernel: 1 = wave w casts the 8 x 8 block (w & 3, w >> 2) of the ray grid (grids up to 32 x 32)
 };
 
 // ------------------------------------------------------------------------------------------------ small helpers
@@ -2221,7 +2222,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8), 
     float ox[RPT], oy[RPT];
 #pragma unroll
     for (int m = 0; m < RPT; ++m) {
-        const int r = tid + m * THREADS;
+        int r = tid + m * THREADS;
+        if (THREADS == 1024 && p.ray_blocks) {
+            // compact footprint per wave: an 8 x 8 block of neighbouring rays (16 x 16 cells of the tile at 2 cells per ray)
+            // instead of two 31-ray lines -- whatever the yaw, a wave's 256 corner reads stay inside ~16 tile rows x 40 bytes
+            const int wv = tid >> 6, ln = tid & 63;
+            const int rx = (wv & 3) * 8 + (ln & 7), ry = (wv >> 2) * 8 + (ln >> 3);
+            r = (rx < c.scan_nx && ry < c.scan_ny) ? ry * c.scan_nx + rx : p.rays;
+        }
         ray[m] = r < p.rays ? r : (m == 0 ? 0 : ray[0]);
         ox[m] = pattern_x(ray[m] % c.scan_nx);
         oy[m] = pattern_y(ray[m] / c.scan_nx);
@@ -2942,7 +2950,11 @@ int rover_height_scan(rover_sim *sim, float *scan, void *stream)
 // step form with one env per iteration
 int rover_debug_set_scan_form(rover_sim *sim, int form)
 {
-    if (!sim || form < 0 || form > 2) return ROVER_ERR_INVALID;
+    if (!sim || form < 0 || form > 4) return ROVER_ERR_INVALID;
+    if (form >= 3) {   // 3 / 4: ray -> thread mapping of the step form: 8 x 8 blocks per wave / lines (measurement hook)
+        sim->p.ray_blocks = (form == 3 && sim->p.cfg.scan_nx <= 32 && sim->p.cfg.scan_ny <= 32) ? 1 : 0;
+        return ROVER_OK;
+    }
     sim->scan_form = form;
     return ROVER_OK;
 }

@@ -17,7 +17,7 @@ CASES = [(1024, "group"), (4096, "group"), (4096, "lane"), (16384, "group"), (32
 if len(sys.argv) > 1:   # e.g. 1024:group 2048:group:wave  (third field: scan kernel of the step path, auto | generic | epi1)
     CASES = [tuple(a.split(":")) for a in sys.argv[1:]]
 import ctypes as C
-FORMS = {"auto": 0, "generic": 1, "epi1": 2}
+FORMS = {"auto": 0, "generic": 1, "epi1": 2, "blocks": 3, "lines": 4}   # blocks / lines: ray -> thread mapping of the step-form scan kernel
 for case in CASES:
     n, mapping, form = int(case[0]), case[1], (case[2] if len(case) > 2 else "auto")
     ter.make_spawns(2 * n)

@@ -12,7 +12,12 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 ter = T.make_procedural_terrain((2048, 2048)); ter.make_spawns(2 * n)
 cfg = RoverEnvCfg(); cfg.scene.num_envs = n; cfg.terrain.kind = "custom"
 cfg.roctx_markers = len(sys.argv) > 3 and sys.argv[3] == "markers"     # rocprofv3 --marker-trace: one range per env step
-env = RoverEnv(cfg, terrain=ter); env.reset()
+env = RoverEnv(cfg, terrain=ter)
+if os.environ.get("ROVER_SCAN_FORM"):   # 3 = 8 x 8 ray blocks per wave, 4 = lines (rover_debug_set_scan_form)
+    import ctypes as C
+    fn = C.CDLL(env._lib._name).rover_debug_set_scan_form; fn.argtypes = [C.c_void_p, C.c_int]
+    assert fn(env._h, int(os.environ["ROVER_SCAN_FORM"])) == 0
+env.reset()
 g = torch.Generator(device="cuda").manual_seed(0)
 acts = torch.rand(steps, n, 2, device="cuda", generator=g) * 2 - 1
 for k in range(steps):
