@@ -96,6 +96,11 @@ struct RvParams {
     int wq, pq;   // 16-byte chunks per heightfield row / per LDS tile row
     int tile_bufs; // LDS tile buffers of the scan kernel (2 when they fit beside full occupancy, else 1)
     int ray_blocks; // step-form scan kernel: 1 = wave w casts the 8 x 8 block (w & 3, w >> 2) of the ray grid (grids up to 32 x 32)
+    // extras["log"]: a wave of the step kernel writes its partial row only when one of its envs reset, tagged (word 15) with
+    // this launch's step_tag, and counts itself in *log_counter; the scan kernel reduces the rows carrying the tag -- or, in
+    // the common case of a step without resets, reads the counter and does nothing
+    uint32_t step_tag;
+    unsigned *log_counter;
 };
 
 // ------------------------------------------------------------------------------------------------ small helpers
@@ -1451,14 +1456,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     // :93 command update
     command_compute(p, S, gid, step_dt);
 
-    // wavefront reductions of the log partials (one row per wave)
+    // wavefront reductions of the log partials (one row per wave) -- only in waves where some env reset
+    if (__ballot(do_reset && active) != 0ull) {
 #pragma unroll
-    for (int i = 0; i < 14; ++i) lg[i] = wave_sum(lg[i]);
-    if (threadIdx.x < 14) {
-        float vsel = 0.0f;
+        for (int i = 0; i < 14; ++i) lg[i] = wave_sum(lg[i]);
+        if (threadIdx.x < 16) {
+            float vsel = threadIdx.x == 15 ? __uint_as_float(p.step_tag) : 0.0f;
 #pragma unroll
-        for (int i = 0; i < 14; ++i) vsel = (threadIdx.x == i) ? lg[i] : vsel;
-        log_partial[(size_t)blockIdx.x * ROVER_LOG_WORDS + threadIdx.x] = vsel;
+            for (int i = 0; i < 14; ++i) vsel = (threadIdx.x == i) ? lg[i] : vsel;
+            log_partial[(size_t)blockIdx.x * ROVER_LOG_WORDS + threadIdx.x] = vsel;
+        }
+        if (threadIdx.x == 0) atomicAdd(p.log_counter, 1u);
     }
 
     if (active) {
@@ -1794,17 +1802,16 @@ __global__ __launch_bounds__(RV_K1G_THREADS) void rover_step_kernel_group(RvPara
     command_compute(p, S, gid, step_dt);
     K1_STAMP(22);
 
-    if (any_reset) {
+    if (any_reset) {   // this wave's row of the log partials, tagged with the step; counted for the scan kernel's reduction
 #pragma unroll
         for (int i = 0; i < 14; ++i) lg[i] = wave_sum(lg[i]);
-    }
-    if (lane < 14) {
-        float vsel = 0.0f;
-        if (any_reset) {   // otherwise every lg[] is the +0 it was initialised to
+        if (lane < 16) {
+            float vsel = lane == 15 ? __uint_as_float(p.step_tag) : 0.0f;
 #pragma unroll
             for (int i = 0; i < 14; ++i) vsel = (lane == i) ? lg[i] : vsel;
+            log_partial[(size_t)wave * ROVER_LOG_WORDS + lane] = vsel;
         }
-        log_partial[(size_t)wave * ROVER_LOG_WORDS + lane] = vsel;
+        if (lane == 0) atomicAdd(p.log_counter, 1u);
     }
     if (writer) {
         write_obs_head(p, S, obs, e);
@@ -1925,15 +1932,33 @@ __device__ __forceinline__ float patch_height(const cell_t *q, int pitch, float 
     const float hx1 = h10 + fx * dx1;
     return hx0 + fy * (hx1 - hx0);
 }
-// deterministic reduction of the per-wave log partials by ONE workgroup: GROUPS x 16 words, then a fixed-order sum
+// extras["log"]: deterministic reduction of the per-wave log partials by the threads of ONE workgroup (workgroup 0 of the
+// scan kernel, after its last env): rows carrying this step's tag, GROUPS x 16 words, then a fixed-order sum.  In a step
+// without resets -- the common case -- the counter is zero and nothing is read.  (Until round 3 an EXTRA workgroup summed
+// all n_waves rows every step; it was dispatched last, i.e. when the first persistent workgroup retired, so its whole
+// duration sat on the kernel's tail: ~2 us at 4096 envs, and 150 us at 131072 envs after the group-mapped step kernel,
+// whose waves hold 4 envs instead of 64 -- the "N = 131072 anomaly" of the round-2 sweep.)
 template <int THREADS>
-__device__ __forceinline__ void reduce_log_partials(const rover_config &c, float *lds, int tid, const float *__restrict__ log_partial,
+__device__ __forceinline__ void reduce_log_partials(const RvParams &p, float *lds, int tid, const float *__restrict__ log_partial,
                                                     int n_waves, float *__restrict__ log_out)
 {
+    const rover_config &c = p.cfg;
+#ifdef RV_K2_NOREDUCE   // diagnostic build (wrong extras["log"]): what does the reduction cost the scan kernel?
+    if (n_waves >= 0) return;
+#endif
+    const unsigned resets = *reinterpret_cast<volatile unsigned *>(p.log_counter);
+    if (resets == 0u) {
+        if (tid == 0) log_out[13] = 0.0f;
+        return;
+    }
     constexpr int GROUPS = THREADS / 16;
     const int word = tid & 15, grp = tid >> 4;
     float acc = 0.0f;
-    for (int w = grp; w < n_waves; w += GROUPS) acc += log_partial[(size_t)w * ROVER_LOG_WORDS + word];
+    for (int w = grp; w < n_waves; w += GROUPS) {
+        const float tag = log_partial[(size_t)w * ROVER_LOG_WORDS + 15];
+        const float v = log_partial[(size_t)w * ROVER_LOG_WORDS + word];
+        acc += __float_as_uint(tag) == p.step_tag ? v : 0.0f;
+    }
     lds[grp * 16 + word] = acc;
     __syncthreads();
     if (tid < 16) {
@@ -1956,6 +1981,7 @@ __device__ __forceinline__ void reduce_log_partials(const rover_config &c, float
             log_out[tid] = val;
         }
     }
+    if (tid == 0) *p.log_counter = 0u;
 }
 #ifndef RV_K2_THREADS
 #define RV_K2_THREADS 512   // 8 waves share the LDS tiles; <= 40 KiB of LDS per workgroup admits 4 workgroups = 32 waves per CU
@@ -1973,14 +1999,10 @@ __global__ __launch_bounds__(RV_K2_THREADS) __attribute__((amdgpu_waves_per_eu(8
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x;
     const int N = p.n;
-    if (MODE == 2 && blockIdx.x == gridDim.x - 1) {
-        reduce_log_partials<RV_K2_THREADS>(p.cfg, lds, tid, log_partial, n_waves, log_out);
-        return;
-    }
     const rover_config &c = p.cfg;
     // persistent workgroups: the grid is sized to what the chip holds at once (launching one 8-wave workgroup per env
     // costs ~10 us of dispatch alone at N = 4096); each workgroup walks envs blockIdx.x, blockIdx.x + n_wg, ...
-    const int n_wg = (int)gridDim.x - (MODE == 2 ? 1 : 0);
+    const int n_wg = (int)gridDim.x;
 #ifdef RV_K2_EMPTY
     if (N > 0) return;  // diagnostic build: launch cost of the grid alone
 #endif
@@ -2167,6 +2189,10 @@ __global__ __launch_bounds__(RV_K2_THREADS) __attribute__((amdgpu_waves_per_eu(8
     wn = wnn;
     e = e_next;
     }  // env loop
+    if (MODE == 2 && blockIdx.x == 0) {   // workgroup 0, after its last env: extras["log"] of this step (usually one counter read)
+        __syncthreads();                  // the tiles are dead: the reduction reuses the LDS
+        reduce_log_partials<RV_K2_THREADS>(p, lds, tid, log_partial, n_waves, log_out);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ K2, step form
@@ -2195,13 +2221,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8), 
 {
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x;
-    if (blockIdx.x == gridDim.x - 1) {
-        reduce_log_partials<THREADS>(p.cfg, lds, tid, log_partial, n_waves, log_out);
-        return;
-    }
     const rover_config &c = p.cfg;
     const int N = p.n;
-    const int n_wg = (int)gridDim.x - 1;
+    const int n_wg = (int)gridDim.x;
     using cell_t = typename std::conditional<Q16, int16_t, float>::type;
     constexpr int CC = Q16 ? 8 : 4;  // cells per 16-byte chunk
     typedef float v4f __attribute__((ext_vector_type(4)));
@@ -2355,6 +2377,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8), 
         to_cast();
         e0 = e_next;
     }
+    if (blockIdx.x == 0) {   // workgroup 0, after its last pair of envs: extras["log"] of this step (usually one counter read)
+        __syncthreads();     // the tiles are dead: the reduction reuses the LDS
+        reduce_log_partials<THREADS>(p, lds, tid, log_partial, n_waves, log_out);
+    }
 }
 
 // ================================================================================================ unit kernels
@@ -2465,6 +2491,7 @@ struct rover_sim {
     int scan_wgs;      // persistent scan workgroups: what the device holds at once
     int scan_form;     // measurement hook: 1 = the generic scan kernel on the step path too
     bool markers;      // roctx ranges around the launches of rover_step (rover_set_markers)
+    uint32_t log_serial; // tag of the log-partial rows of the launch under way
 };
 
 
@@ -2484,6 +2511,8 @@ static void next_batch(rover_sim *sim)
     while (n > 1 && gcd_u32(a, n) != 1u) a = (a + 1u) % n;
     p.spawn_a = a;
     p.spawn_b = n > 0 ? r[1] % n : 0u;
+    p.step_tag = ++sim->log_serial;   // launches of THIS handle (not the restorable call counter: a resumed env must not
+                                      // meet rows an earlier pass through the same counter values left behind); starts at 1
     ++sim->counter;
 }
 
@@ -2497,7 +2526,7 @@ struct ScanForm {
 static ScanForm scan_form_of(const rover_sim *sim, int mode)
 {
     ScanForm f;
-    f.grid = (sim->p.n < sim->scan_wgs ? sim->p.n : sim->scan_wgs) + (mode == 2 ? 1 : 0);
+    f.grid = sim->p.n < sim->scan_wgs ? sim->p.n : sim->scan_wgs;
     f.q16 = sim->p.height_q != nullptr;
     f.tri = sim->p.cfg.scan_surface == 0;
     const int cc = f.q16 ? 8 : 4;
@@ -2510,7 +2539,7 @@ static ScanForm scan_form_of(const rover_sim *sim, int mode)
                                                                                          : 192 * sizeof(float) + f.epi * tile_bytes;
     if (f.simple) {
         const int groups = (sim->p.n + f.epi - 1) / f.epi, wgs = 2 * sim->n_cu;   // two 1024-thread workgroups per CU (one per CU: 19.7 vs 17.8 us)
-        f.grid = (groups < wgs ? groups : wgs) + 1;
+        f.grid = groups < wgs ? groups : wgs;
     }
     return f;
 }
@@ -2642,7 +2671,8 @@ int rover_create(const rover_config *cfg, int32_t num_envs, int32_t env_id_offse
     s->n_waves = s->group_mapping ? s->step_blocks * (RV_K1G_THREADS / 64) : s->step_blocks;
     // workspace: [log partials, padded to 128 B][scan descriptors: n x 32 B]
     s->ws_log_floats = (((size_t)(((num_envs + RV_K1G_ENVS - 1) / RV_K1G_ENVS) * (RV_K1G_THREADS / 64)) * ROVER_LOG_WORDS) + 31) & ~(size_t)31;
-    s->ws_bytes = (s->ws_log_floats + (size_t)num_envs * 8) * sizeof(float);
+    // workspace: [log partials][scan descriptors n x 8 floats, padded to 128 B][the reset-wave counter, 128 B]
+    s->ws_bytes = (((s->ws_log_floats + (size_t)num_envs * 8) * sizeof(float) + 127) & ~(size_t)127) + 128;
     *out = s;
     return ROVER_OK;
 }
@@ -2713,6 +2743,11 @@ int rover_bind(rover_sim *sim, float *state, void *workspace, size_t workspace_b
     sim->state = state;
     sim->log_partial = static_cast<float *>(workspace);
     sim->p.scan_desc = sim->log_partial + sim->ws_log_floats;
+    sim->p.log_counter = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + sim->ws_bytes - 128);
+    {
+        DeviceGuard guard(sim->device);
+        HIP_TRY(hipMemset(sim->p.log_counter, 0, 128));   // init-time, synchronous; the scan kernel returns it to zero after every reduction
+    }
     return ROVER_OK;
 }
 

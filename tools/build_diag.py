@@ -19,7 +19,7 @@ from isaac_rover_orbit_amd import build as b  # noqa: E402
 
 VARIANTS = {"STAMP": ("rover_kernels.hip", "-DRV_K2_STAMP"), "K1STAMP": ("rover_kernels.hip", "-DRV_K1_STAMP"),
             "K1STAMP_INK": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_K1_CONSTS_IN_KERNEL"),
-            "LIFTSTAMP": ("lift_kernels.hip", "-DLF_STAMP"),
+            "LIFTSTAMP": ("lift_kernels.hip", "-DLF_STAMP"), "NOREDUCE": ("rover_kernels.hip", "-DRV_K2_NOREDUCE"),
             "NOCOPY": ("rover_kernels.hip", "-DRV_K2_NO_COPY"),
             "NORAYS": ("rover_kernels.hip", "-DRV_K2_NO_RAYS"), "NOCOPYRAYS": ("rover_kernels.hip", "-DRV_K2_NO_RAYS -DRV_K2_NO_COPY"),
             "K1_INK": ("rover_kernels.hip", "-DRV_K1_CONSTS_IN_KERNEL"),
