@@ -2224,6 +2224,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8), 
     const rover_config &c = p.cfg;
     const int N = p.n;
     const int n_wg = (int)gridDim.x;
+#ifdef RV_K2_EMPTY   // timing experiment: dispatch + drain of the grid alone
+    if (N > 0) return;
+#endif
     using cell_t = typename std::conditional<Q16, int16_t, float>::type;
     constexpr int CC = Q16 ? 8 : 4;  // cells per 16-byte chunk
     typedef float v4f __attribute__((ext_vector_type(4)));
@@ -2261,6 +2264,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8), 
     int e0 = blockIdx.x * EPI;
     if (e0 >= N) return;
     __syncthreads();  // table
+#ifdef RV_K2_PROLOGUE_ONLY   // timing experiment: dispatch + per-thread ray set-up, no env loop
+    if (N > 0) { if (ox[0] + oy[0] == 12345.678f) out[tid] = ox[0]; return; }
+#endif
 
     // asynchronous dense copy of a th x tw4 chunk window into LDS (see rover_scan_obs_kernel)
     auto issue_tile = [&](const float4 &d1, cell_t *tile) {
@@ -2364,8 +2370,21 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8), 
 #else
                 for (int m = 0; m < RPT; ++m) o[m] = ray_obs(ox[m], oy[m], fast_tag);
 #endif
+#if defined(RV_K2_STORE4)   // timing experiment (wrong values): the same bytes as 16-byte stores from every fourth lane
+                if ((tid & 3) == 0) {
+                    if (tid + 3 < p.rays) {
+                        typedef float v4u __attribute__((ext_vector_type(4), aligned(4)));
+                        *reinterpret_cast<v4u *>(row + tid) = (v4u){o[0], o[0], o[0], o[0]};
+                    } else {
+                        for (int q = tid; q < p.rays; ++q) row[q] = o[0];
+                    }
+                }
+#elif defined(RV_K2_NOSTORE)   // timing experiment: no observation stores at all (only thread 0 keeps the values alive)
+                if (tid == 0 && o[0] == 12345.678f) row[0] = o[0];
+#else
 #pragma unroll
                 for (int m = 0; m < RPT; ++m) row[ray[m]] = o[m];
+#endif
             };
             if ((pk[j] >> 15) & 1) all_rays(std::true_type{});
             else all_rays(std::false_type{});

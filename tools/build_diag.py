@@ -20,6 +20,10 @@ from isaac_rover_orbit_amd import build as b  # noqa: E402
 VARIANTS = {"STAMP": ("rover_kernels.hip", "-DRV_K2_STAMP"), "K1STAMP": ("rover_kernels.hip", "-DRV_K1_STAMP"),
             "K1STAMP_INK": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_K1_CONSTS_IN_KERNEL"),
             "LIFTSTAMP": ("lift_kernels.hip", "-DLF_STAMP"), "NOREDUCE": ("rover_kernels.hip", "-DRV_K2_NOREDUCE"),
+            "SKEL_STORE4": ("rover_kernels.hip", "-DRV_K2_NO_RAYS -DRV_K2_NO_COPY -DRV_K2_STORE4"),
+            "SKEL_NOSTORE": ("rover_kernels.hip", "-DRV_K2_NO_RAYS -DRV_K2_NO_COPY -DRV_K2_NOSTORE"),
+            "STORE4": ("rover_kernels.hip", "-DRV_K2_STORE4"),
+            "K2EMPTY": ("rover_kernels.hip", "-DRV_K2_EMPTY"), "K2PROLOGUE": ("rover_kernels.hip", "-DRV_K2_PROLOGUE_ONLY"),
             "NOCOPY": ("rover_kernels.hip", "-DRV_K2_NO_COPY"),
             "NORAYS": ("rover_kernels.hip", "-DRV_K2_NO_RAYS"), "NOCOPYRAYS": ("rover_kernels.hip", "-DRV_K2_NO_RAYS -DRV_K2_NO_COPY"),
             "K1_INK": ("rover_kernels.hip", "-DRV_K1_CONSTS_IN_KERNEL"),

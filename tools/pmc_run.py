@@ -4,6 +4,9 @@ import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if os.environ.get("ABLTAG"):   # diagnostic build of tools/build_diag.py
+    from isaac_rover_orbit_amd import _lib
+    _lib.LIB_PATH = os.path.join(ROOT, "build", "abl", f"librover_abl{os.environ['ABLTAG']}.so")
 from isaac_rover_orbit_amd import terrain as T
 from isaac_rover_orbit_amd.cfg import RoverEnvCfg
 from isaac_rover_orbit_amd.envs import RoverEnv
@@ -19,8 +22,8 @@ if os.environ.get("ROVER_SCAN_FORM"):   # 3 = 8 x 8 ray blocks per wave, 4 = lin
     assert fn(env._h, int(os.environ["ROVER_SCAN_FORM"])) == 0
 env.reset()
 g = torch.Generator(device="cuda").manual_seed(0)
-acts = torch.rand(steps, n, 2, device="cuda", generator=g) * 2 - 1
+acts = torch.rand(min(steps, 64), n, 2, device="cuda", generator=g) * 2 - 1
 for k in range(steps):
-    env.step(acts[k])
+    env.step(acts[k % acts.shape[0]])
 torch.cuda.synchronize()
 env.close()
