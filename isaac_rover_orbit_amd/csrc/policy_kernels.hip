@@ -18,6 +18,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 
@@ -192,6 +193,79 @@ __device__ __forceinline__ void mfma_all(v4f (&acc)[NT], const float *arow_ptr, 
     }
 }
 
+// A split-K layer for the 16 rows of the workgroup (see the header): the 8 waves each take a contiguous range of k groups for up
+// to POL_MAXT column tiles at once, raw partial accumulators go through `part`, and every thread combines one (row, column) in
+// the fixed order ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)), adds the bias and applies the activation.  Shared by the
+// descriptor-driven kernel and the reference-architecture kernel (same numerics by construction).
+struct SplitKArgs {
+    const v4f *W4;
+    const float *bias;
+    int K, N, G, T, act, rows, dst_pitch;
+    float slope;
+    bool last;
+    float *dst_out, *dst_act, *part;
+    const float *arow_ptr;
+};
+// combine step of a split-K pass: thread -> (row, column) with the column fastest; 16 * nt columns starting at tile t0
+__device__ __forceinline__ void split_k_combine(const SplitKArgs &A, int t0, int nt, int tid)
+{
+    constexpr int ppitch = 16 * POL_MAXT + 4;
+    const int ncols = 16 * nt;
+    const float inv = 1.0f / (float)ncols;
+    __syncthreads();
+    for (int e = tid; e < POL_ROWS * ncols; e += POL_THREADS) {
+        const int r = (int)(((float)e + 0.5f) * inv), c = e - r * ncols, col = 16 * t0 + c;   // e / ncols, exact here
+        float q[POL_WAVES];
+#pragma unroll
+        for (int w = 0; w < POL_WAVES; ++w) q[w] = A.part[(w * POL_ROWS + r) * ppitch + c];
+        const float sum = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+        if (r < A.rows && col < A.N) {
+            const float v = activate(sum + A.bias[col], A.act, A.slope);
+            if (A.last) A.dst_out[r * A.dst_pitch + col] = v;
+            else A.dst_act[r * A.dst_pitch + col] = v;
+        }
+    }
+}
+__device__ __forceinline__ void split_k_layer(const SplitKArgs &A, int tid, int lane, int wave, int arow, int akq)
+{
+    const v4f *W4 = A.W4;
+    const float *bias = A.bias;
+    const int K = A.K, N = A.N, G = A.G, T = A.T, rows = A.rows, dst_pitch = A.dst_pitch;
+    const bool last = A.last;
+    float *dst_out = A.dst_out, *dst_act = A.dst_act, *part = A.part;
+    const float *arow_ptr = A.arow_ptr;
+    struct { int act; } lay = {A.act};
+    struct { float leaky_slope; } d = {A.slope};
+    const int gw = ceil_div(G, POL_WAVES), g0 = min(wave * gw, G), g1 = min(g0 + gw, G);
+    const int ppitch = 16 * POL_MAXT + 4;
+    for (int t0 = 0; t0 < T; t0 += POL_MAXT) {
+        const int nt = min(POL_MAXT, T - t0);
+        const v4f *Wt = W4 + (size_t)t0 * G * 64 + lane;
+        if (t0 > 0) __syncthreads();  // the previous pass's partials have been combined
+        auto pass = [&](auto nt_tag) {
+            constexpr int NT = decltype(nt_tag)::value;
+            v4f acc[NT];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) acc[i] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+            mfma_groups<NT, POL_PF>(acc, arow_ptr, akq, K, Wt, (size_t)G * 64, g0, g1, G);
+            float *pw = part + (wave * POL_ROWS + 4 * akq) * ppitch + arow;
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pw[j * ppitch + 16 * i] = acc[i][j];
+        };
+        switch (nt) {
+            case 1: pass(std::integral_constant<int, 1>{}); break;
+            case 2: pass(std::integral_constant<int, 2>{}); break;
+            case 3: pass(std::integral_constant<int, 3>{}); break;
+            case 4: pass(std::integral_constant<int, 4>{}); break;
+            case 5: pass(std::integral_constant<int, 5>{}); break;
+            default: pass(std::integral_constant<int, 6>{}); break;
+        }
+        split_k_combine(A, t0, nt, tid);
+    }
+}
+
 // Packed weights of one layer: for column tile t (16 outputs), k group g (16 inputs = 4 MFMA k-steps), lane l:
 // a float4 {W[n][k0], W[n][k0 + 4], W[n][k0 + 8], W[n][k0 + 12]} with n = 16 t + (l & 15), k0 = 16 g + (l >> 4);
 // zero outside (N, K).  Index ((t * G + g) * 64 + l) * 4.
@@ -264,49 +338,10 @@ __global__ __launch_bounds__(POL_THREADS) void rover_policy_kernel(rover_policy_
         const float *arow_ptr = in + arow * in_pitch;
 
         if (lay.split_k) {
-            const int gw = ceil_div(G, POL_WAVES), g0 = min(wave * gw, G), g1 = min(g0 + gw, G);
-            const int ppitch = 16 * POL_MAXT + 4;
-            for (int t0 = 0; t0 < T; t0 += POL_MAXT) {
-                const int nt = min(POL_MAXT, T - t0);
-                const v4f *Wt = W4 + (size_t)t0 * G * 64 + lane;
-                if (t0 > 0) __syncthreads();  // the previous pass's partials have been combined
-                auto pass = [&](auto nt_tag) {
-                    constexpr int NT = decltype(nt_tag)::value;
-                    v4f acc[NT];
-#pragma unroll
-                    for (int i = 0; i < NT; ++i) acc[i] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-                    mfma_groups<NT, POL_PF>(acc, arow_ptr, akq, K, Wt, (size_t)G * 64, g0, g1, G);
-                    float *pw = part + (wave * POL_ROWS + 4 * akq) * ppitch + arow;
-#pragma unroll
-                    for (int i = 0; i < NT; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) pw[j * ppitch + 16 * i] = acc[i][j];
-                };
-                switch (nt) {
-                    case 1: pass(std::integral_constant<int, 1>{}); break;
-                    case 2: pass(std::integral_constant<int, 2>{}); break;
-                    case 3: pass(std::integral_constant<int, 3>{}); break;
-                    case 4: pass(std::integral_constant<int, 4>{}); break;
-                    case 5: pass(std::integral_constant<int, 5>{}); break;
-                    default: pass(std::integral_constant<int, 6>{}); break;
-                }
-                // combine: thread -> (row, column) with the column fastest; 16 * nt columns
-                const int ncols = 16 * nt;
-                const float inv = 1.0f / (float)ncols;
-                __syncthreads();
-                for (int e = tid; e < POL_ROWS * ncols; e += POL_THREADS) {
-                    const int r = (int)(((float)e + 0.5f) * inv), c = e - r * ncols, col = 16 * t0 + c;   // e / ncols, exact here
-                    float q[POL_WAVES];
-#pragma unroll
-                    for (int w = 0; w < POL_WAVES; ++w) q[w] = part[(w * POL_ROWS + r) * ppitch + c];
-                    const float sum = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
-                    if (r < rows && col < N) {
-                        const float v = activate(sum + bias[col], lay.act, d.leaky_slope);
-                        if (last) dst_out[r * dst_pitch + col] = v;
-                        else dst_act[r * dst_pitch + col] = v;
-                    }
-                }
-            }
+            SplitKArgs A;
+            A.W4 = W4; A.bias = bias; A.K = K; A.N = N; A.G = G; A.T = T; A.act = lay.act; A.rows = rows; A.dst_pitch = dst_pitch;
+            A.slope = d.leaky_slope; A.last = last; A.dst_out = dst_out; A.dst_act = dst_act; A.part = part; A.arow_ptr = arow_ptr;
+            split_k_layer(A, tid, lane, wave, arow, akq);
         } else {
             // column tiles wave, wave + 8, wave + 16, ... belong to this wave; up to four of them are carried at once
             for (int t0 = wave; t0 < T; t0 += 4 * POL_WAVES) {
@@ -370,6 +405,249 @@ __global__ __launch_bounds__(POL_THREADS) void rover_policy_kernel(rover_policy_
         in_pitch = L.act_pitch;
         float *t = cur; cur = nxt; nxt = t;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------- reference architecture
+// The network the reference builds (get_models.py:36-62): 965-wide rows, encoder 961 -> 80 -> 60 on obs[:, 3:-1], MLP
+// (4 + 60) -> 256 -> 160 -> 128 -> out (<= 16), split-K on the first and the last layer.  Same tiles, same chains, same
+// combine order as the descriptor-driven kernel above -- bit-identical results -- but every layer's shape is a compile-time
+// constant, so the B fragments of layer i + 1 are requested while layer i computes and are CARRIED IN REGISTERS across the
+// layer boundary: the generic loop starts every layer with an exposed L2 round trip (~4 k cycles of start-up per small layer,
+// tools/policy_stamps.py).  Register blocks: L2 5, L3 8, L4 32 (waves 0, 1 hold two column tiles), L5 10, L6 1 float4 per
+// lane; at most L4 + L5 = 42 float4 = 168 VGPRs are alive at once (two waves per SIMD: 256 available).
+template <int NT, int GC, int STRIDE>   // fragments b[g * STRIDE + i], i < NT
+__device__ __forceinline__ void ref_load(v4f (&b)[GC * STRIDE], const v4f *Wt, size_t tile_stride)
+{
+#pragma unroll
+    for (int g = 0; g < GC; ++g)
+#pragma unroll
+        for (int i = 0; i < NT; ++i) b[g * STRIDE + i] = Wt[i * tile_stride + (size_t)g * 64];
+}
+template <int NT, int GC, int STRIDE>
+__device__ __forceinline__ void ref_mfma(v4f (&acc)[NT], const float *arow_ptr, int akq, const v4f (&b)[GC * STRIDE])
+{
+    const float *ap = arow_ptr + akq;
+#pragma unroll
+    for (int g = 0; g < GC; ++g) {
+        float a[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = ap[16 * g + 4 * j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[g * STRIDE + i][j], acc[i], 0, 0, 0);
+    }
+}
+// epilogue of a full-K layer: tiles t0 + 8 i; LeakyReLU; into an LDS activation buffer
+template <int NT>
+__device__ __forceinline__ void ref_store(const v4f (&acc)[NT], const float (&bv)[NT], float *dst_act, int dst_pitch, int t0, int N,
+                                          int rows, int arow, int akq, float slope)
+{
+    float *pd = dst_act + 4 * akq * dst_pitch + 16 * t0 + arow;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (4 * akq + j < rows && 16 * (t0 + POL_WAVES * i) + arow < N)
+                pd[j * dst_pitch + 16 * POL_WAVES * i] = activate(acc[i][j] + bv[i], ROVER_ACT_LEAKY_RELU, slope);
+}
+
+__global__ __launch_bounds__(POL_THREADS) void rover_policy_ref_kernel(rover_policy_desc d, PolLaunch L,
+                                                                       const float *__restrict__ packed,
+                                                                       const float *__restrict__ obs, int n,
+                                                                       float *__restrict__ out)
+{
+    extern __shared__ __align__(16) float lds[];
+    packed += (size_t)(blockIdx.x % (unsigned)L.n_copies) * L.copy_floats;
+    PSTAMP(0);
+    float *tile = lds;
+    float *part = tile + L.tile_floats;
+    float *buf0 = part + L.part_floats;
+    float *buf1 = buf0 + POL_ROWS * L.act_pitch;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = blockIdx.x * POL_ROWS;
+    const int rows = min(POL_ROWS, n - row0);
+    constexpr int OBS = 965, PROP = 4, ENC_OFF = 3;
+    constexpr int G2 = 5, G3 = 4, G4 = 16, G5 = 10, G6 = 8;      // k groups of layers 2 .. 6 (K = 80, 64, 256, 160, 128)
+    const int pitch = L.act_pitch;
+    const float slope = d.leaky_slope;
+    const int arow = lane & 15, akq = lane >> 4;
+    auto Wof = [&](int li) { return reinterpret_cast<const v4f *>(packed + d.layers[li].w_off) + lane; };
+    auto Bof = [&](int li) { return packed + d.layers[li].b_off; };
+
+    // layer 1's weights do not depend on the observations: waves 0 .. 6 request the first half of their share (4 of 8 k groups
+    // x 5 column tiles = 20 fragments) BEFORE the tile copy and the second half right after it, so the 307 KB stream through
+    // the L2 port while the rows arrive, and the MFMAs below run as straight-line code behind counted waits.  Wave 7 holds
+    // the ragged end (k groups 56 .. 60, the last one a single input) and takes the generic queue.
+    // (Measured and dropped: no tile at all -- every wave fetching its own A fragments, 32 four-byte loads per lane, straight
+    // from global memory: 51 k cycles instead of 42 k; sixteen 16-byte row segments per load instruction are too many requests.)
+    constexpr int G1 = 61, GW1 = 8, T1 = 5, GH1 = GW1 / 2;
+    v4f f1a[GH1 * T1], f1b[GH1 * T1];   // first half now, second half once the tile copy's staging registers are free
+    const bool full1 = wave < 7;
+    if (full1) ref_load<T1, GH1, T1>(f1a, Wof(0) + (size_t)(wave * GW1) * 64, (size_t)G1 * 64);
+    // ---- observation rows -> LDS (as in the generic kernel)
+    {
+        const float *src = obs + (size_t)row0 * OBS;
+        const int total = rows * OBS, total_pad = POL_ROWS * OBS;
+        if (rows == POL_ROWS && (total & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+            const v4f *s4 = reinterpret_cast<const v4f *>(src);
+            v4f *t4 = reinterpret_cast<v4f *>(tile);
+            const int n4 = total / 4;
+            for (int i0 = tid; i0 < n4; i0 += 8 * POL_THREADS) {
+                v4f r[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) r[u] = __builtin_nontemporal_load(s4 + min(i0 + u * POL_THREADS, n4 - 1));
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (i0 + u * POL_THREADS < n4) t4[i0 + u * POL_THREADS] = r[u];
+            }
+        } else {
+            for (int i = tid; i < total_pad; i += POL_THREADS) tile[i] = i < total ? src[i] : 0.0f;
+        }
+    }
+    __syncthreads();
+    PSTAMP(1);
+
+    v4f f2[G2];
+    float bv2 = 0.0f;
+    const bool has2 = wave < 4;
+    // ---- layer 1: 961 -> 80, split-K, into buf0: accumulate (specialised for waves 0 .. 6), then the shared combine
+    {
+        SplitKArgs A;
+        A.W4 = reinterpret_cast<const v4f *>(packed + d.layers[0].w_off); A.bias = Bof(0);
+        A.K = d.layers[0].K; A.N = d.layers[0].N; A.G = G1; A.T = T1; A.act = d.layers[0].act;
+        A.rows = rows; A.dst_pitch = pitch; A.slope = slope; A.last = false; A.dst_out = out; A.dst_act = buf0; A.part = part;
+        A.arow_ptr = tile + ENC_OFF + arow * OBS;
+        constexpr int ppitch = 16 * POL_MAXT + 4;
+        v4f acc[T1];
+#pragma unroll
+        for (int i = 0; i < T1; ++i) acc[i] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+        if (full1) {
+            ref_load<T1, GH1, T1>(f1b, Wof(0) + (size_t)(wave * GW1 + GH1) * 64, (size_t)G1 * 64);
+            ref_mfma<T1, GH1, T1>(acc, A.arow_ptr + 16 * (wave * GW1), akq, f1a);
+            ref_mfma<T1, GH1, T1>(acc, A.arow_ptr + 16 * (wave * GW1 + GH1), akq, f1b);
+        } else mfma_groups<T1, POL_PF>(acc, A.arow_ptr, akq, A.K, A.W4 + lane, (size_t)G1 * 64, 7 * GW1, G1, G1);
+        float *pw = part + (wave * POL_ROWS + 4 * akq) * ppitch + arow;
+#pragma unroll
+        for (int i = 0; i < T1; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pw[j * ppitch + 16 * i] = acc[i][j];
+        // layer 2's fragments (column tile `wave` of 4; waves 4 .. 7 have none) travel under layer 1's combine
+        if (has2) {
+            ref_load<1, G2, 1>(f2, Wof(1) + (size_t)wave * G2 * 64, 0);
+            bv2 = Bof(1)[min(16 * wave + arow, d.layers[1].N - 1)];
+        }
+        split_k_combine(A, 0, T1, tid);
+    }
+    PSTAMP(2);
+    // layer 3's fragments (tiles wave, wave + 8 of 16) travel under layer 2
+    v4f f3[G3 * 2];
+    float bv3[2];
+    ref_load<2, G3, 2>(f3, Wof(2) + (size_t)wave * G3 * 64, (size_t)POL_WAVES * G3 * 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) bv3[i] = Bof(2)[16 * (wave + POL_WAVES * i) + arow];
+    __syncthreads();   // buf0 = layer 1's activations
+
+    // ---- layer 2: 80 -> 60 into buf1[:, 4 ..], proprioceptive columns in front (models.py:93-96)
+    if (has2) {
+        v4f acc[1] = {(v4f){0.0f, 0.0f, 0.0f, 0.0f}};
+        ref_mfma<1, G2, 1>(acc, buf0 + arow * pitch, akq, f2);
+        const float bv[1] = {bv2};
+        ref_store<1>(acc, bv, buf1 + PROP, pitch, wave, d.layers[1].N, rows, arow, akq, slope);
+    }
+    for (int e = tid; e < POL_ROWS * PROP; e += POL_THREADS) {
+        const int r = e / PROP, c = e - r * PROP;
+        buf1[r * pitch + c] = tile[r * OBS + c];
+    }
+    PSTAMP(3);
+    // layer 4's fragments (tiles wave, wave + 8 of 10: two for waves 0 and 1, one otherwise) travel under layer 3
+    v4f f4[G4 * 2];
+    float bv4[2];
+    const bool two4 = wave < 2;
+    if (two4) ref_load<2, G4, 2>(f4, Wof(3) + (size_t)wave * G4 * 64, (size_t)POL_WAVES * G4 * 64);
+    else ref_load<1, G4, 2>(f4, Wof(3) + (size_t)wave * G4 * 64, 0);
+    bv4[0] = Bof(3)[16 * wave + arow];
+    bv4[1] = Bof(3)[min(16 * (wave + POL_WAVES) + arow, d.layers[3].N - 1)];
+    __syncthreads();   // buf1 = MLP input
+
+    // ---- layer 3: 64 -> 256 into buf0
+    {
+        v4f acc[2] = {(v4f){0.0f, 0.0f, 0.0f, 0.0f}, (v4f){0.0f, 0.0f, 0.0f, 0.0f}};
+        ref_mfma<2, G3, 2>(acc, buf1 + arow * pitch, akq, f3);
+        ref_store<2>(acc, bv3, buf0, pitch, wave, d.layers[2].N, rows, arow, akq, slope);
+    }
+    PSTAMP(4);
+    // layer 5's fragments (tile `wave` of 8) travel under layer 4
+    v4f f5[G5];
+    ref_load<1, G5, 1>(f5, Wof(4) + (size_t)wave * G5 * 64, 0);
+    const float bv5 = Bof(4)[16 * wave + arow];
+    __syncthreads();   // buf0 = layer 3's activations
+
+    // ---- layer 4: 256 -> 160 into buf1
+    if (two4) {
+        v4f acc[2] = {(v4f){0.0f, 0.0f, 0.0f, 0.0f}, (v4f){0.0f, 0.0f, 0.0f, 0.0f}};
+        ref_mfma<2, G4, 2>(acc, buf0 + arow * pitch, akq, f4);
+        ref_store<2>(acc, bv4, buf1, pitch, wave, d.layers[3].N, rows, arow, akq, slope);
+    } else {
+        v4f acc[1] = {(v4f){0.0f, 0.0f, 0.0f, 0.0f}};
+        ref_mfma<1, G4, 2>(acc, buf0 + arow * pitch, akq, f4);
+        const float bv[1] = {bv4[0]};
+        ref_store<1>(acc, bv, buf1, pitch, wave, d.layers[3].N, rows, arow, akq, slope);
+    }
+    PSTAMP(5);
+    // layer 6's fragment (split-K: k group `wave` of 8, the one column tile) travels under layer 5
+    const v4f f6 = Wof(5)[(size_t)wave * 64];
+    __syncthreads();   // buf1 = layer 4's activations
+
+    // ---- layer 5: 160 -> 128 into buf0
+    {
+        v4f acc[1] = {(v4f){0.0f, 0.0f, 0.0f, 0.0f}};
+        ref_mfma<1, G5, 1>(acc, buf1 + arow * pitch, akq, f5);
+        const float bv[1] = {bv5};
+        ref_store<1>(acc, bv, buf0, pitch, wave, d.layers[4].N, rows, arow, akq, slope);
+    }
+    PSTAMP(6);
+    __syncthreads();   // buf0 = layer 5's activations
+
+    // ---- layer 6: 128 -> out, split-K with one k group per wave: the generic arithmetic (mfma_groups over [wave, wave + 1),
+    // partials through `part`, fixed combine order) with the fragment already in registers
+    {
+        const int N = d.layers[5].N, act = d.layers[5].act;
+        constexpr int ppitch = 16 * POL_MAXT + 4;
+        v4f acc = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+        const float *ap = buf0 + arow * pitch + 16 * wave + akq;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * j], f6[j], acc, 0, 0, 0);
+        float *pw = part + (wave * POL_ROWS + 4 * akq) * ppitch + arow;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pw[j * ppitch] = acc[j];
+        __syncthreads();
+        const float *bias = Bof(5);
+        float *dst_out = out + (size_t)row0 * N;
+        for (int e = tid; e < POL_ROWS * 16; e += POL_THREADS) {
+            const int r = e >> 4, c = e & 15;
+            float q[POL_WAVES];
+#pragma unroll
+            for (int w = 0; w < POL_WAVES; ++w) q[w] = part[(w * POL_ROWS + r) * ppitch + c];
+            const float sum = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+            if (r < rows && c < N) dst_out[r * N + c] = activate(sum + bias[c], act, slope);
+        }
+    }
+    PSTAMP(7);
+}
+
+// the shapes rover_policy_ref_kernel is written for
+bool is_reference_architecture(const rover_policy_desc *d)
+{
+    if (d->obs_dim != 965 || d->prop_dim != 4 || d->enc_offset != 3 || d->enc_dim != 961 || d->n_enc != 2 || d->n_mlp != 4) return false;
+    const int K[6] = {961, 80, 64, 256, 160, 128}, N[5] = {80, 60, 256, 160, 128};
+    for (int i = 0; i < 6; ++i) {
+        if (d->layers[i].K != K[i]) return false;
+        if (i < 5 && (d->layers[i].N != N[i] || d->layers[i].act != ROVER_ACT_LEAKY_RELU)) return false;
+        if ((d->layers[i].split_k != 0) != (i == 0 || i == 5)) return false;
+    }
+    return d->layers[5].N >= 1 && d->layers[5].N <= 16;
 }
 
 int check_desc(const rover_policy_desc *d)
@@ -478,13 +756,21 @@ int rover_policy_forward(const rover_policy_desc *d, const float *packed, int32_
     }
     L.part_floats = (part_floats + 3) & ~3;
     L.act_pitch = ((width + 3) & ~3) + 4;
-    const size_t lds = sizeof(float) * ((size_t)L.tile_floats + L.part_floats + 2 * POL_ROWS * L.act_pitch);
+    size_t lds = sizeof(float) * ((size_t)L.tile_floats + L.part_floats + 2 * POL_ROWS * L.act_pitch);
     if (lds > 160 * 1024) return rover_internal_fail(ROVER_ERR_UNSUPPORTED, "network too wide for the 160 KiB LDS");
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rover_policy_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // the reference's architecture has its own kernel (layer shapes at compile time, fragments carried across layers); every
+    // other descriptor runs the generic one.  ROVER_POLICY_GENERIC=1 forces the generic kernel (A/B measurements, tests).
+    static const bool force_generic = getenv("ROVER_POLICY_GENERIC") != nullptr && getenv("ROVER_POLICY_GENERIC")[0] == '1';
+    const bool ref = !force_generic && is_reference_architecture(d);
+    const void *kfn = ref ? reinterpret_cast<const void *>(rover_policy_ref_kernel) : reinterpret_cast<const void *>(rover_policy_kernel);
+    hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return rover_internal_fail(ROVER_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(rover_policy_kernel, dim3(ceil_div(n, POL_ROWS)), dim3(POL_THREADS), lds, static_cast<hipStream_t>(stream),
-                       *d, L, packed, obs, n, out);
+    if (ref)
+        hipLaunchKernelGGL(rover_policy_ref_kernel, dim3(ceil_div(n, POL_ROWS)), dim3(POL_THREADS), lds, static_cast<hipStream_t>(stream),
+                           *d, L, packed, obs, n, out);
+    else
+        hipLaunchKernelGGL(rover_policy_kernel, dim3(ceil_div(n, POL_ROWS)), dim3(POL_THREADS), lds, static_cast<hipStream_t>(stream),
+                           *d, L, packed, obs, n, out);
     e = hipGetLastError();
     if (e != hipSuccess) return rover_internal_fail(ROVER_ERR_HIP, "rover_policy_kernel launch: %s", hipGetErrorString(e));
     return ROVER_OK;
