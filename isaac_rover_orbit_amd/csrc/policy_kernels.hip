@@ -476,34 +476,40 @@ __global__ __launch_bounds__(POL_THREADS) void rover_policy_ref_kernel(rover_pol
     auto Wof = [&](int li) { return reinterpret_cast<const v4f *>(packed + d.layers[li].w_off) + lane; };
     auto Bof = [&](int li) { return packed + d.layers[li].b_off; };
 
-    // layer 1's weights do not depend on the observations: waves 0 .. 6 request the first half of their share (4 of 8 k groups
-    // x 5 column tiles = 20 fragments) BEFORE the tile copy and the second half right after it, so the 307 KB stream through
-    // the L2 port while the rows arrive, and the MFMAs below run as straight-line code behind counted waits.  Wave 7 holds
-    // the ragged end (k groups 56 .. 60, the last one a single input) and takes the generic queue.
-    // (Measured and dropped: no tile at all -- every wave fetching its own A fragments, 32 four-byte loads per lane, straight
-    // from global memory: 51 k cycles instead of 42 k; sixteen 16-byte row segments per load instruction are too many requests.)
-    constexpr int G1 = 61, GW1 = 8, T1 = 5, GH1 = GW1 / 2;
-    v4f f1a[GH1 * T1], f1b[GH1 * T1];   // first half now, second half once the tile copy's staging registers are free
+    // ---- observation rows -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers), and, queued right behind the
+    // copy, layer 1's weights: they do not depend on the observations.  Waves 0 .. 6 request their WHOLE share (8 k groups x 5
+    // column tiles: 30 fragments in front of the barrier, the last 10 right behind it) so that the 307 KB stream through the L2
+    // port while the rows arrive; the wait in front of the barrier is a counted vmcnt(30) -- the copy, not the weights -- and the MFMAs below run as straight-line
+    // code behind counted waits.  Wave 7 holds the ragged end (k groups 56 .. 60, the last one a single input) and takes the
+    // generic queue.  (Measured and dropped: no tile at all -- every wave fetching its own A fragments, 32 four-byte loads per
+    // lane, straight from global memory: 51 k cycles instead of 42 k; sixteen 16-byte row segments per load instruction are too
+    // many requests.)
+    constexpr int G1 = 61, GW1 = 8, T1 = 5, GA1 = 6, GB1 = GW1 - GA1;   // 6 of the 8 k groups up front, 2 behind the barrier
+    v4f f1a[GA1 * T1], f1b[GB1 * T1];
     const bool full1 = wave < 7;
-    if (full1) ref_load<T1, GH1, T1>(f1a, Wof(0) + (size_t)(wave * GW1) * 64, (size_t)G1 * 64);
-    // ---- observation rows -> LDS (as in the generic kernel)
     {
         const float *src = obs + (size_t)row0 * OBS;
         const int total = rows * OBS, total_pad = POL_ROWS * OBS;
-        if (rows == POL_ROWS && (total & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const bool dma = rows == POL_ROWS && (total & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+        if (dma) {
             const v4f *s4 = reinterpret_cast<const v4f *>(src);
             v4f *t4 = reinterpret_cast<v4f *>(tile);
-            const int n4 = total / 4;
-            for (int i0 = tid; i0 < n4; i0 += 8 * POL_THREADS) {
-                v4f r[8];
+            constexpr int n4 = POL_ROWS * OBS / 4;
+            const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) r[u] = __builtin_nontemporal_load(s4 + min(i0 + u * POL_THREADS, n4 - 1));
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (i0 + u * POL_THREADS < n4) t4[i0 + u * POL_THREADS] = r[u];
-            }
+            for (int i0 = 0; i0 < n4; i0 += POL_THREADS)
+                if (i0 + tid < n4)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(s4 + i0 + tid),
+                                                     (__attribute__((address_space(3))) void *)(t4 + i0 + wave_base), 16, 0, 0);
         } else {
             for (int i = tid; i < total_pad; i += POL_THREADS) tile[i] = i < total ? src[i] : 0.0f;
+        }
+        asm volatile("" ::: "memory");   // the weight loads below stay BEHIND the copy in issue order (the counted wait relies on it)
+        if (full1) {
+            ref_load<T1, GA1, T1>(f1a, Wof(0) + (size_t)(wave * GW1) * 64, (size_t)G1 * 64);
+            asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
     __syncthreads();
@@ -524,9 +530,9 @@ __global__ __launch_bounds__(POL_THREADS) void rover_policy_ref_kernel(rover_pol
 #pragma unroll
         for (int i = 0; i < T1; ++i) acc[i] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
         if (full1) {
-            ref_load<T1, GH1, T1>(f1b, Wof(0) + (size_t)(wave * GW1 + GH1) * 64, (size_t)G1 * 64);
-            ref_mfma<T1, GH1, T1>(acc, A.arow_ptr + 16 * (wave * GW1), akq, f1a);
-            ref_mfma<T1, GH1, T1>(acc, A.arow_ptr + 16 * (wave * GW1 + GH1), akq, f1b);
+            ref_load<T1, GB1, T1>(f1b, Wof(0) + (size_t)(wave * GW1 + GA1) * 64, (size_t)G1 * 64);
+            ref_mfma<T1, GA1, T1>(acc, A.arow_ptr + 16 * (wave * GW1), akq, f1a);
+            ref_mfma<T1, GB1, T1>(acc, A.arow_ptr + 16 * (wave * GW1 + GA1), akq, f1b);
         } else mfma_groups<T1, POL_PF>(acc, A.arow_ptr, akq, A.K, A.W4 + lane, (size_t)G1 * 64, 7 * GW1, G1, G1);
         float *pw = part + (wave * POL_ROWS + 4 * akq) * ppitch + arow;
 #pragma unroll
