@@ -333,6 +333,11 @@ def main():
                 bs = [(rs.uniform(-1, 1, nn) / np.sqrt(kk)).astype(np.float32) for kk, nn in zip(K, Nn + [out_dim])]
                 return RoverNet(ws, bs, n_enc=2, final_act=act, device=dev)
             actor, critic = net(2, "tanh"), net(1, "none")
+            if os.environ.get("ROVER_SCAN_FORM"):   # measurement hook: 5 / 6 = XCD-aware pair dealing of the scan kernel off / on
+                import ctypes as C
+                fn = C.CDLL(env._lib._name).rover_debug_set_scan_form
+                fn.argtypes = [C.c_void_p, C.c_int]
+                assert fn(env._h, int(os.environ["ROVER_SCAN_FORM"])) == 0
             obs = env.obs_buf["policy"]
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             t_act = t_val = t_env = 0.0

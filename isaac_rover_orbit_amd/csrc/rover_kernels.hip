@@ -101,6 +101,10 @@ struct RvParams {
     // the common case of a step without resets, reads the counter and does nothing
     uint32_t step_tag;
     unsigned *log_counter;
+    // step-form scan kernel, two envs per round: 1 = pairs are dealt to workgroups so that the eight pairs of a 16-row block of
+    // observations (rows 16 b .. 16 b + 15) are produced on ONE XCD, the XCD (b mod 8) on which workgroup b of a kernel with
+    // one workgroup per 16 rows -- the policy / value forward pass -- will run: its read then hits that XCD's L2
+    int xcd_rows;
 };
 
 // ------------------------------------------------------------------------------------------------ small helpers
@@ -2260,9 +2264,18 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8), 
         oy[m] = pattern_y(ray[m] / c.scan_nx);
     }
 
-    // envs of iteration `it`: (blockIdx.x + it n_wg) EPI + j, j < EPI; indices past the end repeat env N - 1 (same bits again)
-    int e0 = blockIdx.x * EPI;
-    if (e0 >= N) return;
+    // envs of iteration `it`: group (blockIdx.x + it n_wg), envs group * EPI + j, j < EPI; indices past the end repeat env N - 1
+    // (same bits again).  XCD-aware dealing (EPI = 2, p.xcd_rows): workgroup j runs on XCD j mod 8 (round-robin dispatch), and
+    // inside every aligned block of 64 groups the group index is transposed, g = 8 y + x -> 8 x + y, so that the eight pairs
+    // 8 b .. 8 b + 7 of a 16-row block all come from XCD b mod 8.  A bijection of the group indices: every env is still cast once.
+    const int n_groups = (N + EPI - 1) / EPI;
+    auto group_of = [&](int g) {
+        if (EPI == 2 && p.xcd_rows && (g | 63) < n_groups) g = (g & ~63) | ((g & 7) << 3) | ((g >> 3) & 7);
+        return g;
+    };
+    int gidx = blockIdx.x;
+    if (gidx >= n_groups) return;
+    int e0 = group_of(gidx) * EPI;
     __syncthreads();  // table
 #ifdef RV_K2_PROLOGUE_ONLY   // timing experiment: dispatch + per-thread ray set-up, no env loop
     if (N > 0) { if (ox[0] + oy[0] == 12345.678f) out[tid] = ox[0]; return; }
@@ -2316,8 +2329,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8), 
     for (int j = 0; j < EPI; ++j) issue_tile(a1[j], tile_base + j * tile_cells);
     to_cast();
     for (;;) {
-        const int e_next = e0 + n_wg * EPI;
-        const bool more = e_next < N;
+        const int g_next = gidx + n_wg;
+        const bool more = g_next < n_groups;
+        const int e_next = more ? group_of(g_next) * EPI : N;
         if (more) {   // scalar loads: they arrive under the ray phase
 #pragma unroll
             for (int j = 0; j < EPI; ++j) load_desc(e_next + j, a0[j], a1[j]);
@@ -2395,6 +2409,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8), 
         for (int j = 0; j < EPI; ++j) issue_tile(a1[j], tile_base + j * tile_cells);
         to_cast();
         e0 = e_next;
+        gidx = g_next;
     }
     if (blockIdx.x == 0) {   // workgroup 0, after its last pair of envs: extras["log"] of this step (usually one counter read)
         __syncthreads();     // the tiles are dead: the reduction reuses the LDS
@@ -2676,6 +2691,7 @@ int rover_create(const rover_config *cfg, int32_t num_envs, int32_t env_id_offse
     s->p.env_id_offset = env_id_offset;
     s->p.rays = cfg->scan_nx * cfg->scan_ny;
     s->p.obs_w = 4 + s->p.rays;
+    s->p.xcd_rows = 1;
     s->device = device;
     {
         int n_cu = 0;
@@ -3004,7 +3020,11 @@ int rover_height_scan(rover_sim *sim, float *scan, void *stream)
 // step form with one env per iteration
 int rover_debug_set_scan_form(rover_sim *sim, int form)
 {
-    if (!sim || form < 0 || form > 4) return ROVER_ERR_INVALID;
+    if (!sim || form < 0 || form > 6) return ROVER_ERR_INVALID;
+    if (form == 5 || form == 6) {   // 5 / 6: XCD-aware dealing of the env pairs off / on (measurement hook; default on)
+        sim->p.xcd_rows = form == 6;
+        return ROVER_OK;
+    }
     if (form >= 3) {   // 3 / 4: ray -> thread mapping of the step form: 8 x 8 blocks per wave / lines (measurement hook)
         sim->p.ray_blocks = (form == 3 && sim->p.cfg.scan_nx <= 32 && sim->p.cfg.scan_ny <= 32) ? 1 : 0;
         return ROVER_OK;
