@@ -355,11 +355,28 @@ def main():
                 obs = env.step(a_pol)[0]["policy"]
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / args.steps
+            # the same loop with both networks in ONE launch on one staged tile (rover_policy_forward_pair)
+            from isaac_rover_orbit_amd.policy import forward_pair
+            t_pair = 0.0
+            for k in range(reps + 5):
+                ev[0].record(); a_pol, _v = forward_pair(actor, critic, obs); ev[1].record()
+                obs = env.step(a_pol)[0]["policy"]
+                torch.cuda.synchronize()
+                if k >= 5:
+                    t_pair += ev[0].elapsed_time(ev[1])
+            t0 = time.perf_counter()
+            for k in range(args.steps):
+                a_pol, _v = forward_pair(actor, critic, obs)
+                obs = env.step(a_pol)[0]["policy"]
+            torch.cuda.synchronize()
+            dt_pair = (time.perf_counter() - t0) / args.steps
             flops = 2.0 * n * sum(kk * nn for kk, nn in zip(K, Nn + [2]))
             out["with_policy"] = {"ms_per_step": dt * 1e3, "env_steps_per_s": n / dt,
                                   "kernels_us_events": {"rover_policy_kernel (actor)": t_act / reps * 1e3 - ev_ms * 1e3,
                                                         "rover_policy_kernel (critic)": t_val / reps * 1e3 - ev_ms * 1e3,
                                                         "env.step (K1 + K2)": t_env / reps * 1e3 - ev_ms * 1e3},
+                                  "pair": {"ms_per_step": dt_pair * 1e3, "env_steps_per_s": n / dt_pair,
+                                           "rover_policy_ref_pair_kernel_us_events": t_pair / reps * 1e3 - ev_ms * 1e3},
                                   "observations_finite": bool(torch.isfinite(obs).all()),
                                   "actor_TFLOPs_f32": flops / ((t_act / reps - ev_ms) * 1e-3) / 1e12, "f32_mfma_peak_TFLOPs": 157.0,
                                   "note": "closed loop: the actor's mean action drives the env (observations with -inf rays are "

@@ -66,6 +66,14 @@ int rover_policy_pack(rover_policy_desc *d, const float *const *weights, const f
 int rover_policy_forward(const rover_policy_desc *d, const float *packed, int32_t n_copies, const float *obs, int32_t n,
                          float *out, void *stream);
 
+/* Two networks on the same observation rows in one launch -- the policy mean and the value a PPO rollout step asks for
+ * (skrl calls policy.act and value.act on the same states, rover_envs/utils/skrl_utils.py:114-135): the rows are fetched and
+ * staged once, one launch boundary disappears.  Each network's arithmetic is exactly rover_policy_forward's.  Both descriptors
+ * must be the reference architecture (get_models.py:36-62, rover_policy_default_desc); ROVER_ERR_UNSUPPORTED otherwise --
+ * call rover_policy_forward twice then.  out_a (n, N_last of a), out_b (n, N_last of b). */
+int rover_policy_forward_pair(const rover_policy_desc *da, const float *packed_a, const rover_policy_desc *db, const float *packed_b,
+                              int32_t n_copies, const float *obs, int32_t n, float *out_a, float *out_b, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,7 @@ EXPORTS = [
     "rover_terrain_rasterize", "rover_terrain_surface", "rover_terrain_rock_mask", "rover_terrain_scratch_bytes",   # rover_terrain.h
     "rover_set_terrain_lookup",
     "rover_policy_default_desc", "rover_policy_packed_floats", "rover_policy_pack", "rover_policy_forward",  # rover_policy.h
+    "rover_policy_forward_pair",
     "rover_lift_default_config", "rover_lift_config_bytes", "rover_lift_state_words", "rover_lift_create", "rover_lift_destroy",
     "rover_lift_workspace_bytes", "rover_lift_bind", "rover_lift_reset", "rover_lift_step", "rover_lift_terms",   # rover_lift.h
     "rover_lift_model_constants", "rover_lift_set_seed", "rover_lift_profile_step", "rover_lift_kernel_name",
@@ -159,6 +160,7 @@ def load():
     lib.rover_policy_packed_floats.restype = C.c_size_t
     lib.rover_policy_pack.argtypes = [C.POINTER(PolicyDesc), C.POINTER(vp), C.POINTER(vp), vp]
     lib.rover_policy_forward.argtypes = [C.POINTER(PolicyDesc), vp, i32, vp, i32, vp, vp]
+    lib.rover_policy_forward_pair.argtypes = [C.POINTER(PolicyDesc), vp, C.POINTER(PolicyDesc), vp, i32, vp, i32, vp, vp, vp]
     lib.rover_lift_default_config.argtypes = [C.POINTER(LiftConfig)]
     lib.rover_lift_config_bytes.restype = C.c_size_t
     lib.rover_lift_create.argtypes = [C.POINTER(LiftConfig), i32, i32, i32, C.POINTER(vp)]

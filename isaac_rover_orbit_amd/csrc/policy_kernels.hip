@@ -452,14 +452,14 @@ __device__ __forceinline__ void ref_store(const v4f (&acc)[NT], const float (&bv
                 pd[j * dst_pitch + 16 * POL_WAVES * i] = activate(acc[i][j] + bv[i], ROVER_ACT_LEAKY_RELU, slope);
 }
 
-__global__ __launch_bounds__(POL_THREADS) void rover_policy_ref_kernel(rover_policy_desc d, PolLaunch L,
-                                                                       const float *__restrict__ packed,
-                                                                       const float *__restrict__ obs, int n,
-                                                                       float *__restrict__ out)
+// STAGE_TILE: this network is the first of the launch and copies the observation rows into LDS; false: a second network on
+// the tile the first one staged (rover_policy_ref_pair_kernel: actor + critic of one rollout step read the rows ONCE).
+template <bool STAGE_TILE>
+__device__ __forceinline__ void ref_network(const rover_policy_desc &d, const PolLaunch &L, const float *__restrict__ packed,
+                                            const float *__restrict__ obs, int n, float *__restrict__ out, float *lds)
 {
-    extern __shared__ __align__(16) float lds[];
     packed += (size_t)(blockIdx.x % (unsigned)L.n_copies) * L.copy_floats;
-    PSTAMP(0);
+    if (STAGE_TILE) PSTAMP(0);
     float *tile = lds;
     float *part = tile + L.tile_floats;
     float *buf0 = part + L.part_floats;
@@ -491,7 +491,9 @@ __global__ __launch_bounds__(POL_THREADS) void rover_policy_ref_kernel(rover_pol
         const float *src = obs + (size_t)row0 * OBS;
         const int total = rows * OBS, total_pad = POL_ROWS * OBS;
         const bool dma = rows == POL_ROWS && (total & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
-        if (dma) {
+        if (!STAGE_TILE) {
+            // the rows are already in LDS
+        } else if (dma) {
             const v4f *s4 = reinterpret_cast<const v4f *>(src);
             v4f *t4 = reinterpret_cast<v4f *>(tile);
             constexpr int n4 = POL_ROWS * OBS / 4;
@@ -505,15 +507,14 @@ __global__ __launch_bounds__(POL_THREADS) void rover_policy_ref_kernel(rover_pol
             for (int i = tid; i < total_pad; i += POL_THREADS) tile[i] = i < total ? src[i] : 0.0f;
         }
         asm volatile("" ::: "memory");   // the weight loads below stay BEHIND the copy in issue order (the counted wait relies on it)
-        if (full1) {
-            ref_load<T1, GA1, T1>(f1a, Wof(0) + (size_t)(wave * GW1) * 64, (size_t)G1 * 64);
-            asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (full1) ref_load<T1, GA1, T1>(f1a, Wof(0) + (size_t)(wave * GW1) * 64, (size_t)G1 * 64);
+        if (STAGE_TILE) {
+            if (full1) asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
-    __syncthreads();
-    PSTAMP(1);
+    __syncthreads();   // first network: the tile is complete; second network: the first one's combine has read `part`, its buffers are dead
+    if (STAGE_TILE) PSTAMP(1);
 
     v4f f2[G2];
     float bv2 = 0.0f;
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(POL_THREADS) void rover_policy_ref_kernel(rover_pol
         }
         split_k_combine(A, 0, T1, tid);
     }
-    PSTAMP(2);
+    if (STAGE_TILE) PSTAMP(2);
     // layer 3's fragments (tiles wave, wave + 8 of 16) travel under layer 2
     v4f f3[G3 * 2];
     float bv3[2];
@@ -566,7 +567,7 @@ __global__ __launch_bounds__(POL_THREADS) void rover_policy_ref_kernel(rover_pol
         const int r = e / PROP, c = e - r * PROP;
         buf1[r * pitch + c] = tile[r * OBS + c];
     }
-    PSTAMP(3);
+    if (STAGE_TILE) PSTAMP(3);
     // layer 4's fragments (tiles wave, wave + 8 of 10: two for waves 0 and 1, one otherwise) travel under layer 3
     v4f f4[G4 * 2];
     float bv4[2];
@@ -583,7 +584,7 @@ __global__ __launch_bounds__(POL_THREADS) void rover_policy_ref_kernel(rover_pol
         ref_mfma<2, G3, 2>(acc, buf1 + arow * pitch, akq, f3);
         ref_store<2>(acc, bv3, buf0, pitch, wave, d.layers[2].N, rows, arow, akq, slope);
     }
-    PSTAMP(4);
+    if (STAGE_TILE) PSTAMP(4);
     // layer 5's fragments (tile `wave` of 8) travel under layer 4
     v4f f5[G5];
     ref_load<1, G5, 1>(f5, Wof(4) + (size_t)wave * G5 * 64, 0);
@@ -601,7 +602,7 @@ __global__ __launch_bounds__(POL_THREADS) void rover_policy_ref_kernel(rover_pol
         const float bv[1] = {bv4[0]};
         ref_store<1>(acc, bv, buf1, pitch, wave, d.layers[3].N, rows, arow, akq, slope);
     }
-    PSTAMP(5);
+    if (STAGE_TILE) PSTAMP(5);
     // layer 6's fragment (split-K: k group `wave` of 8, the one column tile) travels under layer 5
     const v4f f6 = Wof(5)[(size_t)wave * 64];
     __syncthreads();   // buf1 = layer 4's activations
@@ -613,7 +614,7 @@ __global__ __launch_bounds__(POL_THREADS) void rover_policy_ref_kernel(rover_pol
         const float bv[1] = {bv5};
         ref_store<1>(acc, bv, buf0, pitch, wave, d.layers[4].N, rows, arow, akq, slope);
     }
-    PSTAMP(6);
+    if (STAGE_TILE) PSTAMP(6);
     __syncthreads();   // buf0 = layer 5's activations
 
     // ---- layer 6: 128 -> out, split-K with one k group per wave: the generic arithmetic (mfma_groups over [wave, wave + 1),
@@ -640,7 +641,29 @@ __global__ __launch_bounds__(POL_THREADS) void rover_policy_ref_kernel(rover_pol
             if (r < rows && c < N) dst_out[r * N + c] = activate(sum + bias[c], act, slope);
         }
     }
-    PSTAMP(7);
+    if (STAGE_TILE) PSTAMP(7);
+}
+
+__global__ __launch_bounds__(POL_THREADS) void rover_policy_ref_kernel(rover_policy_desc d, PolLaunch L,
+                                                                       const float *__restrict__ packed,
+                                                                       const float *__restrict__ obs, int n,
+                                                                       float *__restrict__ out)
+{
+    extern __shared__ __align__(16) float lds[];
+    ref_network<true>(d, L, packed, obs, n, out, lds);
+}
+// Two networks of the reference architecture on the same observation rows in ONE launch (the policy mean and the value of a
+// rollout step): the 62 KB of rows per workgroup are fetched and staged once, the second network starts on a warm tile, and
+// one launch boundary disappears.  Same arithmetic per network as rover_policy_ref_kernel (the same device function).
+__global__ __launch_bounds__(POL_THREADS) void rover_policy_ref_pair_kernel(rover_policy_desc da, rover_policy_desc db, PolLaunch La,
+                                                                            PolLaunch Lb, const float *__restrict__ packed_a,
+                                                                            const float *__restrict__ packed_b,
+                                                                            const float *__restrict__ obs, int n,
+                                                                            float *__restrict__ out_a, float *__restrict__ out_b)
+{
+    extern __shared__ __align__(16) float lds[];
+    ref_network<true>(da, La, packed_a, obs, n, out_a, lds);
+    ref_network<false>(db, Lb, packed_b, obs, n, out_b, lds);
 }
 
 // the shapes rover_policy_ref_kernel is written for
@@ -779,6 +802,49 @@ int rover_policy_forward(const rover_policy_desc *d, const float *packed, int32_
                            *d, L, packed, obs, n, out);
     e = hipGetLastError();
     if (e != hipSuccess) return rover_internal_fail(ROVER_ERR_HIP, "rover_policy_kernel launch: %s", hipGetErrorString(e));
+    return ROVER_OK;
+}
+
+int rover_policy_forward_pair(const rover_policy_desc *da, const float *packed_a, const rover_policy_desc *db, const float *packed_b,
+                              int32_t n_copies, const float *obs, int32_t n, float *out_a, float *out_b, void *stream)
+{
+    if (int rc = check_desc(da)) return rc;
+    if (int rc = check_desc(db)) return rc;
+    if (!packed_a || !packed_b || !obs || !out_a || !out_b || n < 1 || n_copies < 1) return rover_internal_fail(ROVER_ERR_INVALID, "bad argument");
+    if ((reinterpret_cast<uintptr_t>(packed_a) | reinterpret_cast<uintptr_t>(packed_b)) & 15)
+        return rover_internal_fail(ROVER_ERR_INVALID, "packed weights must be 16-byte aligned");
+    if (!is_reference_architecture(da) || !is_reference_architecture(db))
+        return rover_internal_fail(ROVER_ERR_UNSUPPORTED, "rover_policy_forward_pair: both networks must have the reference architecture "
+                                                          "(call rover_policy_forward twice otherwise)");
+    PolLaunch L[2];
+    size_t lds = 0;
+    const rover_policy_desc *dd[2] = {da, db};
+    for (int k = 0; k < 2; ++k) {   // same LDS carve for both (identical shapes up to the last layer's width <= 16)
+        const rover_policy_desc *d = dd[k];
+        L[k].n_copies = n_copies;
+        L[k].copy_floats = (unsigned)rover_policy_packed_floats(d);
+        L[k].tile_floats = (POL_ROWS * d->obs_dim + 3) & ~3;
+        int width = d->prop_dim, part_floats = 0;
+        const int nl = d->n_enc + d->n_mlp;
+        for (int i = 0; i < nl; ++i) {
+            const int T = ceil_div(d->layers[i].N, 16);
+            const int pf = d->layers[i].split_k ? POL_WAVES * POL_ROWS * (16 * POL_MAXT + 4) : 0;
+            part_floats = part_floats > pf ? part_floats : pf;
+            const int w = 16 * T + ((d->n_enc > 0 && i == d->n_enc - 1) ? d->prop_dim : 0);
+            width = width > w ? width : w;
+        }
+        L[k].part_floats = (part_floats + 3) & ~3;
+        L[k].act_pitch = ((width + 3) & ~3) + 4;
+        const size_t need = sizeof(float) * ((size_t)L[k].tile_floats + L[k].part_floats + 2 * POL_ROWS * L[k].act_pitch);
+        lds = lds > need ? lds : need;
+    }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rover_policy_ref_pair_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return rover_internal_fail(ROVER_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(rover_policy_ref_pair_kernel, dim3(ceil_div(n, POL_ROWS)), dim3(POL_THREADS), lds, static_cast<hipStream_t>(stream),
+                       *da, *db, L[0], L[1], packed_a, packed_b, obs, n, out_a, out_b);
+    e = hipGetLastError();
+    if (e != hipSuccess) return rover_internal_fail(ROVER_ERR_HIP, "rover_policy_ref_pair_kernel launch: %s", hipGetErrorString(e));
     return ROVER_OK;
 }
 

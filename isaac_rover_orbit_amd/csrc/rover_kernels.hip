@@ -2395,6 +2395,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8), 
                 }
 #elif defined(RV_K2_NOSTORE)   // timing experiment: no observation stores at all (only thread 0 keeps the values alive)
                 if (tid == 0 && o[0] == 12345.678f) row[0] = o[0];
+#elif defined(RV_K2_NT_STORE)   // timing experiment: streaming stores (the rows do not stay dirty in L2 until the kernel boundary)
+#pragma unroll
+                for (int m = 0; m < RPT; ++m) __builtin_nontemporal_store(o[m], &row[ray[m]]);
 #else
 #pragma unroll
                 for (int m = 0; m < RPT; ++m) row[ray[m]] = o[m];

@@ -100,6 +100,34 @@ class RoverNet:
         return self.forward(obs)
 
 
+@torch.no_grad()
+def forward_pair(net_a: RoverNet, net_b: RoverNet, obs: torch.Tensor, out_a: torch.Tensor | None = None,
+                 out_b: torch.Tensor | None = None):
+    """Both networks on the same observation rows in ONE launch (``rover_policy_forward_pair``): what a PPO rollout step asks
+    for -- ``policy.act(states)`` and ``value.act(states)`` (skrl_utils.py:114-135) -- with the rows fetched once.  Bit-identical
+    to ``net_a(obs), net_b(obs)``; falls back to exactly those two calls when a network is not the reference architecture."""
+    if isinstance(obs, dict):
+        obs = obs["policy"]
+    if obs.dim() != 2 or obs.shape[1] != net_a.obs_dim or obs.dtype != torch.float32 or not obs.is_cuda:
+        raise ValueError(f"obs must be a float32 cuda tensor of shape (n, {net_a.obs_dim})")
+    obs = obs.contiguous()
+    n = int(obs.shape[0])
+    if out_a is None:
+        out_a = torch.empty((n, net_a.out_dim), dtype=torch.float32, device=obs.device)
+    if out_b is None:
+        out_b = torch.empty((n, net_b.out_dim), dtype=torch.float32, device=obs.device)
+    if net_a.n_copies != net_b.n_copies or obs.device != net_a.packed.device or obs.device != net_b.packed.device:
+        return net_a(obs, out_a), net_b(obs, out_b)
+    stream = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
+    with torch.cuda.device(obs.device):
+        rc = net_a._lib.rover_policy_forward_pair(C.byref(net_a.desc), net_a.packed.data_ptr(), C.byref(net_b.desc), net_b.packed.data_ptr(),
+                                                  net_a.n_copies, obs.data_ptr(), n, out_a.data_ptr(), out_b.data_ptr(), stream)
+    if rc == 4:      # ROVER_ERR_UNSUPPORTED: not the reference architecture
+        return net_a(obs, out_a), net_b(obs, out_b)
+    _lib.check(rc, "rover_policy_forward_pair")
+    return out_a, out_b
+
+
 def make_desc(shapes, n_enc: int, final_act: str, obs_dim: int, prop_dim: int, leaky_slope: float) -> "_lib.PolicyDesc":
     nl = len(shapes)
     if nl > _lib.POLICY_MAX_LAYERS or nl - n_enc < 1:

@@ -130,3 +130,28 @@ def test_generic_architectures(po):
     a = _generic_case(po, shapes, 2, "tanh", 965, 4, 33, seed=4, force_split=[1] * 6)
     b = _generic_case(po, shapes, 2, "tanh", 965, 4, 33, seed=4, force_split=[0] * 6)
     assert np.abs(a - b).max() < 1e-5 and not np.array_equal(a, b)   # same network, different (documented) summation cuts
+
+
+def test_forward_pair_equals_two_forwards():
+    """rover_policy_forward_pair (actor + critic of a rollout step on one staged tile, one launch) is bit-identical to two
+    rover_policy_forward calls -- for full batches, a ragged last tile and a single row; other architectures fall back."""
+    from isaac_rover_orbit_amd.policy import RoverNet, forward_pair
+    wa, ba = random_policy_weights(seed=3, out_dim=2)
+    wc, bc = random_policy_weights(seed=4, out_dim=1)
+    actor = RoverNet(wa, ba, n_enc=2, final_act="tanh")
+    critic = RoverNet(wc, bc, n_enc=2, final_act="none")
+    for n in (4096, 333, 1):
+        obs = torch.from_numpy(synthetic_obs(n, seed=n)).cuda()
+        a1, v1 = actor(obs), critic(obs)
+        a2, v2 = forward_pair(actor, critic, obs)
+        assert a2.shape == (n, 2) and v2.shape == (n, 1)
+        assert torch.equal(a1, a2) and torch.equal(v1, v2), n
+    # a non-reference architecture takes the two-call path (same results by construction)
+    rng = np.random.RandomState(0)
+    ws = [rng.uniform(-1, 1, (24, 4)).astype(np.float32) / 2, rng.uniform(-1, 1, (3, 24)).astype(np.float32) / 5]
+    bs = [np.zeros(24, np.float32), np.zeros(3, np.float32)]
+    small = RoverNet(ws, bs, n_enc=0, final_act="none")          # an MLP on the four proprioceptive columns only
+    obs = torch.from_numpy(synthetic_obs(64, seed=1)).cuda()
+    s1, v1 = small(obs), critic(obs)
+    s2, v2 = forward_pair(small, critic, obs)
+    assert torch.equal(s1, s2) and torch.equal(v1, v2)

@@ -22,7 +22,7 @@ VARIANTS = {"STAMP": ("rover_kernels.hip", "-DRV_K2_STAMP"), "K1STAMP": ("rover_
             "LIFTSTAMP": ("lift_kernels.hip", "-DLF_STAMP"), "NOREDUCE": ("rover_kernels.hip", "-DRV_K2_NOREDUCE"),
             "SKEL_STORE4": ("rover_kernels.hip", "-DRV_K2_NO_RAYS -DRV_K2_NO_COPY -DRV_K2_STORE4"),
             "SKEL_NOSTORE": ("rover_kernels.hip", "-DRV_K2_NO_RAYS -DRV_K2_NO_COPY -DRV_K2_NOSTORE"),
-            "STORE4": ("rover_kernels.hip", "-DRV_K2_STORE4"),
+            "STORE4": ("rover_kernels.hip", "-DRV_K2_STORE4"), "NTSTORE": ("rover_kernels.hip", "-DRV_K2_NT_STORE"),
             "K2EMPTY": ("rover_kernels.hip", "-DRV_K2_EMPTY"), "K2PROLOGUE": ("rover_kernels.hip", "-DRV_K2_PROLOGUE_ONLY"),
             "NOCOPY": ("rover_kernels.hip", "-DRV_K2_NO_COPY"),
             "NORAYS": ("rover_kernels.hip", "-DRV_K2_NO_RAYS"), "NOCOPYRAYS": ("rover_kernels.hip", "-DRV_K2_NO_RAYS -DRV_K2_NO_COPY"),
