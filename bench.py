@@ -339,15 +339,17 @@ def main():
                 fn.argtypes = [C.c_void_p, C.c_int]
                 assert fn(env._h, int(os.environ["ROVER_SCAN_FORM"])) == 0
             obs = env.obs_buf["policy"]
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            # per-kernel event times in the RUNNING loop (one event set per iteration, one synchronisation at the end: a
+            # synchronisation per iteration makes the actor the first kernel on an idle GPU and adds ~8 us to it)
             t_act = t_val = t_env = 0.0
             reps = max(args.profile_steps, 20)
-            for k in range(reps + 5):
+            evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps + 5)]
+            for ev in evs:
                 ev[0].record(); a_pol = actor(obs); ev[1].record(); critic(obs); ev[2].record()
                 obs = env.step(a_pol)[0]["policy"]; ev[3].record()
-                torch.cuda.synchronize()
-                if k >= 5:
-                    t_act += ev[0].elapsed_time(ev[1]); t_val += ev[1].elapsed_time(ev[2]); t_env += ev[2].elapsed_time(ev[3])
+            torch.cuda.synchronize()
+            for ev in evs[5:]:
+                t_act += ev[0].elapsed_time(ev[1]); t_val += ev[1].elapsed_time(ev[2]); t_env += ev[2].elapsed_time(ev[3])
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for k in range(args.steps):
@@ -358,12 +360,12 @@ def main():
             # the same loop with both networks in ONE launch on one staged tile (rover_policy_forward_pair)
             from isaac_rover_orbit_amd.policy import forward_pair
             t_pair = 0.0
-            for k in range(reps + 5):
+            for ev in evs:
                 ev[0].record(); a_pol, _v = forward_pair(actor, critic, obs); ev[1].record()
                 obs = env.step(a_pol)[0]["policy"]
-                torch.cuda.synchronize()
-                if k >= 5:
-                    t_pair += ev[0].elapsed_time(ev[1])
+            torch.cuda.synchronize()
+            for ev in evs[5:]:
+                t_pair += ev[0].elapsed_time(ev[1])
             t0 = time.perf_counter()
             for k in range(args.steps):
                 a_pol, _v = forward_pair(actor, critic, obs)

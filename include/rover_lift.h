@@ -95,6 +95,15 @@ int rover_lift_reset(rover_lift_sim *sim, float *obs, void *stream);
 int rover_lift_step(rover_lift_sim *sim, const float *action, float *obs, float *reward, uint8_t *terminated, uint8_t *truncated,
                     float *log, void *stream);
 
+/* extras["log"] on demand.  The reference fills the log dictionary inside _reset_idx and its consumers read it now and then
+ * (skrl_utils.py:139-142); the reduction behind `log` is a second, dependent launch per step (~1.6 us of 19).  With
+ * rover_lift_set_log_deferred(sim, 1) rover_lift_step leaves `log` alone and rover_lift_flush_log produces, at any later point
+ * on the same stream, exactly the vector the per-step reduction would hold there: [0..7] from the latest step in which an env
+ * reset, [8] = the number of envs reset in the latest step (0 when the latest resets are older).  Flush at most once per step
+ * (a second flush without a step in between reports [8] = 0).  Default: not deferred. */
+int rover_lift_set_log_deferred(rover_lift_sim *sim, int32_t deferred);
+int rover_lift_flush_log(rover_lift_sim *sim, float *log, void *stream);
+
 /* Profiling twin of rover_lift_step: the same launch bracketed by HIP events on `stream`; device time of the step kernel in
  * milliseconds and, next to it, what an event pair with nothing in between reports (the fixed cost the first figure
  * carries).  Synchronises -- measurement only (bench.py --config 5). */

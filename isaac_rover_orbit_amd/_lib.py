@@ -30,6 +30,7 @@ EXPORTS = [
     "rover_lift_default_config", "rover_lift_config_bytes", "rover_lift_state_words", "rover_lift_create", "rover_lift_destroy",
     "rover_lift_workspace_bytes", "rover_lift_bind", "rover_lift_reset", "rover_lift_step", "rover_lift_terms",   # rover_lift.h
     "rover_lift_model_constants", "rover_lift_set_seed", "rover_lift_profile_step", "rover_lift_kernel_name",
+    "rover_lift_set_log_deferred", "rover_lift_flush_log",
 ]
 POLICY_MAX_LAYERS = 8
 ACT_NONE, ACT_LEAKY_RELU, ACT_TANH = 0, 1, 2
@@ -173,6 +174,8 @@ def load():
     lib.rover_lift_model_constants.argtypes = [vp, i32]
     lib.rover_lift_set_seed.argtypes = [vp, C.c_uint32, C.c_uint32]
     lib.rover_lift_profile_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.rover_lift_set_log_deferred.argtypes = [vp, C.c_int32]
+    lib.rover_lift_flush_log.argtypes = [vp, vp, vp]
     lib.rover_lift_kernel_name.argtypes = [vp, C.c_char_p, C.c_size_t]
     lib.rover_lift_debug_set_lanes.argtypes = [vp, i32]
     lib.rover_lift_terms.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]

@@ -840,7 +840,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     LiftHot hc, const lift_config *__restrict__ cfg_dev, int n, int env_id_offset, float *__restrict__ state,
     const float *__restrict__ action, float *__restrict__ obs,
     float *__restrict__ reward, uint8_t *__restrict__ terminated, uint8_t *__restrict__ truncated, float *__restrict__ lg_out,
-    unsigned *__restrict__ counters)
+    unsigned *__restrict__ counters, uint32_t serial)
 {
     static_assert(LPE == 8 || LPE == 16, "eight lanes per env, optionally shadowed");
     constexpr float QDEF[9] = LF_Q_DEFAULT;
@@ -1034,24 +1034,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         reward[e] = total;
         terminated[e] = dropped ? 1 : 0;
         truncated[e] = time_out ? 1 : 0;
-        lg_out[(size_t)8 * n + e] = lg[8];                  // the reset flag of every env, every step
-        if (do_reset) {
+        if (do_reset) {     // rows tagged with the launch serial: the reduction (this step's or a deferred one) sums the LATEST tagged step
 #pragma unroll
             for (int i = 0; i < 8; ++i) lg_out[(size_t)i * n + e] = lg[i];
+            lg_out[(size_t)8 * n + e] = u2f(serial);
             atomicAdd(&counters[1], 1u);
+            counters[2] = serial;                           // every writer of a launch stores the same value; later launches follow in stream order
         }
     }
     LIFT_STAMP(17);
 }
 
-// extras["log"] of a step: means over the envs that reset in it.  One workgroup; when nobody reset -- the common case -- it
-// reads one counter and leaves (the launch then costs its ~2 us of dispatch, nothing else).  Otherwise a fixed-order
-// reduction: env e is summed by thread e % 256, the threads are combined by a fixed tree => deterministic.
+// extras["log"]: means over the envs that reset in the latest step that had resets.  One workgroup; when nobody reset since the
+// last reduction -- the common case -- it reads one counter and leaves.  Otherwise a fixed-order reduction over the rows tagged
+// with that step's launch serial: env e is summed by thread e % 256, the threads are combined by a fixed tree => deterministic.
+// log_out[0..7] keep their values between reductions; log_out[8] = number of envs that reset in the step `serial_now` (0 when the
+// latest resets are older).  Run after every step (rover_lift_step, default) or on demand (rover_lift_set_log_deferred +
+// rover_lift_flush_log: the same numbers at every flush, bit for bit, without a second launch per step).
 // (Measured alternatives: the round-2 form, one workgroup walking all 10 x n floats every step, took 21 us -- as long as
 // the step kernel; folding the reduction into the step kernel behind a "last wave" ticket cost ~5 us per step, because an
 // agent-scope release on this multi-XCD part is an L2 write-back and every wave waits for its atomic's round trip.)
 __global__ __launch_bounds__(256) void lift_log_kernel(lift_config c, int n, const float *__restrict__ lg, unsigned *counters,
-                                                       float *__restrict__ log_out)
+                                                       float *__restrict__ log_out, uint32_t serial_now)
 {
     __shared__ float part[4][9];
     const int t = threadIdx.x;
@@ -1059,11 +1063,12 @@ __global__ __launch_bounds__(256) void lift_log_kernel(lift_config c, int n, con
         if (t == 0) log_out[8] = 0.0f;
         return;
     }
+    const uint32_t tag = counters[2];
     float acc[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) acc[i] = 0.0f;
     for (int e = t; e < n; e += 256) {
-        if (lg[(size_t)8 * n + e] != 0.0f) {
+        if (f2u(lg[(size_t)8 * n + e]) == tag) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] += lg[(size_t)i * n + e];
             acc[8] += 1.0f;
@@ -1088,7 +1093,7 @@ __global__ __launch_bounds__(256) void lift_log_kernel(lift_config c, int n, con
         for (int i = 0; i < LIFT_NUM_REW; ++i) log_out[i] = tot[i] / cnt / c.max_episode_length_s;
         log_out[6] = tot[6];
         log_out[7] = tot[7];
-        log_out[8] = cnt;
+        log_out[8] = tag == serial_now ? cnt : 0.0f;
         counters[1] = 0u;
     }
 }
@@ -1122,6 +1127,8 @@ struct rover_lift_sim {
     int lanes_per_env;      // 8; 16 (shadowed upper half-rows) is a measurement option
     float *state, *lg;
     unsigned *counters;     // [1] envs reset in the step under way (cleared by the log kernel)
+    uint32_t log_serial;    // launch serial of the latest step (tags the log rows of the envs that reset in it); starts at 1
+    bool log_deferred;      // rover_lift_set_log_deferred: rover_lift_step does not launch the log reduction
     lift_config *cfg_dev;   // device copy of cfg (in the workspace), read by the tail of the step kernel
     bool cfg_dirty;         // host copy changed (rover_lift_set_seed): copy it over before the next launch
 };
@@ -1135,15 +1142,17 @@ static void launch_step(rover_lift_sim *sim, hipStream_t st, const float *action
         sim->cfg_dirty = false;
     }
     const LiftHot hc = hot_of(sim->cfg);
+    const uint32_t serial = ++sim->log_serial;
     const int lpe = sim->lanes_per_env, epw = 64 / lpe;
     const dim3 grid((sim->n + epw - 1) / epw), block(64);
     if (lpe == 16)
         hipLaunchKernelGGL(lift_step_kernel<16>, grid, block, 0, st, hc, sim->cfg_dev, sim->n, sim->env_id_offset, sim->state, action, obs,
-                           reward, terminated, truncated, sim->lg, sim->counters);
+                           reward, terminated, truncated, sim->lg, sim->counters, serial);
     else
         hipLaunchKernelGGL(lift_step_kernel<8>, grid, block, 0, st, hc, sim->cfg_dev, sim->n, sim->env_id_offset, sim->state, action, obs,
-                           reward, terminated, truncated, sim->lg, sim->counters);
-    hipLaunchKernelGGL(lift_log_kernel, dim3(1), dim3(256), 0, st, sim->cfg, sim->n, sim->lg, sim->counters, log);
+                           reward, terminated, truncated, sim->lg, sim->counters, serial);
+    if (!sim->log_deferred)
+        hipLaunchKernelGGL(lift_log_kernel, dim3(1), dim3(256), 0, st, sim->cfg, sim->n, sim->lg, sim->counters, log, serial);
 }
 
 extern "C" {
@@ -1202,7 +1211,7 @@ int rover_lift_create(const lift_config *cfg, int32_t num_envs, int32_t env_id_o
     rover_lift_sim *s = new (std::nothrow) rover_lift_sim();
     if (!s) return rover_internal_fail(ROVER_ERR_INVALID, "out of host memory");
     s->cfg = *cfg; s->n = num_envs; s->env_id_offset = env_id_offset; s->device = device; s->state = nullptr; s->lg = nullptr;
-    s->lanes_per_env = 8; s->counters = nullptr; s->cfg_dev = nullptr; s->cfg_dirty = false;
+    s->lanes_per_env = 8; s->counters = nullptr; s->cfg_dev = nullptr; s->cfg_dirty = false; s->log_serial = 0; s->log_deferred = false;
     *out = s;
     return ROVER_OK;
 }
@@ -1222,6 +1231,8 @@ int rover_lift_bind(rover_lift_sim *sim, float *state, void *workspace, size_t w
     sim->counters = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + lift_lg_bytes(sim));
     sim->cfg_dev = reinterpret_cast<lift_config *>(static_cast<char *>(workspace) + lift_lg_bytes(sim) + 128);
     HIP_TRY(hipMemset(sim->counters, 0, 128));     // init-time, synchronous: the log kernel keeps them at zero afterwards
+    HIP_TRY(hipMemset(sim->lg + (size_t)8 * sim->n, 0, (size_t)sim->n * sizeof(float)));   // no row carries a tag yet (serials start at 1)
+    sim->log_serial = 0;
     HIP_TRY(hipMemcpy(sim->cfg_dev, &sim->cfg, sizeof(lift_config), hipMemcpyHostToDevice));
     sim->cfg_dirty = false;
     return ROVER_OK;
@@ -1267,6 +1278,22 @@ int rover_lift_step(rover_lift_sim *sim, const float *action, float *obs, float 
     DeviceGuardL guard(sim->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
     launch_step(sim, st, action, obs, reward, terminated, truncated, log);
+    HIP_TRY(hipGetLastError());
+    return ROVER_OK;
+}
+int rover_lift_set_log_deferred(rover_lift_sim *sim, int32_t deferred)
+{
+    if (!sim) return rover_internal_fail(ROVER_ERR_INVALID, "sim is NULL");
+    sim->log_deferred = deferred != 0;
+    return ROVER_OK;
+}
+int rover_lift_flush_log(rover_lift_sim *sim, float *log, void *stream)
+{
+    if (!sim || !sim->state) return rover_internal_fail(ROVER_ERR_STATE, "rover_lift_bind has not been called");
+    if (!log) return rover_internal_fail(ROVER_ERR_INVALID, "log is NULL");
+    DeviceGuardL guard(sim->device);
+    hipLaunchKernelGGL(lift_log_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), sim->cfg, sim->n, sim->lg, sim->counters,
+                       log, sim->log_serial);
     HIP_TRY(hipGetLastError());
     return ROVER_OK;
 }

@@ -62,6 +62,9 @@ class LiftEnvCfg:
     ee_offset_z: float = 0.1034
     seed: int = 0
     solver_iterations: int = 8
+    # extras["log"]: "on_demand" reduces the episodic sums of the envs that reset when the dictionary is READ (same numbers, no
+    # second kernel launch per step); "every_step" runs the reduction behind every step like the C entry's default
+    log_reduction: str = "on_demand"
     env_id_offset: int = 0
 
     @property
@@ -88,6 +91,36 @@ class LiftEnvCfg:
         c.seed_lo, c.seed_hi = self.seed & 0xFFFFFFFF, (self.seed >> 32) & 0xFFFFFFFF
         c.solver_iterations = self.solver_iterations
         return c
+
+
+class _LogDict(dict):
+    """``extras["log"]``: a dict of 0-d device tensors (views of the env's log vector, as ORBIT's ``extras["log"]`` holds 0-d
+    tensors).  Every read access first lets the env run its pending reduction (``FrankaCubeLiftEnv.flush_log``), so that the
+    values are the ones a per-step reduction would have left there; iteration over keys alone does not need it."""
+
+    def __init__(self, env, items):
+        super().__init__(items)
+        self._env = env
+
+    def __getitem__(self, k):
+        self._env.flush_log()
+        return super().__getitem__(k)
+
+    def get(self, k, default=None):
+        self._env.flush_log()
+        return super().get(k, default)
+
+    def items(self):
+        self._env.flush_log()
+        return super().items()
+
+    def values(self):
+        self._env.flush_log()
+        return super().values()
+
+    def copy(self):
+        self._env.flush_log()
+        return dict(super().items())
 
 
 class _Managers:
@@ -123,7 +156,12 @@ class FrankaCubeLiftEnv(RLTaskEnv):
             self._trunc = [torch.zeros(n, dtype=torch.uint8, device=self.device) for _ in range(2)]
             self._log = torch.zeros(_lib.LIFT_LOG_WORDS, device=self.device)
         self._cur = 0
-        self._log_dict = {k: self._log[i] for i, k in enumerate(LOG_KEYS)}
+        self._log_pending = False
+        self._log_deferred = self.cfg.log_reduction == "on_demand"
+        if self.cfg.log_reduction not in ("on_demand", "every_step"):
+            raise ValueError("log_reduction must be 'on_demand' or 'every_step'")
+        _lib.check(self._lib.rover_lift_set_log_deferred(self._h, int(self._log_deferred)), "rover_lift_set_log_deferred")
+        self._log_dict = _LogDict(self, {k: self._log[i] for i, k in enumerate(LOG_KEYS)})
         self.extras = {"log": self._log_dict, "episode": self._log_dict}
         self.episode_length_buf = self.state[_lib.LIFT_EP_LEN].view(torch.int32)
         self.obs_buf = {"policy": self._obs[0]}
@@ -188,8 +226,16 @@ class FrankaCubeLiftEnv(RLTaskEnv):
         _lib.check(self._lib.rover_lift_step(self._h, _ptr(action), _ptr(self._obs[k]), _ptr(self._rew[k]), _ptr(self._term[k]),
                                              _ptr(self._trunc[k]), _ptr(self._log), self._stream()), "rover_lift_step")
         self.common_step_counter += 1
+        self._log_pending = self._log_deferred
         self.obs_buf = {"policy": self._obs[k]}
         return self.obs_buf, self._rew[k], self._term[k].view(torch.bool), self._trunc[k].view(torch.bool), self.extras
+
+    def flush_log(self):
+        """Bring ``extras["log"]`` up to date (``rover_lift_flush_log``).  Called by the log dictionary itself on any read; only
+        needed by code that kept a reference to one of its tensors from an earlier step."""
+        if self._log_pending:
+            self._log_pending = False
+            _lib.check(self._lib.rover_lift_flush_log(self._h, _ptr(self._log), self._stream()), "rover_lift_flush_log")
 
     def profile_step(self, action: torch.Tensor):
         """``step`` with HIP-event timing: returns ``(ms_step_kernel, ms_log_kernel)``, event overhead included.  Syncs."""
@@ -203,6 +249,7 @@ class FrankaCubeLiftEnv(RLTaskEnv):
                                                      _ptr(self._trunc[k]), _ptr(self._log), self._stream(), C.byref(a), C.byref(b)),
                    "rover_lift_profile_step")
         self.common_step_counter += 1
+        self._log_pending = self._log_deferred
         self.obs_buf = {"policy": self._obs[k]}
         return a.value, b.value
 
@@ -214,6 +261,7 @@ class FrankaCubeLiftEnv(RLTaskEnv):
 
     # checkpoint / resume: the state words + the RNG key are the whole environment (counter-based Philox)
     def state_dict(self) -> dict:
+        self.flush_log()
         return {"state": self.get_state().cpu(), "obs": self.obs_buf["policy"].detach().cpu().clone(),
                 "log": self._log.detach().cpu().clone(), "num_envs": self.num_envs,
                 "common_step_counter": int(self.common_step_counter),
@@ -223,6 +271,7 @@ class FrankaCubeLiftEnv(RLTaskEnv):
         if int(sd["num_envs"]) != self.num_envs or tuple(sd["state"].shape) != (self.num_envs, _lib.LIFT_STATE_WORDS):
             raise ValueError("checkpoint was taken from an env of a different size")
         self.set_state(sd["state"])
+        self.flush_log()                              # nothing of the old trajectory may land in the restored vector later
         self._log.copy_(sd["log"].to(self.device))
         self._obs[self._cur].copy_(sd["obs"].to(self.device))
         self.common_step_counter = int(sd.get("common_step_counter", 0))

@@ -57,11 +57,13 @@ def test_lift_terms_match_reference_fixture(lo, golden_dir):
     env.close()
 
 
-@pytest.mark.parametrize("n,seed,lanes", [(64, 0, 8), (333, 5, 8), (61, 2, 16)])
-def test_lift_rollout_matches_oracle(lo, n, seed, lanes):
+@pytest.mark.parametrize("n,seed,lanes,log_every", [(64, 0, 8, 1), (333, 5, 8, 7), (61, 2, 16, 1), (64, 3, 8, 0)])
+def test_lift_rollout_matches_oracle(lo, n, seed, lanes, log_every):
     """300 closed-loop steps (every env times out once: in-step resets, command resampling), random actions incl. gripper;
-    batch sizes that do not fill the last wave; eight lanes per env and the shadowed sixteen-lane form."""
-    env = make_env(n, seed=seed)
+    batch sizes that do not fill the last wave; eight lanes per env and the shadowed sixteen-lane form.  extras["log"]: reduced on
+    demand, read after every step / after every seventh step only (the deferred reduction must then hold what the per-step
+    reduction of the oracle holds at that step), or reduced behind every step (log_every = 0, the C entry's default)."""
+    env = make_env(n, seed=seed, log_reduction="every_step" if log_every == 0 else "on_demand")
     assert env._lib.rover_lift_debug_set_lanes(env._h, lanes) == 0 and env.kernel_name() == f"lift_step_kernel<{lanes}>"
     ocfg = oracle_cfg(lo, env)
     obs, info = env.reset()
@@ -80,8 +82,14 @@ def test_lift_rollout_matches_oracle(lo, n, seed, lanes):
         assert np.array_equal(term.cpu().numpy(), term_o.astype(bool)) and np.array_equal(trunc.cpu().numpy(), trunc_o.astype(bool)), k
         assert_close(obs["policy"].cpu().numpy(), obs_o, 0, 0, f"obs step {k}")
         assert_close(rew.cpu().numpy(), rew_o, 0, 0, f"reward step {k}")
-        log = env._log.cpu().numpy()
-        assert log[8] == log_o[8]
+        if log_every == 0:
+            log = env._log.cpu().numpy()                                        # the raw vector: reduced by the step itself
+        elif k % log_every == log_every - 1:
+            log = np.array([float(v) for v in info["log"].values()] + [float(env._log[8])], np.float32)   # a read reduces
+            assert list(info["log"].keys()) == list(env._log_dict.keys()) and info["episode"] is info["log"]
+        else:
+            continue
+        assert log[8] == log_o[8], k
         assert_close(log[:8], log_o[:8], 1e-7, 1e-5, f"log step {k}")
     assert np.array_equal(env.get_state().cpu().numpy().view(np.int32), So.view(np.int32)), "final state bit exact"
     assert trunc_o.sum() == 0 and So[:, lo.EP_LEN].view(np.int32).max() < 60
