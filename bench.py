@@ -62,8 +62,8 @@ def bench_lift(args):
            "config": {"workload": f"FrankaCubeLift-v0 num_envs={n}, random U(-1,1) actions, 100 Hz x decimation 2, in-step resets "
                                   "(BASELINE config 5)", "baseline_config": 5, "num_envs_per_gpu": n}}
     # ---- roofline leg.  Algorithmic bytes per env-step of this path: state read + write 2 x 4 x 64 B,
-    #      observation row 36 x 4 B, action 8 x 4 B, reward + flags 6 B = 694 B.  The kernel is bound by the length of one wave's
-    #      instruction stream (256 waves at 2048 envs), not by HBM: the fraction is structurally tiny and says so.
+    #      observation row 36 x 4 B, action 8 x 4 B, reward + flags 6 B = 694 B.  The kernel is bound by the length of its waves'
+    #      instruction streams (512 waves at 2048 envs), not by HBM: the fraction is structurally tiny and says so.
     ps = max(args.profile_steps, 1)
     ms_raw = ms_ev = 0.0
     for k in range(ps):
@@ -78,8 +78,9 @@ def bench_lift(args):
                        "frac": alg / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "event_pair_overhead_ms": ms_ev,
                        "kernels": {name: {"ms": ms_k, "ms_raw_events": ms_raw, "algorithmic_bytes": alg,
                                           "GB/s": alg / (ms_k * 1e-3) / 1e9}},
-                       "note": "latency-bound by construction: 8 lanes per env = 256 waves on 1024 SIMDs at 2048 envs; the time is "
-                               "one wave's instruction stream (~9 k instructions), see DESIGN.md section 9"}
+                       "note": "latency-bound by construction: 8 lanes per env, two pipelined waves per 8 envs = 512 waves on 1024 SIMDs "
+                               "at 2048 envs; the time is the critical path arm substep 0 -> cube substeps 0, 1 -> managers "
+                               "(~35 k cycles), see DESIGN.md section 9"}
     out["config"]["parity"] = ("reward / observation term functions pinned by the reference fixture (lift_terms.npz); arm / cube / gripper "
                                "simulator is a documented model (PhysX in the reference), parity unpinned; HIP == the separately "
                                "written scalar oracle bit for bit")

@@ -743,7 +743,21 @@ LF_DEV void write_observation(const float *S, float *o)
 // 16-byte reads of different groups fall into different LDS banks.  A 64-thread workgroup is one wave: __syncthreads() is
 // a compiler / memory fence only (no s_barrier is emitted for a single-wave workgroup).
 constexpr int XSTRIDE = 68;
-template <int K>
+// Synchronisation of ONE wave with itself around its private LDS slot.  Single-wave workgroup: __syncthreads() (no s_barrier is
+// emitted).  Two-wave (pipelined) workgroup: the waves run different code between their common barriers, so the wave-private
+// exchanges must not use the workgroup barrier: a wavefront-scope fence (LDS operations of one wave complete in order).
+template <bool WAVE_ONLY>
+__device__ __forceinline__ void slot_sync()
+{
+    if constexpr (WAVE_ONLY) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+template <int K, bool WAVE_ONLY = false>
 __device__ __forceinline__ void gather8(float *xbuf, int slot, int role, bool shadow, const float (&mine)[K], float (&all)[8][K])
 {
     float *base = xbuf + slot * XSTRIDE;
@@ -757,7 +771,7 @@ __device__ __forceinline__ void gather8(float *xbuf, int slot, int role, bool sh
             reinterpret_cast<float2 *>(base + role * 2)[0] = make_float2(mine[0], mine[1]);
         }
     }
-    __syncthreads();
+    slot_sync<WAVE_ONLY>();
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         if constexpr (K == 8) {
@@ -772,7 +786,7 @@ __device__ __forceinline__ void gather8(float *xbuf, int slot, int role, bool sh
             all[r][0] = a.x; all[r][1] = a.y;
         }
     }
-    __syncthreads();
+    slot_sync<WAVE_ONLY>();
 }
 // Element `role` of an 8-vector that every lane holds, with the lane's one-hot bit masks (sel[i] = all ones iff role == i):
 // eight v_and_or_b32 on register values.  (A chain of selects between the elements would be turned by the optimiser into
@@ -791,10 +805,10 @@ __device__ __forceinline__ float pick8(const float *v, const uint32_t *sel)
 __device__ unsigned long long *g_lift_stamps;
 __device__ __forceinline__ void lift_stamp(int slot)
 {
-    if (threadIdx.x == 0) {
+    if ((threadIdx.x & 63) == 0) {      // lane 0 of either wave: [workgroup][wave][slot]
         unsigned long long t;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-        g_lift_stamps[(size_t)blockIdx.x * 32 + slot] = t;
+        g_lift_stamps[((size_t)blockIdx.x * 2 + (threadIdx.x >> 6)) * 32 + slot] = t;
     }
 }
 #define LIFT_STAMP(k) lift_stamp(k)
@@ -835,17 +849,28 @@ static LiftHot hot_of(const lift_config &c)
 }
 
 // RLTaskEnv.step of FrankaCubeLift-v0, LPE lanes per env (8, or 16 with lanes 8..15 of a row shadowing lanes 0..7).
-template <int LPE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void lift_step_kernel(
+// PIPE: two waves per eight envs.  The arm does not feel the cube in this model (one-way coupling: pads -> cube), so wave 0
+// integrates the arm -- inverse-dynamics passes, solves, hand kinematics -- one substep AHEAD of wave 1, which runs the cube /
+// finger contact of the substep from the hand pose wave 0 left in LDS, and then the managers.  One workgroup barrier per
+// substep; the arithmetic and its order are those of the single-wave form (bit-identical results).
+template <int LPE, bool PIPE>
+__global__ __launch_bounds__(PIPE ? 128 : 64) __attribute__((amdgpu_waves_per_eu(1, 1))) void lift_step_kernel(
     LiftHot hc, const lift_config *__restrict__ cfg_dev, int n, int env_id_offset, float *__restrict__ state,
     const float *__restrict__ action, float *__restrict__ obs,
     float *__restrict__ reward, uint8_t *__restrict__ terminated, uint8_t *__restrict__ truncated, float *__restrict__ lg_out,
     unsigned *__restrict__ counters, uint32_t serial)
 {
     static_assert(LPE == 8 || LPE == 16, "eight lanes per env, optionally shadowed");
+    static_assert(!PIPE || LPE == 8, "the pipelined form has eight lanes per env");
     constexpr float QDEF[9] = LF_Q_DEFAULT;
-    __shared__ __attribute__((aligned(16))) float xbuf[8 * XSTRIDE];
-    const int lane = threadIdx.x, role = lane & 7;
+    constexpr int HAND_WORDS = 20, ARM_WORDS = 16;
+    __shared__ __attribute__((aligned(16))) float xbuf_all[(PIPE ? 2 : 1) * 8 * XSTRIDE];
+    __shared__ __attribute__((aligned(16))) float hand_buf[PIPE ? 2 * 8 * HAND_WORDS : 4];   // [substep parity][env slot]: R, tcp, v, w
+    __shared__ __attribute__((aligned(16))) float arm_buf[PIPE ? 8 * ARM_WORDS : 4];          // [env slot]: final q[0..6], qd[0..6]
+    const int wave = PIPE ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    const bool do_arm = !PIPE || wave == 0, do_cube = !PIPE || wave == 1;
+    float *xbuf = xbuf_all + wave * 8 * XSTRIDE;
+    const int lane = threadIdx.x & 63, role = lane & 7;
     const int slot = LPE == 8 ? lane >> 3 : (lane >> 4) * 2;
     const bool shadow = LPE == 16 && (lane & 8) != 0;
     int e = blockIdx.x * (64 / LPE) + lane / LPE;
@@ -869,7 +894,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         float mine[4], all[8][4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) mine[k] = column(state, k);
-        gather8<4>(xbuf, slot, role, shadow, mine, all);
+        gather8<4, PIPE>(xbuf, slot, role, shadow, mine, all);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -899,49 +924,96 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     auto joint_trig = [&]() {       // sin / cos of joint `role` in lane `role`, then shared
         float mine[2], all[8][2];
         sincos_poly(pick8(q, sel), mine[0], mine[1]);      // lane 7 evaluates finger joint q[7]: unused
-        gather8<2>(xbuf, slot, role, shadow, mine, all);
+        gather8<2, PIPE>(xbuf, slot, role, shadow, mine, all);
 #pragma unroll
         for (int i = 0; i < 8; ++i) { sn[i] = all[i][0]; cs[i] = all[i][1]; }
     };
     LIFT_STAMP(0);
-    joint_trig();
+    if (do_arm) joint_trig();
     HandPose hand;
     LIFT_STAMP(1);
+    // hand-off of the pipelined form: the arm wave leaves the hand pose of the substep (and, every time, the arm's joint state:
+    // the last one written is the final one) in LDS; the cube wave picks them up behind the substep's barrier
+    auto hand_put = [&](int par) {
+        if (role == 0) {
+            float4 *hb = reinterpret_cast<float4 *>(hand_buf + (par * 8 + slot) * HAND_WORDS);
+            hb[0] = make_float4(hand.R[0][0], hand.R[0][1], hand.R[0][2], hand.R[1][0]);
+            hb[1] = make_float4(hand.R[1][1], hand.R[1][2], hand.R[2][0], hand.R[2][1]);
+            hb[2] = make_float4(hand.R[2][2], hand.tcp[0], hand.tcp[1], hand.tcp[2]);
+            hb[3] = make_float4(hand.v[0], hand.v[1], hand.v[2], hand.w[0]);
+            hb[4] = make_float4(hand.w[1], hand.w[2], 0.0f, 0.0f);
+            float4 *ab = reinterpret_cast<float4 *>(arm_buf + slot * ARM_WORDS);
+            ab[0] = make_float4(q[0], q[1], q[2], q[3]);
+            ab[1] = make_float4(q[4], q[5], q[6], qd[0]);
+            ab[2] = make_float4(qd[1], qd[2], qd[3], qd[4]);
+            ab[3] = make_float4(qd[5], qd[6], 0.0f, 0.0f);
+        }
+    };
+    auto hand_get = [&](int par) {
+        const float4 *hb = reinterpret_cast<const float4 *>(hand_buf + (par * 8 + slot) * HAND_WORDS);
+        const float4 h0 = hb[0], h1 = hb[1], h2 = hb[2], h3 = hb[3], h4 = hb[4];
+        hand.R[0][0] = h0.x; hand.R[0][1] = h0.y; hand.R[0][2] = h0.z; hand.R[1][0] = h0.w;
+        hand.R[1][1] = h1.x; hand.R[1][2] = h1.y; hand.R[2][0] = h1.z; hand.R[2][1] = h1.w;
+        hand.R[2][2] = h2.x; hand.tcp[0] = h2.y; hand.tcp[1] = h2.z; hand.tcp[2] = h2.w;
+        hand.v[0] = h3.x; hand.v[1] = h3.y; hand.v[2] = h3.z; hand.w[0] = h3.w;
+        hand.w[1] = h4.x; hand.w[2] = h4.y;
+    };
     for (int s = 0; s < hc.decimation; ++s) {
         // ---- arm: pass `role` of the eight inverse-dynamics passes, exchanged, then the replicated 7 x 7 solve
-        {
-            float qd_l[7], qdd_l[7], tau[8], cols[8][8];
+        if (do_arm) {
+            {
+                float qd_l[7], qdd_l[7], tau[8], cols[8][8];
 #pragma unroll
-            for (int i = 0; i < 7; ++i) { qd_l[i] = u2f(f2u(qd[i]) & sel[7]); qdd_l[i] = u2f(0x3f800000u & sel[i]); }
-            newton_euler(sn, cs, qd_l, qdd_l, u2f(f2u(K_GRAV) & sel[7]), tau);
-            tau[7] = 0.0f;
-            LIFT_STAMP(2 + 6 * (s & 1));
-            gather8<8>(xbuf, slot, role, shadow, tau, cols);
-            arm_solve_integrate<true>(h, cols, target, q, qd);
+                for (int i = 0; i < 7; ++i) { qd_l[i] = u2f(f2u(qd[i]) & sel[7]); qdd_l[i] = u2f(0x3f800000u & sel[i]); }
+                newton_euler(sn, cs, qd_l, qdd_l, u2f(f2u(K_GRAV) & sel[7]), tau);
+                tau[7] = 0.0f;
+                LIFT_STAMP(2 + 6 * (s & 1));
+                gather8<8, PIPE>(xbuf, slot, role, shadow, tau, cols);
+                arm_solve_integrate<true>(h, cols, target, q, qd);
+            }
+            LIFT_STAMP(3 + 6 * (s & 1));
+            joint_trig();
+            hand_kinematics(sn, cs, qd, hc.ee_offset_z, hand);
+            if constexpr (PIPE) hand_put(s & 1);
         }
-        LIFT_STAMP(3 + 6 * (s & 1));
-        joint_trig();
-        hand_kinematics(sn, cs, qd, hc.ee_offset_z, hand);
+        if constexpr (PIPE) __syncthreads();       // the ONE workgroup barrier of a substep: hand pose s is in LDS
         LIFT_STAMP(4 + 6 * (s & 1));
         // ---- cube: gravity, rows of corner `role`, exchanged, then the replicated Gauss-Seidel sweeps
-        {
+        if (do_cube) {
+            if constexpr (PIPE) hand_get(s & 1);
             float *pos = S + LIFT_OBJ_POS, *quat = S + LIFT_OBJ_QUAT, *lin = S + LIFT_OBJ_LIN, *ang = S + LIFT_OBJ_ANG;
             lin[2] = fmaf(-K_GRAV, h, lin[2]);
             float Rc[3][3], mine[8], cr[8][8];
             quat_to_matrix(quat, Rc);
             corner_rows(role, Rc, pos[2], K, mine);      // corner index = role: three per-lane sign selects, uniform code otherwise
-            gather8<8>(xbuf, slot, role, shadow, mine, cr);
+            gather8<8, PIPE>(xbuf, slot, role, shadow, mine, cr);
             LIFT_STAMP(5 + 6 * (s & 1));
             cube_substep<true>(hc, h, K, hand, Rc, cr, finger_target, q + 7, qd + 7, pos, quat, lin, ang);
         }
         LIFT_STAMP(7 + 6 * (s & 1));
     }
-    if (hc.decimation <= 0) hand_kinematics(sn, cs, qd, hc.ee_offset_z, hand);
+    if (hc.decimation <= 0) {
+        if (do_arm) {
+            hand_kinematics(sn, cs, qd, hc.ee_offset_z, hand);
+            if constexpr (PIPE) hand_put(0);
+        }
+        if constexpr (PIPE) {
+            __syncthreads();
+            if (do_cube) hand_get(0);
+        }
+    }
+    if constexpr (PIPE) {
+        if (!do_cube) return;                      // the arm wave is done: everything below is the cube wave's
+        const float4 *ab = reinterpret_cast<const float4 *>(arm_buf + slot * ARM_WORDS);
+        const float4 a0 = ab[0], a1 = ab[1], a2 = ab[2], a3 = ab[3];
+        q[0] = a0.x; q[1] = a0.y; q[2] = a0.z; q[3] = a0.w; q[4] = a1.x; q[5] = a1.y; q[6] = a1.z;
+        qd[0] = a1.w; qd[1] = a2.x; qd[2] = a2.y; qd[3] = a2.z; qd[4] = a2.w; qd[5] = a3.x; qd[6] = a3.y;
+    }
 
     // ---- manager words; ActionManager.process_action (prev_action <- action <- the raw action)
     {
         float all[8][4];
-        gather8<4>(xbuf, slot, role, shadow, late, all);
+        gather8<4, PIPE>(xbuf, slot, role, shadow, late, all);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -1017,9 +1089,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 reinterpret_cast<float4 *>(base + r * 8)[1] = make_float4(S[32 + r], S[40 + r], S[48 + r], S[56 + r]);
             }
         }
-        __syncthreads();
+        slot_sync<PIPE>();
         const float4 v0 = reinterpret_cast<const float4 *>(base + role * 8)[0], v1 = reinterpret_cast<const float4 *>(base + role * 8)[1];
-        __syncthreads();
+        slot_sync<PIPE>();
         if (valid && !shadow) {
             column(state, 0) = v0.x; column(state, 1) = v0.y; column(state, 2) = v0.z; column(state, 3) = v0.w;
             column(state, 4) = v1.x; column(state, 5) = v1.y; column(state, 6) = v1.z; column(state, 7) = v1.w;
@@ -1129,10 +1201,21 @@ struct rover_lift_sim {
     unsigned *counters;     // [1] envs reset in the step under way (cleared by the log kernel)
     uint32_t log_serial;    // launch serial of the latest step (tags the log rows of the envs that reset in it); starts at 1
     bool log_deferred;      // rover_lift_set_log_deferred: rover_lift_step does not launch the log reduction
+    int pipeline;           // eight lanes per env as two waves (arm one substep ahead of cube + managers): 1 on, 0 off, -1 = decide
+                            // from the batch (on while the two waves of every eight envs all fit the chip at once)
+    int simd_count;         // 4 x compute units of the device
     lift_config *cfg_dev;   // device copy of cfg (in the workspace), read by the tail of the step kernel
     bool cfg_dirty;         // host copy changed (rover_lift_set_seed): copy it over before the next launch
 };
 
+// The pipelined form doubles the waves (two per eight envs).  It wins while all of them are resident at once -- one wave per SIMD --
+// and loses beyond (8192 envs on an MI355X: 2048 waves on 1024 SIMDs, 30.6 us against 22.0 us for the single-wave form).
+static bool lift_pipelined(const rover_lift_sim *sim)
+{
+    if (sim->lanes_per_env != 8) return false;
+    if (sim->pipeline >= 0) return sim->pipeline != 0;
+    return 2 * ((sim->n + 7) / 8) <= (sim->simd_count > 0 ? sim->simd_count : 1024);
+}
 static void launch_step(rover_lift_sim *sim, hipStream_t st, const float *action, float *obs, float *reward, uint8_t *terminated,
                         uint8_t *truncated, float *log)
 {
@@ -1144,13 +1227,14 @@ static void launch_step(rover_lift_sim *sim, hipStream_t st, const float *action
     const LiftHot hc = hot_of(sim->cfg);
     const uint32_t serial = ++sim->log_serial;
     const int lpe = sim->lanes_per_env, epw = 64 / lpe;
-    const dim3 grid((sim->n + epw - 1) / epw), block(64);
-    if (lpe == 16)
-        hipLaunchKernelGGL(lift_step_kernel<16>, grid, block, 0, st, hc, sim->cfg_dev, sim->n, sim->env_id_offset, sim->state, action, obs,
-                           reward, terminated, truncated, sim->lg, sim->counters, serial);
-    else
-        hipLaunchKernelGGL(lift_step_kernel<8>, grid, block, 0, st, hc, sim->cfg_dev, sim->n, sim->env_id_offset, sim->state, action, obs,
-                           reward, terminated, truncated, sim->lg, sim->counters, serial);
+    const dim3 grid((sim->n + epw - 1) / epw);
+#define LIFT_LAUNCH(L, P, THREADS)                                                                                                   \
+    hipLaunchKernelGGL((lift_step_kernel<L, P>), grid, dim3(THREADS), 0, st, hc, sim->cfg_dev, sim->n, sim->env_id_offset, sim->state, \
+                       action, obs, reward, terminated, truncated, sim->lg, sim->counters, serial)
+    if (lpe == 16) LIFT_LAUNCH(16, false, 64);
+    else if (lift_pipelined(sim)) LIFT_LAUNCH(8, true, 128);
+    else LIFT_LAUNCH(8, false, 64);
+#undef LIFT_LAUNCH
     if (!sim->log_deferred)
         hipLaunchKernelGGL(lift_log_kernel, dim3(1), dim3(256), 0, st, sim->cfg, sim->n, sim->lg, sim->counters, log, serial);
 }
@@ -1208,10 +1292,12 @@ int rover_lift_create(const lift_config *cfg, int32_t num_envs, int32_t env_id_o
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count));
     if (device < 0 || device >= count) return rover_internal_fail(ROVER_ERR_INVALID, "device ordinal out of range");
+    int cus = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
     rover_lift_sim *s = new (std::nothrow) rover_lift_sim();
     if (!s) return rover_internal_fail(ROVER_ERR_INVALID, "out of host memory");
     s->cfg = *cfg; s->n = num_envs; s->env_id_offset = env_id_offset; s->device = device; s->state = nullptr; s->lg = nullptr;
-    s->lanes_per_env = 8; s->counters = nullptr; s->cfg_dev = nullptr; s->cfg_dirty = false; s->log_serial = 0; s->log_deferred = false;
+    s->lanes_per_env = 8; s->counters = nullptr; s->cfg_dev = nullptr; s->cfg_dirty = false; s->log_serial = 0; s->log_deferred = false; s->pipeline = -1; s->simd_count = 4 * cus;
     *out = s;
     return ROVER_OK;
 }
@@ -1245,11 +1331,18 @@ int rover_lift_set_seed(rover_lift_sim *sim, uint32_t seed_lo, uint32_t seed_hi)
     sim->cfg_dirty = true;
     return ROVER_OK;
 }
-// measurement hook (tools/lift_time.py): lanes per env of the step kernel, 8 (default) or 16
+// measurement hooks (tools/lift_time.py): lanes per env of the step kernel, 8 (default) or 16; the two-wave pipelined form of
+// the eight-lane kernel (default) or the single-wave one
 int rover_lift_debug_set_lanes(rover_lift_sim *sim, int lanes)
 {
     if (!sim || (lanes != 8 && lanes != 16)) return ROVER_ERR_INVALID;
     sim->lanes_per_env = lanes;
+    return ROVER_OK;
+}
+int rover_lift_debug_set_pipeline(rover_lift_sim *sim, int on)
+{
+    if (!sim) return ROVER_ERR_INVALID;
+    sim->pipeline = on < 0 ? -1 : (on != 0);
     return ROVER_OK;
 }
 #ifdef LF_STAMP
@@ -1323,7 +1416,7 @@ int rover_lift_profile_step(rover_lift_sim *sim, const float *action, float *obs
 int rover_lift_kernel_name(const rover_lift_sim *sim, char *step_kernel, size_t cap)
 {
     if (!sim || !step_kernel || cap < 8) return rover_internal_fail(ROVER_ERR_INVALID, "bad argument");
-    snprintf(step_kernel, cap, "lift_step_kernel<%d>", sim->lanes_per_env);
+    snprintf(step_kernel, cap, "lift_step_kernel<%d, %s>", sim->lanes_per_env, lift_pipelined(sim) ? "true" : "false");
     return ROVER_OK;
 }
 int rover_lift_terms(rover_lift_sim *sim, int32_t n, const float *obj_pos, const float *ee_pos, const float *root_state,

@@ -57,14 +57,17 @@ def test_lift_terms_match_reference_fixture(lo, golden_dir):
     env.close()
 
 
-@pytest.mark.parametrize("n,seed,lanes,log_every", [(64, 0, 8, 1), (333, 5, 8, 7), (61, 2, 16, 1), (64, 3, 8, 0)])
-def test_lift_rollout_matches_oracle(lo, n, seed, lanes, log_every):
+@pytest.mark.parametrize("n,seed,lanes,log_every,pipe", [(64, 0, 8, 1, True), (333, 5, 8, 7, True), (61, 2, 16, 1, False),
+                                                         (64, 3, 8, 0, False), (13, 6, 8, 1, True)])
+def test_lift_rollout_matches_oracle(lo, n, seed, lanes, log_every, pipe):
     """300 closed-loop steps (every env times out once: in-step resets, command resampling), random actions incl. gripper;
-    batch sizes that do not fill the last wave; eight lanes per env and the shadowed sixteen-lane form.  extras["log"]: reduced on
+    batch sizes that do not fill the last wave; eight lanes per env as two pipelined waves (the product form) and as one wave, and
+    the shadowed sixteen-lane form.  extras["log"]: reduced on
     demand, read after every step / after every seventh step only (the deferred reduction must then hold what the per-step
     reduction of the oracle holds at that step), or reduced behind every step (log_every = 0, the C entry's default)."""
     env = make_env(n, seed=seed, log_reduction="every_step" if log_every == 0 else "on_demand")
-    assert env._lib.rover_lift_debug_set_lanes(env._h, lanes) == 0 and env.kernel_name() == f"lift_step_kernel<{lanes}>"
+    assert env._lib.rover_lift_debug_set_lanes(env._h, lanes) == 0 and env._lib.rover_lift_debug_set_pipeline(env._h, int(pipe)) == 0
+    assert env.kernel_name() == f"lift_step_kernel<{lanes}, {'true' if pipe else 'false'}>"
     ocfg = oracle_cfg(lo, env)
     obs, info = env.reset()
     So = lo.new_state(n)

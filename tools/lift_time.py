@@ -13,6 +13,8 @@ cfg = LiftEnvCfg(); cfg.scene.num_envs = n
 env = FrankaCubeLiftEnv(cfg); env.reset()
 if os.environ.get("LIFT_LANES"):
     assert env._lib.rover_lift_debug_set_lanes(env._h, int(os.environ["LIFT_LANES"])) == 0
+if os.environ.get("LIFT_PIPE"):
+    assert env._lib.rover_lift_debug_set_pipeline(env._h, int(os.environ["LIFT_PIPE"])) == 0
 g = torch.Generator(device=env.device).manual_seed(0)
 acts = torch.rand(64, n, 8, device=env.device, generator=g) * 2 - 1
 for k in range(50): env.step(acts[k % 64])
