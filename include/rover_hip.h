@@ -170,8 +170,19 @@ int rover_set_counter(rover_sim *sim, uint64_t counter);
 int rover_step(rover_sim *sim, const float *action, float *obs, float *reward, uint8_t *terminated, uint8_t *truncated,
                float *force, float *log, void *stream);
 
+/* extras["log"] on demand.  The reference fills the dictionary inside _reset_idx (rover_env.py:27-39) and its consumers read it
+ * now and then (skrl_utils.py:139-142).  With rover_set_log_deferred(sim, 1) rover_step leaves `log` alone; rover_flush_log
+ * produces, at any later point on the same stream, exactly the vector the per-step reduction would hold there: [0..12] from the
+ * latest step in which an env reset, [13] = the number of envs reset in the latest step (0 when the latest resets are older).
+ * Flush at most once per step (a second flush without a step in between reports [13] = 0).  Deferral is also what lets
+ * rover_step run as ONE kernel launch -- the height scan as the last phase of the step kernel's waves (group mapping, int16
+ * terrain copy, a batch that one workgroup per compute unit holds): without it a second launch would follow for the log alone.
+ * Default: not deferred (two launches; the scan kernel's first workgroup reduces the log). */
+int rover_set_log_deferred(rover_sim *sim, int32_t deferred);
+int rover_flush_log(rover_sim *sim, float *log, void *stream);
+
 /* Profiling twin of rover_step: identical launches, bracketed by HIP events recorded on `stream`; returns the device
- * time of the two kernels in milliseconds.  Synchronises the host -- measurement only (bench.py roofline leg). */
+ * time of the two kernels in milliseconds (one-launch form: of the fused kernel and of the log reduction, if any).  Synchronises the host -- measurement only (bench.py roofline leg). */
 int rover_profile_step(rover_sim *sim, const float *action, float *obs, float *reward, uint8_t *terminated,
                        uint8_t *truncated, float *force, float *log, void *stream, float *ms_step_kernel,
                        float *ms_scan_kernel);
@@ -186,7 +197,8 @@ int rover_profile_event_overhead(rover_sim *sim, void *stream, int32_t reps, flo
  * library is resolved with dlopen at the first enabling call (ROVER_ERR_UNSUPPORTED when none is installed).  Host only. */
 int rover_set_markers(rover_sim *sim, int32_t enabled);
 
-/* Names of the two kernels rover_step launches for the current configuration / terrain, exactly as rocprofv3's kernel trace
+/* (One-launch form: step_kernel = "rover_step_scan_kernel<true|false>", scan_kernel = "rover_log_kernel" or "" when deferred.)
+ * Names of the two kernels rover_step launches for the current configuration / terrain, exactly as rocprofv3's kernel trace
  * prints them minus the "(anonymous namespace)::" qualifier and the parameter list (e.g. "rover_step_kernel_group",
  * "rover_scan_step_kernel<true, true, 1024, 2>"): the keys of bench.py's roofline block and of profiles/hbm_traffic.json.
  * Both buffers hold `cap` bytes.  Host only. */

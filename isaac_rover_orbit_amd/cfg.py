@@ -164,6 +164,9 @@ class RoverEnvCfg:
     record_contact_forces: bool = True       # materialise contact_sensor.data.force_matrix_w every step
     use_int16_terrain: bool = True           # stage the exact int16 copy of the heightfield in the scan kernel when it exists
     roctx_markers: bool = False              # roctx ranges around the two launches of every step (rocprofv3 --marker-trace)
+    # extras["log"]: "on_demand" = the reduction of the episodic sums runs when the dictionary is read (same numbers; lets a step be
+    # ONE kernel launch where the fused step + scan kernel applies); "every_step" = behind every step, like the C entry's default
+    log_reduction: str = "on_demand"
     # multi-GPU sharding: this process simulates global env ids [env_id_offset, env_id_offset + num_envs)
     env_id_offset: int = 0
     global_num_envs: int | None = None

@@ -24,6 +24,7 @@
 // Physics / ray-caster / contact sensor are third-party in the reference (PhysX, Warp); the reduced rover model used
 // here is specified in DESIGN.md.  All arithmetic is fp32 with -ffp-contract=off.
 #include <hip/hip_runtime.h>
+#include <vector>
 
 #include <cmath>
 #include <cstdio>
@@ -1009,9 +1010,20 @@ __device__ __forceinline__ void k1_stamp(int slot)
         g_k1_stamps[(size_t)blockIdx.x * 32 + slot] = t;
     }
 }
+// a stamp that does not wait for the wave's outstanding memory operations (is an instruction's ISSUE what takes the time?)
+__device__ __forceinline__ void k1_stamp_nowait(int slot)
+{
+    if (threadIdx.x == 0) {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        g_k1_stamps[(size_t)blockIdx.x * 32 + slot] = t;
+    }
+}
 #define K1_STAMP(k) k1_stamp(k)
+#define K1_STAMP_NOWAIT(k) k1_stamp_nowait(k)
 #else
 #define K1_STAMP(k) do { } while (0)
+#define K1_STAMP_NOWAIT(k) do { } while (0)
 #endif
 // the projected-Jacobi iterations of one lane (wheel slot x role): see the arithmetic contract above RoleRows
 __device__ __forceinline__ void solver_iteration_generic(const StepConsts &K, Contact &ct, const RoleRows &rr, f2 *V, float cw,
@@ -1470,7 +1482,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             for (int i = 0; i < 14; ++i) vsel = (threadIdx.x == i) ? lg[i] : vsel;
             log_partial[(size_t)blockIdx.x * ROVER_LOG_WORDS + threadIdx.x] = vsel;
         }
-        if (threadIdx.x == 0) atomicAdd(p.log_counter, 1u);
+        if (threadIdx.x == 0) {
+            atomicAdd(p.log_counter, 1u);
+            p.log_counter[1] = p.step_tag;   // the latest launch with resets
+        }
     }
 
     if (active) {
@@ -1623,6 +1638,197 @@ __device__ __forceinline__ void group_store(float *__restrict__ state, int N, in
     }
 }
 
+#define RV_K1G_THREADS 256
+#define RV_K1G_ENVS (RV_K1G_THREADS / 16)
+// surface height from four staged cells (unscaled): the plane of the cell's triangle the ray falls in (cells split along
+// the (i, j) - (i+1, j+1) diagonal: what a ray-cast of the terrain's triangle mesh returns) or the bilinear patch
+template <bool TRI, typename cell_t>
+__device__ __forceinline__ float patch_height(const cell_t *q, int pitch, float fx, float fy)
+{
+    // Four separate 16-bit LDS reads for the int16 tile.  With unaligned access enabled hipcc merges the two cells of a row into
+    // ONE ds_read_b32 at a 2-byte-aligned address, which costs more LDS time than the two reads it replaces (scan kernel 22.5
+    // vs 18.6 us at num_envs = 4096): rover_scan_step_kernel is compiled with target("no-unaligned-access-mode").  (A
+    // `volatile` read also prevents the merge, but turns the reads into serialised FLAT loads.)
+    const float h00 = (float)q[0], h01 = (float)q[1], h10 = (float)q[pitch], h11 = (float)q[pitch + 1];
+    if (TRI) {
+        const bool lower = fx >= fy;                       // lower triangle: corners 00, 01, 11; upper: 00, 10, 11
+        const float pm = lower ? h01 : h10;
+        const float d1 = pm - h00, d2 = h11 - pm;
+        const float a = lower ? d1 : d2, b = lower ? d2 : d1;
+        return fmaf(fy, b, fmaf(fx, a, h00));
+    }
+    const float dx0 = h01 - h00, dx1 = h11 - h10;
+    const float hx0 = h00 + fx * dx0;
+    const float hx1 = h10 + fx * dx1;
+    return hx0 + fy * (hx1 - hx0);
+}
+// ------------------------------------------------------------------------------------------------ scan, wave-private form
+// The same rays from the same staged cells as rover_scan_step_kernel<true, TRI, ...>, cast by ONE wave for up to four envs
+// from two wave-private LDS tiles: no workgroup barrier, K1's launch shape (one wave per SIMD).  What hides the LDS latency is
+// the wave's own instruction-level parallelism (sixteen rays per lane, 256 VGPRs to unroll into).  As a kernel of its own
+// (measurement hook, rover_debug_set_scan_form(sim, 7)) and as the last phase of the fused step kernel.
+struct PrivateWindows {      // wave-uniform: the windows of the wave's four envs
+    float px[4], py[4], pz[4], cy[4], sy[4];
+    int i_lo[4], j_lo[4], pk[4];
+};
+template <bool TRI, bool FAST>
+__device__ __forceinline__ float private_ray(const RvParams &p, const int16_t *tile, int pitch, int th, float px, float py, float pz,
+                                             float cy, float sy, int i_lo, int j_lo, float rx, float ry)
+{
+    const float x = px + (cy * rx - sy * ry);
+    const float y = py + (sy * rx + cy * ry);
+    float hgt;
+    if (FAST) {
+        const float u = (x - p.min_x) * p.inv_res;
+        const float v = (y - p.min_y) * p.inv_res;
+        const int j0 = (int)u, i0 = (int)v;
+        const float fx = u - (float)j0, fy = v - (float)i0;
+        hgt = patch_height<TRI>(tile + (__umul24(i0 - i_lo, pitch) + (j0 - j_lo)), pitch, fx, fy);
+    } else if (x < p.min_x || x > p.x_max || y < p.min_y || y > p.y_max) {
+        return pz - INFINITY - p.cfg.scan_height_offset;  // ray leaves the terrain: ORBIT RayCaster reports +inf
+    } else {
+        float u = (x - p.min_x) * p.inv_res;
+        float v = (y - p.min_y) * p.inv_res;
+        u = clampf(u, 0.0f, (float)(p.W - 1));
+        v = clampf(v, 0.0f, (float)(p.H - 1));
+        int j0 = (int)u, i0 = (int)v;
+        if (j0 > p.W - 2) j0 = p.W - 2;
+        if (i0 > p.H - 2) i0 = p.H - 2;
+        const float fx = u - (float)j0, fy = v - (float)i0;
+        const int jl = j0 - j_lo, il = i0 - i_lo;
+        const int tw = min(pitch, p.W - j_lo);
+        const bool in_tile = jl >= 0 && il >= 0 && jl + 1 < tw && il + 1 < th;
+        const int jc = max(0, min(jl, tw - 2)), ic = max(0, min(il, th - 2));
+        hgt = patch_height<TRI>(tile + ic * pitch + jc, pitch, fx, fy);
+        if (!in_tile) return __int_as_float(0x7fc00000);  // a ray outside the staged window is a bug: NaN
+    }
+    hgt *= p.q_scale;
+    return pz - hgt - p.cfg.scan_height_offset;  // observations.py:45
+}
+// Window copy by ONE wave, whole rows per instruction: with tw4 chunks per row a global_load_lds moves rpi = 64 / tw4 rows
+// (lanes rpi * tw4 .. 63 idle); lane -> (row in the group, chunk in the row) is formed once per tile, an iteration costs one
+// 64-bit add, one compare and the load.  LDS chunk index of (row r, chunk c) = r * tw4 + c, as in the scan kernels.
+__device__ __forceinline__ void private_issue(const RvParams &p, const PrivateWindows &w, int j, int16_t *tile, int lane)
+{
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const int16_t *hsrc = p.height_q;
+    const int th = w.pk[j] & 0x7FFF, tw4 = max(w.pk[j] >> 16, 1);
+    const int rpi = 64 / tw4;                                          // wave-uniform
+    const int lr = (int)(((float)lane + 0.5f) * (1.0f / (float)tw4));  // lane / tw4, exact
+    const int lc = lane - (int)__umul24(lr, tw4);
+    const v4f *src = reinterpret_cast<const v4f *>(hsrc + (size_t)w.i_lo[j] * p.W + w.j_lo[j]) + (size_t)(__umul24(lr, p.wq) + lc);
+    v4f *dst = reinterpret_cast<v4f *>(tile);
+    const size_t src_step = (size_t)__umul24(rpi, p.wq);
+    const int dst_step = rpi * tw4;
+    const bool lane_on = lr < rpi;
+    for (int r0 = 0; r0 < th; r0 += rpi) {
+        if (lane_on && r0 + lr < th)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        src += src_step;
+        dst += dst_step;
+    }
+}
+// (Measured and not kept: the same copy through registers -- 16-byte global loads issued before the rays of the env that still
+// occupies the tile, LDS writes afterwards.  A single wave issues one global_load_lds_dwordx4 every ~145 cycles, 2.6 k cycles per
+// window during which nothing else of the wave issues; the register route was slower still: 53.0 us per step against 48.3 us.
+// The four waves of a CU move 4 x 4 windows x 18.9 KB = 302 KB per step through one L1 either way.)
+// the windows of the wave's four envs from the per-lane window of each env's row (lane 16 j speaks for env j)
+__device__ __forceinline__ void private_windows(const ScanWindow &sw, PrivateWindows &w)
+{
+    const int pk = sw.th | (sw.interior << 15) | (sw.tw4 << 16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        auto bcast = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16 * j)); };
+        w.px[j] = bcast(sw.px); w.py[j] = bcast(sw.py); w.pz[j] = bcast(sw.pz); w.cy[j] = bcast(sw.cy); w.sy[j] = bcast(sw.sy);
+        w.i_lo[j] = __builtin_amdgcn_readlane(sw.i_lo, 16 * j); w.j_lo[j] = __builtin_amdgcn_readlane(sw.j_lo, 16 * j);
+        w.pk[j] = __builtin_amdgcn_readlane(pk, 16 * j);
+    }
+}
+// ray_xy: 1024 x (x, y) pattern offsets of ray m * 64 + lane (rays past the pattern repeat ray 0), built by the host
+template <bool TRI>
+__device__ __forceinline__ void scan_private_wave(const RvParams &p, int16_t *tile0, int16_t *tile1, int lane, int n_env, int e_base,
+                                                  const PrivateWindows &w, float *__restrict__ out, int row_stride, int col0,
+                                                  const float2 *__restrict__ ray_xy, bool issued01 = false)
+{
+    constexpr int CC = 8, ROUNDS = 16, GROUP = 8;
+    auto issue = [&](int j, int16_t *tile) { private_issue(p, w, j, tile, lane); };
+    float ox[ROUNDS], oy[ROUNDS];
+    // A lane without a ray in round m repeats ray 0 (the table says so) and stores the same bits to row[0] again: no execution
+    // masks, no branches inside a group of GROUP rounds -- one basic block whose 4 GROUP LDS reads the scheduler can put in
+    // flight together (with a branch per round the fused kernel spent 600 cycles per round, three times its VALU work).
+    auto cast = [&](int j, const int16_t *tile) {
+        const int th = w.pk[j] & 0x7FFF;
+        const int pitch = (w.pk[j] >> 16) * CC;
+        float *row = out + (size_t)(e_base + j) * row_stride + col0;
+        if ((w.pk[j] >> 15) & 1) {
+#pragma unroll
+            for (int m0 = 0; m0 < ROUNDS; m0 += GROUP) {
+                if (m0 * 64 < p.rays) {      // wave-uniform, once per group of rounds
+                    float o[GROUP];
+#pragma unroll
+                    for (int q = 0; q < GROUP; ++q)
+                        o[q] = private_ray<TRI, true>(p, tile, pitch, th, w.px[j], w.py[j], w.pz[j], w.cy[j], w.sy[j], w.i_lo[j],
+                                                      w.j_lo[j], ox[m0 + q], oy[m0 + q]);
+#pragma unroll
+                    for (int q = 0; q < GROUP; ++q) {
+                        const int r = lane + 64 * (m0 + q);
+                        row[r < p.rays ? r : 0] = o[q];
+                    }
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int m = 0; m < ROUNDS; ++m) {
+                if (m * 64 < p.rays) {
+                    // (ox / oy indexed by a loop counter would leave the registers: the slow path re-reads the table)
+                    const float2 xy = ray_xy[m * 64 + lane];
+                    const float o = private_ray<TRI, false>(p, tile, pitch, th, w.px[j], w.py[j], w.pz[j], w.cy[j], w.sy[j], w.i_lo[j],
+                                                            w.j_lo[j], xy.x, xy.y);
+                    const int r = lane + 64 * m;
+                    if (r < p.rays) row[r] = o;
+                }
+            }
+        }
+    };
+    if (n_env <= 0) return;
+    if (!issued01) {   // (the fused step kernel stages the first two windows before its manager tail)
+        issue(0, tile0);
+        if (n_env > 1) issue(1, tile1);
+    }
+#pragma unroll
+    for (int m = 0; m < ROUNDS; ++m) {
+        const float2 v = ray_xy[m * 64 + lane];
+        ox[m] = v.x;
+        oy[m] = v.y;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    K1_STAMP(27);
+    cast(0, tile0);
+    K1_STAMP(28);
+    if (n_env > 2) {   // tile 0 is dead (its LDS reads have returned: their values were consumed); env 2's window lands under env 1's rays
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        issue(2, tile0);
+        K1_STAMP_NOWAIT(19);
+    }
+    if (n_env > 1) cast(1, tile1);
+    K1_STAMP(29);
+    if (n_env > 2) {   // env 2's window was issued before env 1's rays: it has landed; env 3's goes out now and lands under env 2's rays
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (n_env > 3) issue(3, tile1);
+        K1_STAMP(30);
+        cast(2, tile0);
+    }
+    K1_STAMP(31);
+    if (n_env > 3) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        cast(3, tile1);
+    }
+}
+
 // ================================================================================================ K1g: step, group mapping
 // Sixteen lanes per env: a wave holds 4 envs, a 256-thread workgroup 16.  The waves of a workgroup never talk to each
 // other; the workgroup exists for PLACEMENT: its four waves go to the four SIMDs of one CU, so at N = 4096 (256 workgroups
@@ -1630,13 +1836,14 @@ __device__ __forceinline__ void group_store(float *__restrict__ state, int N, in
 // the younger one starves behind the older one's VALU stream (measured: 61 us instead of 30 us).
 // Physics: one wheel slot x role per lane, chassis replicated; MDP tail (terminations, rewards, reset, command):
 // replicated in the 16 lanes, stored by lane 0 of the group.
-#define RV_K1G_THREADS 256
-#define RV_K1G_ENVS (RV_K1G_THREADS / 16)
-__global__ __launch_bounds__(RV_K1G_THREADS) void rover_step_kernel_group(RvParams p, float *__restrict__ state,
-                                                              const float *__restrict__ action, float *__restrict__ obs,
-                                                              float *__restrict__ reward, uint8_t *__restrict__ terminated,
-                                                              uint8_t *__restrict__ truncated, float *__restrict__ force,
-                                                              float *__restrict__ log_partial)
+// FUSE: 0 = the step alone (the scan kernel follows as a second launch and reads the 32-byte descriptors); 1 / 2 = the height
+// scan of the wave's four envs (bilinear patch / triangle mesh, int16 terrain copy) is the LAST PHASE of the same wave, from two
+// wave-private LDS tiles (scan_private_wave): one launch per env step, no descriptor round trip, no second dispatch.
+template <int FUSE>
+__device__ __forceinline__ void step_group_body(const RvParams &p, float *__restrict__ state, const float *__restrict__ action,
+                                                float *__restrict__ obs, float *__restrict__ reward, uint8_t *__restrict__ terminated,
+                                                uint8_t *__restrict__ truncated, float *__restrict__ force,
+                                                float *__restrict__ log_partial, float *lds, const float2 *__restrict__ ray_xy)
 {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * (RV_K1G_THREADS / 64) + (threadIdx.x >> 6);
@@ -1692,7 +1899,6 @@ __global__ __launch_bounds__(RV_K1G_THREADS) void rover_step_kernel_group(RvPara
     K1_STAMP(20);
     if (!id.wheel_active) { Fw[0] = 0.0f; Fw[1] = 0.0f; Fw[2] = 0.0f; Fw[3] = 0.0f; }
     if (active) group_store(state, N, e, id, g);
-
     // contact report: gather the six Drive-body forces and the twelve link-point forces of the env (sensor body order) into
     // every lane -- only in waves where some body touches the obstacle layer (otherwise every force is the +0 the array holds)
     float F[ROVER_NUM_BODIES * 3];
@@ -1815,11 +2021,14 @@ __global__ __launch_bounds__(RV_K1G_THREADS) void rover_step_kernel_group(RvPara
             for (int i = 0; i < 14; ++i) vsel = (lane == i) ? lg[i] : vsel;
             log_partial[(size_t)wave * ROVER_LOG_WORDS + lane] = vsel;
         }
-        if (lane == 0) atomicAdd(p.log_counter, 1u);
+        if (lane == 0) {
+            atomicAdd(p.log_counter, 1u);
+            p.log_counter[1] = p.step_tag;   // the latest launch with resets (every wave of a launch stores the same value)
+        }
     }
     if (writer) {
         write_obs_head(p, S, obs, e);
-        write_scan_desc(p, S + ROVER_POS, S + ROVER_QUAT, e);
+        if (FUSE == 0) write_scan_desc(p, S + ROVER_POS, S + ROVER_QUAT, e);
         if (do_reset) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) state[(size_t)(ROVER_POS + i) * N + e] = S[ROVER_POS + i];
@@ -1834,6 +2043,38 @@ __global__ __launch_bounds__(RV_K1G_THREADS) void rover_step_kernel_group(RvPara
         truncated[e] = time_out ? 1 : 0;
     }
     K1_STAMP(25);
+    if constexpr (FUSE != 0) {
+        // ---- height scan of the wave's four envs.  Every lane of an env's row holds the env's (post-reset) pose: the window is
+        // formed in all lanes and lane 16 j's copy becomes wave-uniform.  (Staging the first two windows BEFORE the manager
+        // tail -- the pose is final after the physics unless the env resets -- moved the 2 x 2.6 k cycles of copy issue, it did
+        // not hide them, and the kernel got 2.5 us slower.)
+        const int tile_cells = p.tile_dim * p.tile_pitch;
+        const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        int16_t *ptile0 = reinterpret_cast<int16_t *>(lds) + (size_t)(2 * wv) * tile_cells;
+        const int n_scan = max(0, min(4, p.n - wave * 4));
+        PrivateWindows pw;
+        private_windows(scan_window(p, S + ROVER_POS, S + ROVER_QUAT), pw);
+        scan_private_wave<FUSE == 2>(p, ptile0, ptile0 + tile_cells, lane, n_scan, wave * 4, pw, obs, p.obs_w, 4, ray_xy);
+        K1_STAMP(26);
+    }
+}
+__global__ __launch_bounds__(RV_K1G_THREADS) void rover_step_kernel_group(RvParams p, float *__restrict__ state,
+                                                              const float *__restrict__ action, float *__restrict__ obs,
+                                                              float *__restrict__ reward, uint8_t *__restrict__ terminated,
+                                                              uint8_t *__restrict__ truncated, float *__restrict__ force,
+                                                              float *__restrict__ log_partial)
+{
+    step_group_body<0>(p, state, action, obs, reward, terminated, truncated, force, log_partial, nullptr, nullptr);
+}
+// One launch per env step: the group-mapped step with the height scan as its last phase (TRI: triangle-mesh surface).
+template <bool TRI>
+__global__ __launch_bounds__(RV_K1G_THREADS) __attribute__((target("no-unaligned-access-mode"))) void rover_step_scan_kernel(
+    RvParams p, float *__restrict__ state, const float *__restrict__ action, float *__restrict__ obs, float *__restrict__ reward,
+    uint8_t *__restrict__ terminated, uint8_t *__restrict__ truncated, float *__restrict__ force, float *__restrict__ log_partial,
+    const float2 *__restrict__ ray_xy)
+{
+    extern __shared__ __align__(16) float lds[];
+    step_group_body<TRI ? 2 : 1>(p, state, action, obs, reward, terminated, truncated, force, log_partial, lds, ray_xy);
 }
 
 __global__ __launch_bounds__(RV_K1G_THREADS) void rover_physics_kernel_group(RvParams p, float *__restrict__ state,
@@ -1914,28 +2155,6 @@ __global__ __launch_bounds__(64) void rover_reset_kernel(RvParams p, float *__re
 //   MODE 1  pose from the state tensor + observation head                                   (rover_reset)
 //   MODE 2  pose + terrain window from the 32-byte descriptor the step kernel left (one scalar load), the head was
 //           written by the step kernel; the LAST workgroup reduces the log partials          (rover_step)
-// surface height from four staged cells (unscaled): the plane of the cell's triangle the ray falls in (cells split along
-// the (i, j) - (i+1, j+1) diagonal: what a ray-cast of the terrain's triangle mesh returns) or the bilinear patch
-template <bool TRI, typename cell_t>
-__device__ __forceinline__ float patch_height(const cell_t *q, int pitch, float fx, float fy)
-{
-    // Four separate 16-bit LDS reads for the int16 tile.  With unaligned access enabled hipcc merges the two cells of a row into
-    // ONE ds_read_b32 at a 2-byte-aligned address, which costs more LDS time than the two reads it replaces (scan kernel 22.5
-    // vs 18.6 us at num_envs = 4096): rover_scan_step_kernel is compiled with target("no-unaligned-access-mode").  (A
-    // `volatile` read also prevents the merge, but turns the reads into serialised FLAT loads.)
-    const float h00 = (float)q[0], h01 = (float)q[1], h10 = (float)q[pitch], h11 = (float)q[pitch + 1];
-    if (TRI) {
-        const bool lower = fx >= fy;                       // lower triangle: corners 00, 01, 11; upper: 00, 10, 11
-        const float pm = lower ? h01 : h10;
-        const float d1 = pm - h00, d2 = h11 - pm;
-        const float a = lower ? d1 : d2, b = lower ? d2 : d1;
-        return fmaf(fy, b, fmaf(fx, a, h00));
-    }
-    const float dx0 = h01 - h00, dx1 = h11 - h10;
-    const float hx0 = h00 + fx * dx0;
-    const float hx1 = h10 + fx * dx1;
-    return hx0 + fy * (hx1 - hx0);
-}
 // extras["log"]: deterministic reduction of the per-wave log partials by the threads of ONE workgroup (workgroup 0 of the
 // scan kernel, after its last env): rows carrying this step's tag, GROUPS x 16 words, then a fixed-order sum.  In a step
 // without resets -- the common case -- the counter is zero and nothing is read.  (Until round 3 an EXTRA workgroup summed
@@ -1950,18 +2169,23 @@ __device__ __forceinline__ void reduce_log_partials(const RvParams &p, float *ld
 #ifdef RV_K2_NOREDUCE   // diagnostic build (wrong extras["log"]): what does the reduction cost the scan kernel?
     if (n_waves >= 0) return;
 #endif
+    // Rows carry the tag of the launch that wrote them; the reduction sums the rows of the LATEST launch in which an env reset
+    // (log_counter[1]).  Run behind every step that is this step's tag whenever the counter is non-zero; run on demand
+    // (rover_flush_log) it reproduces what the per-step reduction would hold: entries 0..12 from the latest step with resets,
+    // entry 13 = that step's count if it IS the latest step, else 0.
     const unsigned resets = *reinterpret_cast<volatile unsigned *>(p.log_counter);
     if (resets == 0u) {
         if (tid == 0) log_out[13] = 0.0f;
         return;
     }
+    const unsigned latest = *reinterpret_cast<volatile unsigned *>(p.log_counter + 1);
     constexpr int GROUPS = THREADS / 16;
     const int word = tid & 15, grp = tid >> 4;
     float acc = 0.0f;
     for (int w = grp; w < n_waves; w += GROUPS) {
         const float tag = log_partial[(size_t)w * ROVER_LOG_WORDS + 15];
         const float v = log_partial[(size_t)w * ROVER_LOG_WORDS + word];
-        acc += __float_as_uint(tag) == p.step_tag ? v : 0.0f;
+        acc += __float_as_uint(tag) == latest ? v : 0.0f;
     }
     lds[grp * 16 + word] = acc;
     __syncthreads();
@@ -1975,7 +2199,7 @@ __device__ __forceinline__ void reduce_log_partials(const RvParams &p, float *ld
     if (tid < 14) {
         const float cnt = lds[THREADS + 13];
         if (tid == 13) {
-            log_out[13] = cnt;
+            log_out[13] = latest == p.step_tag ? cnt : 0.0f;
         } else if (cnt > 0.0f) {
             const float s = lds[THREADS + tid];
             float val;
@@ -2193,7 +2417,7 @@ __global__ __launch_bounds__(RV_K2_THREADS) __attribute__((amdgpu_waves_per_eu(8
     wn = wnn;
     e = e_next;
     }  // env loop
-    if (MODE == 2 && blockIdx.x == 0) {   // workgroup 0, after its last env: extras["log"] of this step (usually one counter read)
+    if (MODE == 2 && blockIdx.x == 0 && log_out) {   // workgroup 0, after its last env: extras["log"] of this step (usually one counter read)
         __syncthreads();                  // the tiles are dead: the reduction reuses the LDS
         reduce_log_partials<RV_K2_THREADS>(p, lds, tid, log_partial, n_waves, log_out);
     }
@@ -2414,9 +2638,43 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8), 
         e0 = e_next;
         gidx = g_next;
     }
-    if (blockIdx.x == 0) {   // workgroup 0, after its last pair of envs: extras["log"] of this step (usually one counter read)
+    if (blockIdx.x == 0 && log_out) {   // workgroup 0, after its last pair of envs: extras["log"] of this step (usually one counter read)
         __syncthreads();     // the tiles are dead: the reduction reuses the LDS
         reduce_log_partials<THREADS>(p, lds, tid, log_partial, n_waves, log_out);
+    }
+}
+
+// extras["log"] behind the fused step kernel (the scan kernel's workgroup 0 does this on the two-launch path)
+// (1024 threads: the summation order of the scan kernel's reduction, so that both paths produce the same bits)
+__global__ __launch_bounds__(1024) void rover_log_kernel(RvParams p, const float *__restrict__ log_partial, int n_waves,
+                                                         float *__restrict__ log_out)
+{
+    __shared__ float lds[1024 + 16];
+    reduce_log_partials<1024>(p, lds, threadIdx.x, log_partial, n_waves, log_out);
+}
+template <bool TRI>
+__global__ __launch_bounds__(RV_K1G_THREADS) __attribute__((target("no-unaligned-access-mode"))) void rover_scan_private_kernel(
+    RvParams p, float *__restrict__ out, int row_stride, int col0, const float *__restrict__ log_partial, int n_waves,
+    float *__restrict__ log_out, const float *__restrict__ scan_desc, const float2 *__restrict__ ray_xy)
+{
+    extern __shared__ __align__(16) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int e_base = (blockIdx.x * (RV_K1G_THREADS / 64) + wv) * 4;
+    const int tile_cells = p.tile_dim * p.tile_pitch;
+    int16_t *tile0 = reinterpret_cast<int16_t *>(lds) + (size_t)(2 * wv) * tile_cells, *tile1 = tile0 + tile_cells;
+    const int n_env = max(0, min(4, p.n - e_base));
+    PrivateWindows w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 *d = reinterpret_cast<const float4 *>(scan_desc + (size_t)min(e_base + j, p.n - 1) * 8);
+        const float4 d0 = d[0], d1 = d[1];
+        w.px[j] = d0.x; w.py[j] = d0.y; w.pz[j] = d0.z; w.cy[j] = d0.w; w.sy[j] = d1.x;
+        w.i_lo[j] = __float_as_int(d1.y); w.j_lo[j] = __float_as_int(d1.z); w.pk[j] = __float_as_int(d1.w);
+    }
+    scan_private_wave<TRI>(p, tile0, tile1, lane, n_env, e_base, w, out, row_stride, col0, ray_xy);
+    if (blockIdx.x == 0 && log_out) {   // workgroup 0: extras["log"] of this step (usually one counter read)
+        __syncthreads();     // the tiles are dead: the reduction reuses the LDS
+        reduce_log_partials<RV_K1G_THREADS>(p, lds, tid, log_partial, n_waves, log_out);
     }
 }
 
@@ -2529,6 +2787,11 @@ struct rover_sim {
     int scan_form;     // measurement hook: 1 = the generic scan kernel on the step path too
     bool markers;      // roctx ranges around the launches of rover_step (rover_set_markers)
     uint32_t log_serial; // tag of the log-partial rows of the launch under way
+    int fused;           // one launch per step (rover_step_scan_kernel): -1 = decide (group mapping, int16 terrain copy, <= 1024 rays,
+                         // the four waves' eight tiles fit the LDS, one workgroup per CU holds the batch), 0 = off, 1 = on where possible
+    size_t fused_lds_set; // dynamic-LDS limit already raised to this many bytes for the fused kernels
+    bool log_deferred;   // rover_set_log_deferred: rover_step leaves `log` alone, rover_flush_log reduces it on demand
+    float2 *ray_xy;      // [1024] pattern offsets of ray i (rays past the pattern repeat ray 0): the wave-private scan's table (workspace)
 };
 
 
@@ -2581,6 +2844,23 @@ static ScanForm scan_form_of(const rover_sim *sim, int mode)
     return f;
 }
 
+// Does rover_step run as ONE launch (rover_step_scan_kernel: the scan is the last phase of the step kernel's waves)?
+static size_t fused_lds_bytes(const rover_sim *sim) { return (size_t)(RV_K1G_THREADS / 64) * 2 * (size_t)sim->p.tile_dim * sim->p.tile_pitch * 2; }
+static bool fused_step(const rover_sim *sim)
+{
+    if (sim->fused == 0 || !sim->group_mapping || sim->scan_form != 0) return false;
+    const ScanForm f = scan_form_of(sim, 2);
+    if (!f.simple || !f.q16 || sim->p.rays > 1024 || sim->p.ray_blocks) return false;
+    if (fused_lds_bytes(sim) > 160 * 1024) return false;
+    // the tiles leave room for ONE workgroup per CU: past one round of workgroups the two-launch path (two step-kernel
+    // workgroups per CU, a scan kernel with eight waves per SIMD) is the faster one
+    // ... and without the on-demand log reduction the one launch would need a second one after all (4 us behind the boundary)
+    return sim->fused == 1 || (sim->step_blocks <= sim->n_cu && sim->log_deferred);
+}
+// the kernel launches of one env step (rover_step / rover_profile_step); ev: optional event recorded between the two launches
+static void launch_step_kernels(rover_sim *sim, hipStream_t st, const float *action, float *obs, float *reward, uint8_t *terminated,
+                                uint8_t *truncated, float *force, float *log, hipEvent_t mid);
+
 template <int MODE>
 static void launch_scan(rover_sim *sim, int grid, hipStream_t st, float *out, int row_stride, int col0, const float *log_partial,
                         int n_waves, float *log_out)
@@ -2590,6 +2870,24 @@ static void launch_scan(rover_sim *sim, int grid, hipStream_t st, float *out, in
     const bool q16 = f.q16, tri = f.tri, simple = f.simple;
     const int epi = f.epi;
     const size_t step_lds = f.step_lds;
+    if (MODE == 2 && sim->scan_form == 7 && simple && q16) {   // measurement hook: the wave-private form as a kernel of its own
+        const size_t tile_bytes = (size_t)sim->p.tile_dim * sim->p.tile_pitch * 2;
+        size_t lds = (RV_K1G_THREADS / 64) * 2 * tile_bytes;
+        if (lds < (RV_K1G_THREADS + 16) * sizeof(float)) lds = (RV_K1G_THREADS + 16) * sizeof(float);
+        if (lds <= 160 * 1024) {
+            const int blocks = (sim->p.n + RV_K1G_ENVS - 1) / RV_K1G_ENVS;
+            if (tri) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rover_scan_private_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL((rover_scan_private_kernel<true>), dim3(blocks), dim3(RV_K1G_THREADS), lds, st, sim->p, out, row_stride, col0,
+                                   log_partial, n_waves, log_out, sim->p.scan_desc, sim->ray_xy);
+            } else {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rover_scan_private_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL((rover_scan_private_kernel<false>), dim3(blocks), dim3(RV_K1G_THREADS), lds, st, sim->p, out, row_stride, col0,
+                                   log_partial, n_waves, log_out, sim->p.scan_desc, sim->ray_xy);
+            }
+            return;
+        }
+    }
 #define RV_LAUNCH_STEP(Q, T, E)                                                                                               \
     hipLaunchKernelGGL((rover_scan_step_kernel<Q, T, 1024, E>), dim3(grid), dim3(1024), step_lds, st, sim->p, out, row_stride, \
                        col0, log_partial, n_waves, log_out, sim->p.scan_desc)
@@ -2637,6 +2935,46 @@ struct MarkerRange {
     MarkerRange(const rover_sim *sim, const char *name) : on(sim->markers && roctx_resolve()) { if (on) g_roctx_push(name); }
     ~MarkerRange() { if (on) g_roctx_pop(); }
 };
+
+static void launch_step_kernels(rover_sim *sim, hipStream_t st, const float *action, float *obs, float *reward, uint8_t *terminated,
+                                uint8_t *truncated, float *force, float *log, hipEvent_t mid)
+{
+    const RvParams &p = sim->p;
+    if (fused_step(sim)) {
+        MarkerRange k1(sim, "rover_step_scan_kernel");
+        const size_t lds = fused_lds_bytes(sim);
+        if (sim->fused_lds_set != lds) {   // once per handle and tile size (the attribute call costs tens of microseconds of host time)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rover_step_scan_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rover_step_scan_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            sim->fused_lds_set = lds;
+        }
+        if (p.cfg.scan_surface == 0) {
+            hipLaunchKernelGGL((rover_step_scan_kernel<true>), dim3(sim->step_blocks), dim3(RV_K1G_THREADS), lds, st, p, sim->state, action, obs,
+                               reward, terminated, truncated, force, sim->log_partial, sim->ray_xy);
+        } else {
+            hipLaunchKernelGGL((rover_step_scan_kernel<false>), dim3(sim->step_blocks), dim3(RV_K1G_THREADS), lds, st, p, sim->state, action, obs,
+                               reward, terminated, truncated, force, sim->log_partial, sim->ray_xy);
+        }
+        if (mid) (void)hipEventRecord(mid, st);
+        if (!sim->log_deferred)
+            hipLaunchKernelGGL(rover_log_kernel, dim3(1), dim3(1024), 0, st, p, sim->log_partial, sim->n_waves, log);
+        return;
+    }
+    {
+        MarkerRange k1(sim, sim->group_mapping ? "K1 rover_step_kernel_group" : "K1 rover_step_kernel");
+        if (sim->group_mapping)
+            hipLaunchKernelGGL(rover_step_kernel_group, dim3(sim->step_blocks), dim3(RV_K1G_THREADS), 0, st, p, sim->state, action, obs, reward,
+                               terminated, truncated, force, sim->log_partial);
+        else
+            hipLaunchKernelGGL(rover_step_kernel, dim3(sim->step_blocks), dim3(64), 0, st, p, sim->state, action, obs, reward,
+                               terminated, truncated, force, sim->log_partial);
+    }
+    if (mid) (void)hipEventRecord(mid, st);
+    {
+        MarkerRange k2(sim, "K2 scan + observation rows");
+        launch_scan<2>(sim, p.n + 1, st, obs, p.obs_w, 4, sim->log_partial, sim->n_waves, sim->log_deferred ? nullptr : log);
+    }
+}
 
 extern "C" {
 
@@ -2710,7 +3048,12 @@ int rover_create(const rover_config *cfg, int32_t num_envs, int32_t env_id_offse
     // workspace: [log partials, padded to 128 B][scan descriptors: n x 32 B]
     s->ws_log_floats = (((size_t)(((num_envs + RV_K1G_ENVS - 1) / RV_K1G_ENVS) * (RV_K1G_THREADS / 64)) * ROVER_LOG_WORDS) + 31) & ~(size_t)31;
     // workspace: [log partials][scan descriptors n x 8 floats, padded to 128 B][the reset-wave counter, 128 B]
-    s->ws_bytes = (((s->ws_log_floats + (size_t)num_envs * 8) * sizeof(float) + 127) & ~(size_t)127) + 128;
+    // ... [ray pattern table of the wave-private scan, 1024 x 8 B] ...
+    s->ws_bytes = (((s->ws_log_floats + (size_t)num_envs * 8) * sizeof(float) + 127) & ~(size_t)127) + 1024 * sizeof(float2) + 128;
+    s->ray_xy = nullptr;
+    s->fused = -1;
+    s->fused_lds_set = 0;
+    s->log_deferred = false;
     *out = s;
     return ROVER_OK;
 }
@@ -2782,9 +3125,21 @@ int rover_bind(rover_sim *sim, float *state, void *workspace, size_t workspace_b
     sim->log_partial = static_cast<float *>(workspace);
     sim->p.scan_desc = sim->log_partial + sim->ws_log_floats;
     sim->p.log_counter = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + sim->ws_bytes - 128);
+    sim->ray_xy = reinterpret_cast<float2 *>(static_cast<char *>(workspace) + sim->ws_bytes - 128 - 1024 * sizeof(float2));
     {
         DeviceGuard guard(sim->device);
         HIP_TRY(hipMemset(sim->p.log_counter, 0, 128));   // init-time, synchronous; the scan kernel returns it to zero after every reduction
+        // ORBIT grid_pattern: arange(-size/2, size/2 + 1e-9, res) evaluated in double, x fastest (App. C) -- the values the scan
+        // kernels derive per thread
+        const rover_config &c = sim->p.cfg;
+        std::vector<float2> tab(1024);
+        const int rays = c.scan_nx * c.scan_ny;
+        for (int i = 0; i < 1024; ++i) {
+            const int r = i < rays ? i : 0;
+            tab[i].x = (float)(-0.5 * (double)c.scan_size_x + (double)c.scan_resolution * (double)(r % c.scan_nx));
+            tab[i].y = (float)(-0.5 * (double)c.scan_size_y + (double)c.scan_resolution * (double)(r / c.scan_nx));
+        }
+        HIP_TRY(hipMemcpy(sim->ray_xy, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice));
     }
     return ROVER_OK;
 }
@@ -2884,21 +3239,24 @@ int rover_step(rover_sim *sim, const float *action, float *obs, float *reward, u
     DeviceGuard guard(sim->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
     next_batch(sim);
-    const RvParams &p = sim->p;
     MarkerRange whole(sim, "rover_step");
-    {
-        MarkerRange k1(sim, sim->group_mapping ? "K1 rover_step_kernel_group" : "K1 rover_step_kernel");
-        if (sim->group_mapping)
-            hipLaunchKernelGGL(rover_step_kernel_group, dim3(sim->step_blocks), dim3(RV_K1G_THREADS), 0, st, p, sim->state, action, obs, reward,
-                               terminated, truncated, force, sim->log_partial);
-        else
-            hipLaunchKernelGGL(rover_step_kernel, dim3(sim->step_blocks), dim3(64), 0, st, p, sim->state, action, obs, reward,
-                               terminated, truncated, force, sim->log_partial);
-    }
-    {
-        MarkerRange k2(sim, "K2 scan + observation rows");
-        launch_scan<2>(sim, p.n + 1, st, obs, p.obs_w, 4, sim->log_partial, sim->n_waves, log);
-    }
+    launch_step_kernels(sim, st, action, obs, reward, terminated, truncated, force, log, nullptr);
+    HIP_TRY(hipGetLastError());
+    return ROVER_OK;
+}
+
+int rover_set_log_deferred(rover_sim *sim, int32_t deferred)
+{
+    if (!sim) return fail(ROVER_ERR_INVALID, "sim is NULL");
+    sim->log_deferred = deferred != 0;
+    return ROVER_OK;
+}
+int rover_flush_log(rover_sim *sim, float *log, void *stream)
+{
+    if (int rc = ready(sim)) return rc;
+    if (!log) return fail(ROVER_ERR_INVALID, "log is NULL");
+    DeviceGuard guard(sim->device);
+    hipLaunchKernelGGL(rover_log_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), sim->p, sim->log_partial, sim->n_waves, log);
     HIP_TRY(hipGetLastError());
     return ROVER_OK;
 }
@@ -2918,6 +3276,11 @@ int rover_kernel_names(const rover_sim *sim, char *step_kernel, char *scan_kerne
     // and of profiles/hbm_traffic.json.
     if (!sim || !step_kernel || !scan_kernel || cap < 8) return fail(ROVER_ERR_INVALID, "bad argument");
     if (!sim->have_terrain) return fail(ROVER_ERR_STATE, "rover_set_terrain has not been called");
+    if (fused_step(sim)) {   // one launch: the scan is the last phase of the step kernel; the second name is the log reduction's
+        snprintf(step_kernel, cap, "rover_step_scan_kernel<%s>", sim->p.cfg.scan_surface == 0 ? "true" : "false");
+        snprintf(scan_kernel, cap, "%s", sim->log_deferred ? "" : "rover_log_kernel");
+        return ROVER_OK;
+    }
     snprintf(step_kernel, cap, "%s", sim->group_mapping ? "rover_step_kernel_group" : "rover_step_kernel");
     const ScanForm f = scan_form_of(sim, 2);
     if (f.simple)
@@ -2938,18 +3301,10 @@ int rover_profile_step(rover_sim *sim, const float *action, float *obs, float *r
     DeviceGuard guard(sim->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
     next_batch(sim);
-    const RvParams &p = sim->p;
     hipEvent_t ev[3];
     for (int i = 0; i < 3; ++i) HIP_TRY(hipEventCreate(&ev[i]));
     HIP_TRY(hipEventRecord(ev[0], st));
-    if (sim->group_mapping)
-        hipLaunchKernelGGL(rover_step_kernel_group, dim3(sim->step_blocks), dim3(RV_K1G_THREADS), 0, st, p, sim->state, action, obs, reward,
-                           terminated, truncated, force, sim->log_partial);
-    else
-        hipLaunchKernelGGL(rover_step_kernel, dim3(sim->step_blocks), dim3(64), 0, st, p, sim->state, action, obs, reward,
-                           terminated, truncated, force, sim->log_partial);
-    HIP_TRY(hipEventRecord(ev[1], st));
-    launch_scan<2>(sim, p.n + 1, st, obs, p.obs_w, 4, sim->log_partial, sim->n_waves, log);
+    launch_step_kernels(sim, st, action, obs, reward, terminated, truncated, force, log, ev[1]);
     HIP_TRY(hipEventRecord(ev[2], st));
     HIP_TRY(hipEventSynchronize(ev[2]));
     HIP_TRY(hipEventElapsedTime(ms_step_kernel, ev[0], ev[1]));
@@ -3023,7 +3378,7 @@ int rover_height_scan(rover_sim *sim, float *scan, void *stream)
 // step form with one env per iteration
 int rover_debug_set_scan_form(rover_sim *sim, int form)
 {
-    if (!sim || form < 0 || form > 6) return ROVER_ERR_INVALID;
+    if (!sim || form < 0 || form > 7) return ROVER_ERR_INVALID;   // 7: the wave-private scan as a kernel of its own
     if (form == 5 || form == 6) {   // 5 / 6: XCD-aware dealing of the env pairs off / on (measurement hook; default on)
         sim->p.xcd_rows = form == 6;
         return ROVER_OK;
@@ -3033,6 +3388,13 @@ int rover_debug_set_scan_form(rover_sim *sim, int form)
         return ROVER_OK;
     }
     sim->scan_form = form;
+    return ROVER_OK;
+}
+// measurement hook: -1 = automatic, 0 = two launches per step, 1 = one launch wherever the fused kernel can run
+int rover_debug_set_fused(rover_sim *sim, int fused)
+{
+    if (!sim || fused < -1 || fused > 1) return ROVER_ERR_INVALID;
+    sim->fused = fused;
     return ROVER_OK;
 }
 #ifdef RV_K1_STAMP

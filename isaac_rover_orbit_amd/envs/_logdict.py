@@ -1,0 +1,32 @@
+"""``extras["log"]`` reduced on demand: a dict of 0-d device tensors whose read accessors first let the env run its pending
+log reduction (``flush_log``), so that the values are the ones a per-step reduction would have left there."""
+from __future__ import annotations
+
+
+class LogDict(dict):
+    """A ``dict`` (ORBIT's ``extras["log"]`` holds 0-d tensors under "Episode Reward/<term>" ... keys) bound to an env with a
+    ``flush_log()`` method.  Iteration over keys alone does not need the values and does not flush."""
+
+    def __init__(self, env, items):
+        super().__init__(items)
+        self._env = env
+
+    def __getitem__(self, k):
+        self._env.flush_log()
+        return super().__getitem__(k)
+
+    def get(self, k, default=None):
+        self._env.flush_log()
+        return super().get(k, default)
+
+    def items(self):
+        self._env.flush_log()
+        return super().items()
+
+    def values(self):
+        self._env.flush_log()
+        return super().values()
+
+    def copy(self):
+        self._env.flush_log()
+        return dict(super().items())

@@ -18,6 +18,7 @@ import numpy as np
 import torch
 
 from .. import _lib
+from ._logdict import LogDict
 from .rover_env import RLTaskEnv, _ptr, _spaces
 
 REWARD_ORDER = ["reaching_object", "lifting_object", "object_goal_tracking", "object_goal_tracking_fine_grained", "action_rate",
@@ -93,36 +94,6 @@ class LiftEnvCfg:
         return c
 
 
-class _LogDict(dict):
-    """``extras["log"]``: a dict of 0-d device tensors (views of the env's log vector, as ORBIT's ``extras["log"]`` holds 0-d
-    tensors).  Every read access first lets the env run its pending reduction (``FrankaCubeLiftEnv.flush_log``), so that the
-    values are the ones a per-step reduction would have left there; iteration over keys alone does not need it."""
-
-    def __init__(self, env, items):
-        super().__init__(items)
-        self._env = env
-
-    def __getitem__(self, k):
-        self._env.flush_log()
-        return super().__getitem__(k)
-
-    def get(self, k, default=None):
-        self._env.flush_log()
-        return super().get(k, default)
-
-    def items(self):
-        self._env.flush_log()
-        return super().items()
-
-    def values(self):
-        self._env.flush_log()
-        return super().values()
-
-    def copy(self):
-        self._env.flush_log()
-        return dict(super().items())
-
-
 class _Managers:
     pass
 
@@ -161,7 +132,7 @@ class FrankaCubeLiftEnv(RLTaskEnv):
         if self.cfg.log_reduction not in ("on_demand", "every_step"):
             raise ValueError("log_reduction must be 'on_demand' or 'every_step'")
         _lib.check(self._lib.rover_lift_set_log_deferred(self._h, int(self._log_deferred)), "rover_lift_set_log_deferred")
-        self._log_dict = _LogDict(self, {k: self._log[i] for i, k in enumerate(LOG_KEYS)})
+        self._log_dict = LogDict(self, {k: self._log[i] for i, k in enumerate(LOG_KEYS)})
         self.extras = {"log": self._log_dict, "episode": self._log_dict}
         self.episode_length_buf = self.state[_lib.LIFT_EP_LEN].view(torch.int32)
         self.obs_buf = {"policy": self._obs[0]}

@@ -21,6 +21,7 @@ import torch
 from .. import _lib
 from ..cfg import OBS_ORDER, REWARD_ORDER, TERMINATION_ORDER, RoverEnvCfg
 from ..terrain import Terrain, make_flat_terrain, make_procedural_terrain
+from ._logdict import LogDict
 
 try:  # gymnasium is what the reference uses (robots/aau_rover/__init__.py:3); optional here
     import gymnasium as gym
@@ -292,8 +293,14 @@ class RoverEnv(RLTaskEnv):
         self.reward_buf = self._rew[0]
         self.reset_terminated = self._term[0].view(torch.bool)
         self.reset_time_outs = self._trunc[0].view(torch.bool)
-        # extras["log"]: 0-d views into the device log vector, refreshed by the kernels (no host sync)
-        self._log_dict = {k: self._log[i] for i, k in enumerate(LOG_KEYS)}
+        # extras["log"]: 0-d views into the device log vector, refreshed by the kernels (no host sync).  "on_demand" (default): the
+        # reduction behind it runs when the dictionary is READ -- the same numbers, and rover_step may then be ONE kernel launch
+        self._log_pending = False
+        self._log_deferred = getattr(self.cfg, "log_reduction", "on_demand") == "on_demand"
+        if getattr(self.cfg, "log_reduction", "on_demand") not in ("on_demand", "every_step"):
+            raise ValueError("log_reduction must be 'on_demand' or 'every_step'")
+        _lib.check(self._lib.rover_set_log_deferred(self._h, int(self._log_deferred)), "rover_set_log_deferred")
+        self._log_dict = LogDict(self, {k: self._log[i] for i, k in enumerate(LOG_KEYS)})
         self.extras = {"log": self._log_dict, "episode": self._log_dict}   # rover_env.py:39
 
         # ---- manager / scene facades + spaces
@@ -406,11 +413,19 @@ class RoverEnv(RLTaskEnv):
             _lib.check(rc, "rover_step")
         self._bump_counter()
         self.common_step_counter += 1
+        self._log_pending = self._log_deferred
         self.obs_buf = self._obs_dicts[k]
         self.reward_buf = self._rew[k]
         self.reset_terminated = self._term_b[k]
         self.reset_time_outs = self._trunc_b[k]
         return self.obs_buf, self.reward_buf, self.reset_terminated, self.reset_time_outs, self.extras
+
+    def flush_log(self):
+        """Bring ``extras["log"]`` / ``episode_log_vector`` up to date (``rover_flush_log``).  The log dictionary calls it on
+        every read; only code that kept one of its tensors from an earlier step needs to call it itself."""
+        if self._log_pending:
+            self._log_pending = False
+            _lib.check(self._lib.rover_flush_log(self._h, self._log_ptr, self._stream()), "rover_flush_log")
 
     def profile_step(self, action: torch.Tensor):
         """``step`` (same validation and bookkeeping) with HIP-event timing of the two kernels; returns
@@ -424,6 +439,7 @@ class RoverEnv(RLTaskEnv):
                                                 self._stream(), C.byref(a), C.byref(b)), "rover_profile_step")
         self._bump_counter()
         self.common_step_counter += 1
+        self._log_pending = self._log_deferred
         self.obs_buf = self._obs_dicts[k]
         self.reward_buf = self._rew[k]
         self.reset_terminated = self._term_b[k]
@@ -509,7 +525,8 @@ class RoverEnv(RLTaskEnv):
         """The raw 16-float device vector behind ``extras["log"]``: [0:7] mean episodic reward sums per term, [7:11]
         number of envs that ended this step by (time_out, is_success, far_from_target, collision), [11:13] mean metrics,
         [13] number of envs that were reset in this step.  Entries other than [13] keep their last value while no env
-        resets (ORBIT only refreshes ``extras["log"]`` on resets)."""
+        resets (ORBIT only refreshes ``extras["log"]`` on resets).  Reading it runs the pending reduction first."""
+        self.flush_log()
         return self._log
 
     # ---- state access (env state is never checkpointed in the reference; here it is just a tensor) -------------
@@ -525,6 +542,7 @@ class RoverEnv(RLTaskEnv):
     # the global env id and the per-env reset counter, which is a state word), so resuming is exact
     def state_dict(self) -> dict:
         """Everything needed to continue bit-for-bit: state words, the last observation, the episodic log vector."""
+        self.flush_log()
         return {"state": self.get_state().cpu(), "obs": self.obs_buf["policy"].detach().cpu().clone(),
                 "log": self._log.detach().cpu().clone(), "num_envs": self.num_envs,
                 "common_step_counter": int(self.common_step_counter), "call_counter": self.call_counter,
@@ -536,6 +554,7 @@ class RoverEnv(RLTaskEnv):
         if int(sd["num_envs"]) != self.num_envs or tuple(sd["state"].shape) != (self.num_envs, _lib.STATE_WORDS):
             raise ValueError("checkpoint was taken from an env of a different size")
         self.set_state(sd["state"])
+        self.flush_log()                                       # nothing of the old trajectory may land in the restored vector later
         self._log.copy_(sd["log"].to(self._log.device))
         self._obs[self._cur].copy_(sd["obs"].to(self.device))
         self.common_step_counter = int(sd.get("common_step_counter", 0))

@@ -23,6 +23,8 @@ def make_env(n, ter, **over):
     cfg = RoverEnvCfg()
     cfg.scene.num_envs = n
     cfg.terrain.kind = "custom"
+    if over.get("step_mapping") == "group2":     # the group mapping as TWO launches (log reduced behind every step by the scan kernel)
+        over = dict(over, step_mapping="group", log_reduction="every_step")
     for k, v in over.items():
         setattr(cfg, k, v)
     if ter.spawn_locations is None or ter.spawn_locations.shape[0] != 2 * (cfg.global_num_envs or n):
@@ -211,7 +213,9 @@ def test_reset_matches_oracle(oracle):
 
 
 # ------------------------------------------------------------------------------------------------ physics
-MAPPINGS = ["lane", "group"]     # one env per lane | eight lanes per env: both must reproduce the oracle bit for bit
+# one env per lane | sixteen lanes per env, ONE launch per step (height scan = last phase of the step kernel, log on demand: the
+# product form up to 4096 envs) | sixteen lanes per env, two launches: all must reproduce the oracle bit for bit
+MAPPINGS = ["lane", "group", "group2"]
 
 
 @pytest.mark.parametrize("mapping", MAPPINGS)
@@ -311,7 +315,7 @@ def rollout_compare(oracle, env, steps, actions, tol_step, tol_final, resync):
         assert_close(obs[ok], obs_o[ok], tol, tol, f"obs step {k}")
         assert_close(rew[ok], rew_o[ok], tol, tol, f"reward step {k}")
         if not bad.any():
-            log = env._log.cpu().numpy()
+            log = env.episode_log_vector.cpu().numpy()
             assert log[13] == log_o[13], f"reset count step {k}"
             assert_close(log[:13], log_o[:13], 1e-7, 1e-5, f"extras['log'] step {k}")
         S = state_np(env)
@@ -516,7 +520,7 @@ def test_timeout_truncation_and_success(oracle, mapping, reset_velocities):
     assert (term.cpu().numpy().astype(np.uint8) == term_o).all() and (trunc.cpu().numpy().astype(np.uint8) == trunc_o).all()
     assert_close(rew.cpu().numpy(), rew_o, 0, 0, "reward with forced branches")
     assert_close(obs["policy"].cpu().numpy(), obs_o, 0, 0, "obs with forced branches")
-    log = env._log.cpu().numpy()
+    log = env.episode_log_vector.cpu().numpy()
     assert log[13] == log_o[13] and log[13] >= 40
     assert_close(log[:13], log_o[:13], 1e-7, 1e-5, "extras['log']")
     # reset envs observe a zeroed last action and a fresh episode counter
@@ -556,7 +560,7 @@ def test_full_size_properties():
         d = (st[52] ** 2 + st[53] ** 2).sqrt() * 0.11
         assert torch.allclose(o[:, 2], d, atol=1e-5)
         total_resets += int(done.sum())
-        assert float(env._log[13]) == float(done.sum())
+        assert float(env.episode_log_vector[13]) == float(done.sum())
     assert total_resets > 0
     env.close()
 
@@ -628,6 +632,9 @@ def test_kernel_names_markers_and_spawn_table_check():
     for the without-replacement draw."""
     ter = small_procedural()
     env = make_env(64, ter)
+    assert env.kernel_names() == ("rover_step_scan_kernel<true>", "")        # one launch per step, log on demand
+    env.close()
+    env = make_env(64, ter, log_reduction="every_step")
     k1, k2 = env.kernel_names()
     assert k1 == "rover_step_kernel_group" and k2 == "rover_scan_step_kernel<true, true, 1024, 2>"
     env.set_markers(True)
@@ -689,6 +696,7 @@ def test_random_configurations_match_oracle(oracle, seed):
     cfg.use_int16_terrain = bool(rng.randint(0, 2))
     cfg.height_scanner.surface = str(rng.choice(["triangles", "bilinear"]))
     cfg.spawn_draw = str(rng.choice(["distinct", "independent"]))
+    cfg.log_reduction = str(rng.choice(["on_demand", "every_step"]))      # with "group" + int16 terrain: one launch per step / two
     env = RoverEnv(cfg, terrain=ter)
     assert env.num_rays == nx * ny, (env.num_rays, nx, ny, res)
     actions = rng.uniform(-1, 1, (12, n, 2)).astype(np.float32)

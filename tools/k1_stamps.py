@@ -12,7 +12,12 @@ _lib.LIB_PATH = os.path.join(ROOT, "build", "abl", f"librover_abl{os.environ.get
 _lib.EXPORTS.append("rover_debug_set_k1_stamps")
 ter = T.make_procedural_terrain((2048, 2048)); ter.make_spawns(2 * n)
 cfg = RoverEnvCfg(); cfg.scene.num_envs = n; cfg.terrain.kind = "custom"
-env = RoverEnv(cfg, terrain=ter); env.reset()
+env = RoverEnv(cfg, terrain=ter)
+if os.environ.get("FUSED"):
+    fnf = env._lib.rover_debug_set_fused; fnf.argtypes = [C.c_void_p, C.c_int]
+    assert fnf(env._h, int(os.environ["FUSED"])) == 0
+env.reset()
+print(env.kernel_names())
 stamps = torch.zeros(n // 16, 32, dtype=torch.int64, device="cuda")
 fn = env._lib.rover_debug_set_k1_stamps; fn.argtypes = [C.c_void_p]
 assert fn(C.c_void_p(stamps.data_ptr())) == 0
@@ -27,12 +32,18 @@ for i in range(6):
     names[2 + 3 * i] = f"sub{i} start"; names[3 + 3 * i] = f"sub{i} geometry done"; names[4 + 3 * i] = f"sub{i} solver done"
 names.update({20: "physics done", 23: "state stored + force gathered", 24: "mdp terms done", 21: "rewards + reset done", 22: "command done", 25: "log + final stores done"})
 order = [0, 1] + [k for i in range(6) for k in (2 + 3 * i, 3 + 3 * i, 4 + 3 * i)] + [20, 23, 24, 21, 22, 25]
+fused = env.kernel_names()[0].startswith("rover_step_scan_kernel")
+if fused:
+    names.update({27: "scan: windows, tiles 0 / 1 + ray table landed", 28: "scan: env 0 cast", 29: "scan: tile 2 issued, env 1 cast",
+                  30: "scan: tile 3 issued, tile 2 landed", 31: "scan: env 2 cast", 26: "scan: env 3 cast"})
+    names[19] = "scan: tile 2's copy instructions ISSUED (stamp without a wait)"
+    order += [27, 28, 19, 29, 30, 31, 26]
 keys = order
 prev = None
-tot = np.median(s[:, 25] - s[:, 0])
+tot = None
 for k in keys:
     if prev is not None:
         d = s[:, k] - s[:, prev]
         print(f"{names[k]:28s} +{np.median(d):8.0f} cycles (p90 {np.percentile(d, 90):8.0f})")
     prev = k
-print("total start->end median", tot, "cycles")
+print("total start->end median", np.median(s[:, keys[-1]] - s[:, 0]), "cycles")
