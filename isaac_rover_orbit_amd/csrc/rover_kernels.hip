@@ -1745,52 +1745,61 @@ __device__ __forceinline__ void private_windows(const ScanWindow &sw, PrivateWin
         w.pk[j] = __builtin_amdgcn_readlane(pk, 16 * j);
     }
 }
+constexpr int PRIVATE_ROUNDS = 16, PRIVATE_GROUP = 16;
+// A lane without a ray in round m repeats ray 0 (the table says so) and stores the same bits to row[0] again: no execution
+// masks, no branches inside a group of GROUP rounds -- one basic block whose 4 GROUP LDS reads the scheduler can put in
+// flight together (with a branch per round the fused kernel spent 600 cycles per round, three times its VALU work).
+// Rounds [M0, M1) of the env's sixteen (the step wave and its copy wave share an env's rays).
+template <bool TRI, int M0 = 0, int M1 = PRIVATE_ROUNDS>
+__device__ __forceinline__ void private_cast(const RvParams &p, const PrivateWindows &w, int j, const int16_t *tile, int lane, int e_base,
+                                             float *__restrict__ out, int row_stride, int col0, const float (&ox)[PRIVATE_ROUNDS],
+                                             const float (&oy)[PRIVATE_ROUNDS], const float2 *__restrict__ ray_xy)
+{
+    constexpr int CC = 8, G = PRIVATE_GROUP < M1 - M0 ? PRIVATE_GROUP : M1 - M0;
+    static_assert((M1 - M0) % G == 0, "whole groups");
+    const int th = w.pk[j] & 0x7FFF;
+    const int pitch = (w.pk[j] >> 16) * CC;
+    float *row = out + (size_t)(e_base + j) * row_stride + col0;
+    if ((w.pk[j] >> 15) & 1) {
+#pragma unroll
+        for (int m0 = M0; m0 < M1; m0 += G) {
+            if (m0 * 64 < p.rays) {      // wave-uniform, once per group of rounds
+                float o[G];
+#pragma unroll
+                for (int q = 0; q < G; ++q)
+                    o[q] = private_ray<TRI, true>(p, tile, pitch, th, w.px[j], w.py[j], w.pz[j], w.cy[j], w.sy[j], w.i_lo[j],
+                                                  w.j_lo[j], ox[m0 + q], oy[m0 + q]);
+#pragma unroll
+                for (int q = 0; q < G; ++q) {
+                    const int r = lane + 64 * (m0 + q);
+                    row[r < p.rays ? r : 0] = o[q];
+                }
+            }
+        }
+    } else {
+#pragma unroll 1
+        for (int m = M0; m < M1; ++m) {
+            if (m * 64 < p.rays) {
+                // (ox / oy indexed by a loop counter would leave the registers: the slow path re-reads the table)
+                const float2 xy = ray_xy[m * 64 + lane];
+                const float o = private_ray<TRI, false>(p, tile, pitch, th, w.px[j], w.py[j], w.pz[j], w.cy[j], w.sy[j], w.i_lo[j],
+                                                        w.j_lo[j], xy.x, xy.y);
+                const int r = lane + 64 * m;
+                if (r < p.rays) row[r] = o;
+            }
+        }
+    }
+}
 // ray_xy: 1024 x (x, y) pattern offsets of ray m * 64 + lane (rays past the pattern repeat ray 0), built by the host
 template <bool TRI>
 __device__ __forceinline__ void scan_private_wave(const RvParams &p, int16_t *tile0, int16_t *tile1, int lane, int n_env, int e_base,
                                                   const PrivateWindows &w, float *__restrict__ out, int row_stride, int col0,
                                                   const float2 *__restrict__ ray_xy, bool issued01 = false)
 {
-    constexpr int CC = 8, ROUNDS = 16, GROUP = 8;
+    constexpr int ROUNDS = PRIVATE_ROUNDS;
     auto issue = [&](int j, int16_t *tile) { private_issue(p, w, j, tile, lane); };
     float ox[ROUNDS], oy[ROUNDS];
-    // A lane without a ray in round m repeats ray 0 (the table says so) and stores the same bits to row[0] again: no execution
-    // masks, no branches inside a group of GROUP rounds -- one basic block whose 4 GROUP LDS reads the scheduler can put in
-    // flight together (with a branch per round the fused kernel spent 600 cycles per round, three times its VALU work).
-    auto cast = [&](int j, const int16_t *tile) {
-        const int th = w.pk[j] & 0x7FFF;
-        const int pitch = (w.pk[j] >> 16) * CC;
-        float *row = out + (size_t)(e_base + j) * row_stride + col0;
-        if ((w.pk[j] >> 15) & 1) {
-#pragma unroll
-            for (int m0 = 0; m0 < ROUNDS; m0 += GROUP) {
-                if (m0 * 64 < p.rays) {      // wave-uniform, once per group of rounds
-                    float o[GROUP];
-#pragma unroll
-                    for (int q = 0; q < GROUP; ++q)
-                        o[q] = private_ray<TRI, true>(p, tile, pitch, th, w.px[j], w.py[j], w.pz[j], w.cy[j], w.sy[j], w.i_lo[j],
-                                                      w.j_lo[j], ox[m0 + q], oy[m0 + q]);
-#pragma unroll
-                    for (int q = 0; q < GROUP; ++q) {
-                        const int r = lane + 64 * (m0 + q);
-                        row[r < p.rays ? r : 0] = o[q];
-                    }
-                }
-            }
-        } else {
-#pragma unroll 1
-            for (int m = 0; m < ROUNDS; ++m) {
-                if (m * 64 < p.rays) {
-                    // (ox / oy indexed by a loop counter would leave the registers: the slow path re-reads the table)
-                    const float2 xy = ray_xy[m * 64 + lane];
-                    const float o = private_ray<TRI, false>(p, tile, pitch, th, w.px[j], w.py[j], w.pz[j], w.cy[j], w.sy[j], w.i_lo[j],
-                                                            w.j_lo[j], xy.x, xy.y);
-                    const int r = lane + 64 * m;
-                    if (r < p.rays) row[r] = o;
-                }
-            }
-        }
-    };
+    auto cast = [&](int j, const int16_t *tile) { private_cast<TRI>(p, w, j, tile, lane, e_base, out, row_stride, col0, ox, oy, ray_xy); };
     if (n_env <= 0) return;
     if (!issued01) {   // (the fused step kernel stages the first two windows before its manager tail)
         issue(0, tile0);
@@ -1827,6 +1836,81 @@ __device__ __forceinline__ void scan_private_wave(const RvParams &p, int16_t *ti
         __builtin_amdgcn_wave_barrier();
         cast(3, tile1);
     }
+}
+
+// ---- the fused step kernel's scan phase with COPY WAVES.  One wave issues a global_load_lds_dwordx4 every ~145 cycles and
+// nothing else meanwhile (2.5 k cycles per window, measured with a stamp that does not wait), so the four step waves of a
+// workgroup are paired with four copy waves (waves 4..7, one per SIMD, asleep at a barrier during the physics): copy wave k + 4
+// stages the windows of step wave k -- the first two under k's manager tail, the third and fourth under k's rays.
+// The copy wave also casts: rounds 8..15 of envs 0 and 3 (nothing to stage beside them), 12..15 of envs 1 and 2.
+// Windows travel through LDS (win[wave][set][env][8 words]: set 0 = after the physics, set 1 = final); SIX workgroup barriers,
+// executed by all eight waves on every path (B2 right after B: the step wave has restaged windows 0, 1 if one of its envs reset):
+//   A  set 0 written            | copy: stage windows 0, 1 (set 0), wait        | step: manager tail, set 1, ray table
+//   B  windows 0, 1 landed, set 1 written                                        | step: (reset in the wave: restage 0, 1 itself) rays of env 0
+//   C  tile 0 free              | copy: stage window 2 (set 1) into tile 0, wait | step: rays of env 1
+//   D  window 2 landed, tile 1 free | copy: stage window 3 into tile 1, wait     | step: rays of env 2
+//   E  window 3 landed                                                           | step: rays of env 3
+__device__ __forceinline__ void windows_to_lds(float *win, const ScanWindow &sw, int lane)
+{
+    if ((lane & 15) == 0) {
+        float4 *d = reinterpret_cast<float4 *>(win + (lane >> 4) * 8);
+        d[0] = make_float4(sw.px, sw.py, sw.pz, sw.cy);
+        d[1] = make_float4(sw.sy, __int_as_float(sw.i_lo), __int_as_float(sw.j_lo), __int_as_float(sw.th | (sw.interior << 15) | (sw.tw4 << 16)));
+    }
+}
+__device__ __forceinline__ void windows_from_lds(const float *win, PrivateWindows &w)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 d0 = reinterpret_cast<const float4 *>(win + j * 8)[0], d1 = reinterpret_cast<const float4 *>(win + j * 8)[1];
+        auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+        w.px[j] = uni(d0.x); w.py[j] = uni(d0.y); w.pz[j] = uni(d0.z); w.cy[j] = uni(d0.w); w.sy[j] = uni(d1.x);
+        w.i_lo[j] = __builtin_amdgcn_readfirstlane(__float_as_int(d1.y)); w.j_lo[j] = __builtin_amdgcn_readfirstlane(__float_as_int(d1.z));
+        w.pk[j] = __builtin_amdgcn_readfirstlane(__float_as_int(d1.w));
+    }
+}
+// rounds of an env's sixteen cast by the step wave; the copy wave takes the rest (it also has a window to stage under envs 1, 2)
+constexpr int SHARE_FREE = 8, SHARE_COPY = 12;
+template <bool TRI>
+__device__ __forceinline__ void scan_copy_wave(const RvParams &p, float *lds, int partner, int lane, float *__restrict__ obs,
+                                               const float2 *__restrict__ ray_xy)
+{
+    const int tile_cells = p.tile_dim * p.tile_pitch;
+    int16_t *tile0 = reinterpret_cast<int16_t *>(lds) + (size_t)(2 * partner) * tile_cells, *tile1 = tile0 + tile_cells;
+    const float *win = reinterpret_cast<const float *>(reinterpret_cast<int16_t *>(lds) + (size_t)8 * tile_cells) + partner * 64;
+    const int e_base = (int)(blockIdx.x * 4 + partner) * 4;
+    const int n_env = max(0, min(4, p.n - e_base));
+    PrivateWindows w;
+    __syncthreads();                                                    // A
+    windows_from_lds(win, w);
+    if (n_env > 0) private_issue(p, w, 0, tile0, lane);
+    if (n_env > 1) private_issue(p, w, 1, tile1, lane);
+    float ox[PRIVATE_ROUNDS], oy[PRIVATE_ROUNDS];
+#pragma unroll
+    for (int m = 0; m < PRIVATE_ROUNDS; ++m) {
+        ox[m] = 0.0f; oy[m] = 0.0f;
+        if (m >= SHARE_FREE) {
+            const float2 v = ray_xy[m * 64 + lane];
+            ox[m] = v.x;
+            oy[m] = v.y;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                                    // B
+    windows_from_lds(win + 32, w);
+    __syncthreads();                                                    // B2 (a reset in the step wave: it has restaged windows 0, 1)
+    if (n_env > 0) private_cast<TRI, SHARE_FREE, PRIVATE_ROUNDS>(p, w, 0, tile0, lane, e_base, obs, p.obs_w, 4, ox, oy, ray_xy);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                                    // C
+    if (n_env > 2) private_issue(p, w, 2, tile0, lane);
+    if (n_env > 1) private_cast<TRI, SHARE_COPY, PRIVATE_ROUNDS>(p, w, 1, tile1, lane, e_base, obs, p.obs_w, 4, ox, oy, ray_xy);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                                    // D
+    if (n_env > 3) private_issue(p, w, 3, tile1, lane);
+    if (n_env > 2) private_cast<TRI, SHARE_COPY, PRIVATE_ROUNDS>(p, w, 2, tile0, lane, e_base, obs, p.obs_w, 4, ox, oy, ray_xy);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                                    // E
+    if (n_env > 3) private_cast<TRI, SHARE_FREE, PRIVATE_ROUNDS>(p, w, 3, tile1, lane, e_base, obs, p.obs_w, 4, ox, oy, ray_xy);
 }
 
 // ================================================================================================ K1g: step, group mapping
@@ -1899,6 +1983,12 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
     K1_STAMP(20);
     if (!id.wheel_active) { Fw[0] = 0.0f; Fw[1] = 0.0f; Fw[2] = 0.0f; Fw[3] = 0.0f; }
     if (active) group_store(state, N, e, id, g);
+    if constexpr (FUSE != 0) {   // the physics has fixed the pose (unless the env resets below): its windows go to the copy wave
+        const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        float *win = reinterpret_cast<float *>(reinterpret_cast<int16_t *>(lds) + (size_t)8 * p.tile_dim * p.tile_pitch) + wv * 64;
+        windows_to_lds(win, scan_window(p, g.pos, g.quat), lane);
+        __syncthreads();                                                // A
+    }
     // contact report: gather the six Drive-body forces and the twelve link-point forces of the env (sensor body order) into
     // every lane -- only in waves where some body touches the obstacle layer (otherwise every force is the +0 the array holds)
     float F[ROVER_NUM_BODIES * 3];
@@ -2044,17 +2134,52 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
     }
     K1_STAMP(25);
     if constexpr (FUSE != 0) {
-        // ---- height scan of the wave's four envs.  Every lane of an env's row holds the env's (post-reset) pose: the window is
-        // formed in all lanes and lane 16 j's copy becomes wave-uniform.  (Staging the first two windows BEFORE the manager
-        // tail -- the pose is final after the physics unless the env resets -- moved the 2 x 2.6 k cycles of copy issue, it did
-        // not hide them, and the kernel got 2.5 us slower.)
+        // ---- height scan of the wave's four envs (see scan_copy_wave for the protocol).  Every lane of an env's row holds the
+        // env's final pose: the window is formed in all lanes, lane 16 j's copy goes to LDS (set 1) and becomes wave-uniform.
         const int tile_cells = p.tile_dim * p.tile_pitch;
         const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-        int16_t *ptile0 = reinterpret_cast<int16_t *>(lds) + (size_t)(2 * wv) * tile_cells;
+        int16_t *tile0 = reinterpret_cast<int16_t *>(lds) + (size_t)(2 * wv) * tile_cells, *tile1 = tile0 + tile_cells;
+        float *win = reinterpret_cast<float *>(reinterpret_cast<int16_t *>(lds) + (size_t)8 * tile_cells) + wv * 64;
         const int n_scan = max(0, min(4, p.n - wave * 4));
+        const int e_base = wave * 4;
         PrivateWindows pw;
-        private_windows(scan_window(p, S + ROVER_POS, S + ROVER_QUAT), pw);
-        scan_private_wave<FUSE == 2>(p, ptile0, ptile0 + tile_cells, lane, n_scan, wave * 4, pw, obs, p.obs_w, 4, ray_xy);
+        {
+            const ScanWindow sw = scan_window(p, S + ROVER_POS, S + ROVER_QUAT);
+            windows_to_lds(win + 32, sw, lane);
+            private_windows(sw, pw);
+        }
+        float ox[PRIVATE_ROUNDS], oy[PRIVATE_ROUNDS];
+#pragma unroll
+        for (int m = 0; m < PRIVATE_ROUNDS; ++m) {
+            ox[m] = 0.0f; oy[m] = 0.0f;
+            if (m < SHARE_COPY) {
+                const float2 v = ray_xy[m * 64 + lane];
+                ox[m] = v.x;
+                oy[m] = v.y;
+            }
+        }
+        const bool restage = __ballot(do_reset) != 0ull;   // a reset moved a rover of this wave: windows 0 / 1 were staged for the old pose
+        __syncthreads();                                                // B
+        if (restage) {
+            if (n_scan > 0) private_issue(p, pw, 0, tile0, lane);
+            if (n_scan > 1) private_issue(p, pw, 1, tile1, lane);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the ray table (and a restaged window)
+        __syncthreads();                                                // B2
+        K1_STAMP(27);
+        if (n_scan > 0) private_cast<FUSE == 2, 0, SHARE_FREE>(p, pw, 0, tile0, lane, e_base, obs, p.obs_w, 4, ox, oy, ray_xy);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        K1_STAMP(28);
+        __syncthreads();                                                // C
+        if (n_scan > 1) private_cast<FUSE == 2, 0, SHARE_COPY>(p, pw, 1, tile1, lane, e_base, obs, p.obs_w, 4, ox, oy, ray_xy);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        K1_STAMP(29);
+        __syncthreads();                                                // D
+        if (n_scan > 2) private_cast<FUSE == 2, 0, SHARE_COPY>(p, pw, 2, tile0, lane, e_base, obs, p.obs_w, 4, ox, oy, ray_xy);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        K1_STAMP(31);
+        __syncthreads();                                                // E
+        if (n_scan > 3) private_cast<FUSE == 2, 0, SHARE_FREE>(p, pw, 3, tile1, lane, e_base, obs, p.obs_w, 4, ox, oy, ray_xy);
         K1_STAMP(26);
     }
 }
@@ -2068,13 +2193,17 @@ __global__ __launch_bounds__(RV_K1G_THREADS) void rover_step_kernel_group(RvPara
 }
 // One launch per env step: the group-mapped step with the height scan as its last phase (TRI: triangle-mesh surface).
 template <bool TRI>
-__global__ __launch_bounds__(RV_K1G_THREADS) __attribute__((target("no-unaligned-access-mode"))) void rover_step_scan_kernel(
+__global__ __launch_bounds__(2 * RV_K1G_THREADS) __attribute__((target("no-unaligned-access-mode"))) void rover_step_scan_kernel(
     RvParams p, float *__restrict__ state, const float *__restrict__ action, float *__restrict__ obs, float *__restrict__ reward,
     uint8_t *__restrict__ terminated, uint8_t *__restrict__ truncated, float *__restrict__ force, float *__restrict__ log_partial,
     const float2 *__restrict__ ray_xy)
 {
     extern __shared__ __align__(16) float lds[];
-    step_group_body<TRI ? 2 : 1>(p, state, action, obs, reward, terminated, truncated, force, log_partial, lds, ray_xy);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (wv < RV_K1G_THREADS / 64)   // waves 0..3: the step (threadIdx.x < 256: the group kernel's own indexing); waves 4..7: their copy waves
+        step_group_body<TRI ? 2 : 1>(p, state, action, obs, reward, terminated, truncated, force, log_partial, lds, ray_xy);
+    else
+        scan_copy_wave<TRI>(p, lds, wv - RV_K1G_THREADS / 64, (int)(threadIdx.x & 63), obs, ray_xy);
 }
 
 __global__ __launch_bounds__(RV_K1G_THREADS) void rover_physics_kernel_group(RvParams p, float *__restrict__ state,
@@ -2845,7 +2974,8 @@ static ScanForm scan_form_of(const rover_sim *sim, int mode)
 }
 
 // Does rover_step run as ONE launch (rover_step_scan_kernel: the scan is the last phase of the step kernel's waves)?
-static size_t fused_lds_bytes(const rover_sim *sim) { return (size_t)(RV_K1G_THREADS / 64) * 2 * (size_t)sim->p.tile_dim * sim->p.tile_pitch * 2; }
+// eight tiles (two per step wave) + the windows' hand-over area (4 waves x 2 sets x 4 envs x 32 B)
+static size_t fused_lds_bytes(const rover_sim *sim) { return (size_t)(RV_K1G_THREADS / 64) * 2 * (size_t)sim->p.tile_dim * sim->p.tile_pitch * 2 + 1024; }
 static bool fused_step(const rover_sim *sim)
 {
     if (sim->fused == 0 || !sim->group_mapping || sim->scan_form != 0) return false;
@@ -2949,10 +3079,10 @@ static void launch_step_kernels(rover_sim *sim, hipStream_t st, const float *act
             sim->fused_lds_set = lds;
         }
         if (p.cfg.scan_surface == 0) {
-            hipLaunchKernelGGL((rover_step_scan_kernel<true>), dim3(sim->step_blocks), dim3(RV_K1G_THREADS), lds, st, p, sim->state, action, obs,
+            hipLaunchKernelGGL((rover_step_scan_kernel<true>), dim3(sim->step_blocks), dim3(2 * RV_K1G_THREADS), lds, st, p, sim->state, action, obs,
                                reward, terminated, truncated, force, sim->log_partial, sim->ray_xy);
         } else {
-            hipLaunchKernelGGL((rover_step_scan_kernel<false>), dim3(sim->step_blocks), dim3(RV_K1G_THREADS), lds, st, p, sim->state, action, obs,
+            hipLaunchKernelGGL((rover_step_scan_kernel<false>), dim3(sim->step_blocks), dim3(2 * RV_K1G_THREADS), lds, st, p, sim->state, action, obs,
                                reward, terminated, truncated, force, sim->log_partial, sim->ray_xy);
         }
         if (mid) (void)hipEventRecord(mid, st);

@@ -87,6 +87,24 @@ def test_lift_model_constants_agree_and_step_kernel_has_no_scratch():
             # one 2176-byte exchange slot set per wave; the two-wave pipelined form adds its hand-off buffers: 6144 bytes
             assert re.search(r"\.group_segment_fixed_size:\s*(2176|6144)\b", entry), f"{m.group(1)}: unexpected LDS size"
     assert found >= 3, "lift_step_kernel<8, true> / <8, false> / <16, false> not found in the code object metadata"
+    # the rover step kernels at one wave per SIMD: no scratch either, no static LDS (a promoted alloca would make the kernel read
+    # its workgroup size from the dispatch packet in host memory: DESIGN 3.1), and the one-launch form is a 512-thread workgroup
+    seen = {}
+    for blob in gfx950_code_objects(_lib.LIB_PATH):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(blob)
+            f.flush()
+            notes = subprocess.run([readelf, "--notes", f.name], capture_output=True, text=True).stdout
+        for entry in re.split(r"\n\s*- \.", notes):
+            m = re.search(r"\.name:\s*(\S*(rover_step_kernel_group|rover_step_scan_kernel)\S*)", entry)
+            if not m or ".private_segment_fixed_size" not in entry:
+                continue
+            seen[m.group(2)] = seen.get(m.group(2), 0) + 1
+            assert re.search(r"\.private_segment_fixed_size:\s*0\b", entry), f"{m.group(1)} uses scratch memory"
+            assert re.search(r"\.group_segment_fixed_size:\s*0\b", entry), f"{m.group(1)}: static LDS"
+            if m.group(2) == "rover_step_scan_kernel":
+                assert re.search(r"\.max_flat_workgroup_size:\s*512\b", entry), f"{m.group(1)}: four step waves + four copy waves"
+    assert seen.get("rover_step_kernel_group", 0) >= 1 and seen.get("rover_step_scan_kernel", 0) >= 2, seen
 
 
 def test_errors_are_codes_not_crashes():
