@@ -2984,8 +2984,10 @@ static bool fused_step(const rover_sim *sim)
     if (fused_lds_bytes(sim) > 160 * 1024) return false;
     // the tiles leave room for ONE workgroup per CU: past one round of workgroups the two-launch path (two step-kernel
     // workgroups per CU, a scan kernel with eight waves per SIMD) is the faster one
-    // ... and without the on-demand log reduction the one launch would need a second one after all (4 us behind the boundary)
-    return sim->fused == 1 || (sim->step_blocks <= sim->n_cu && sim->log_deferred);
+    // ... not far below it either: the scan phase of a wave is four envs long whatever the batch, while the scan KERNEL shrinks
+    // with it (N sweep: 1024 envs 36.7 vs 34.6 us, 4096 envs 42.0 vs 47.1 us per step; break-even near 2048 envs on 256 CUs);
+    // and without the on-demand log reduction the one launch would need a second one after all (4 us behind the boundary)
+    return sim->fused == 1 || (sim->step_blocks <= sim->n_cu && 2 * sim->step_blocks >= sim->n_cu && sim->log_deferred);
 }
 // the kernel launches of one env step (rover_step / rover_profile_step); ev: optional event recorded between the two launches
 static void launch_step_kernels(rover_sim *sim, hipStream_t st, const float *action, float *obs, float *reward, uint8_t *terminated,

@@ -29,7 +29,14 @@ def make_env(n, ter, **over):
         setattr(cfg, k, v)
     if ter.spawn_locations is None or ter.spawn_locations.shape[0] != 2 * (cfg.global_num_envs or n):
         ter.make_spawns(2 * (cfg.global_num_envs or n))
-    return RoverEnv(cfg, terrain=ter)
+    env = RoverEnv(cfg, terrain=ter)
+    if over.get("step_mapping") == "group" and cfg.log_reduction == "on_demand":
+        # "group" in these tests = the ONE-launch form at any batch size (the product picks it from 2048 envs per GPU on)
+        import ctypes as C
+        fn = C.CDLL(env._lib._name).rover_debug_set_fused
+        fn.argtypes = [C.c_void_p, C.c_int]
+        assert fn(env._h, 1) == 0
+    return env
 
 
 def oracle_side(ro, env, counter=None):
@@ -632,11 +639,11 @@ def test_kernel_names_markers_and_spawn_table_check():
     for the without-replacement draw."""
     ter = small_procedural()
     env = make_env(64, ter)
-    assert env.kernel_names() == ("rover_step_scan_kernel<true>", "")        # one launch per step, log on demand
-    env.close()
-    env = make_env(64, ter, log_reduction="every_step")
-    k1, k2 = env.kernel_names()
+    k1, k2 = env.kernel_names()                                              # 64 envs: two launches (one from 2048 envs on)
     assert k1 == "rover_step_kernel_group" and k2 == "rover_scan_step_kernel<true, true, 1024, 2>"
+    env.close()
+    env = make_env(64, ter, step_mapping="group")                            # the tests' "group" forces the one-launch form
+    assert env.kernel_names() == ("rover_step_scan_kernel<true>", "")        # ... whose log is reduced on demand
     env.set_markers(True)
     env.reset()
     o1 = env.step(torch.zeros(64, 2, device="cuda"))[0]["policy"].clone()
@@ -698,6 +705,11 @@ def test_random_configurations_match_oracle(oracle, seed):
     cfg.spawn_draw = str(rng.choice(["distinct", "independent"]))
     cfg.log_reduction = str(rng.choice(["on_demand", "every_step"]))      # with "group" + int16 terrain: one launch per step / two
     env = RoverEnv(cfg, terrain=ter)
+    if cfg.step_mapping == "group" and cfg.log_reduction == "on_demand":       # one launch per step wherever that kernel can run
+        import ctypes as C
+        fn = C.CDLL(env._lib._name).rover_debug_set_fused
+        fn.argtypes = [C.c_void_p, C.c_int]
+        assert fn(env._h, 1) == 0
     assert env.num_rays == nx * ny, (env.num_rays, nx, ny, res)
     actions = rng.uniform(-1, 1, (12, n, 2)).astype(np.float32)
     flips = rollout_compare(oracle, env, 12, actions, 0.0, 0.0, resync=False)

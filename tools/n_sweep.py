@@ -12,8 +12,11 @@ if os.environ.get("ABLTAG"):
     _lib.LIB_PATH = os.path.join(ROOT, "build", "abl", f"librover_abl{os.environ['ABLTAG']}.so")
 ter = T.make_procedural_terrain((2048, 2048))
 out = []
-CASES = [(1024, "group"), (4096, "group"), (4096, "lane"), (16384, "group"), (32768, "group"), (32768, "lane"),
-         (65536, "group"), (65536, "lane"), (131072, "group"), (131072, "lane")]
+# mapping: group = the product's choice for the group mapping (one launch per step while one round of workgroups holds the batch),
+# group2 = the group mapping as two launches (log reduced behind every step), groupf = one launch forced beyond that batch size
+CASES = [(1024, "group"), (1024, "group2"), (4096, "group"), (4096, "group2"), (4096, "lane"), (8192, "group"), (8192, "groupf"),
+         (16384, "group"), (16384, "groupf"), (32768, "group"), (32768, "lane"), (65536, "group"), (65536, "lane"), (131072, "group"),
+         (131072, "lane")]
 if len(sys.argv) > 1:   # e.g. 1024:group 2048:group:wave  (third field: scan kernel of the step path, auto | generic | epi1)
     CASES = [tuple(a.split(":")) for a in sys.argv[1:]]
 import ctypes as C
@@ -21,8 +24,13 @@ FORMS = {"auto": 0, "generic": 1, "epi1": 2, "blocks": 3, "lines": 4}   # blocks
 for case in CASES:
     n, mapping, form = int(case[0]), case[1], (case[2] if len(case) > 2 else "auto")
     ter.make_spawns(2 * n)
-    cfg = RoverEnvCfg(); cfg.scene.num_envs = n; cfg.terrain.kind = "custom"; cfg.step_mapping = mapping
+    cfg = RoverEnvCfg(); cfg.scene.num_envs = n; cfg.terrain.kind = "custom"; cfg.step_mapping = "group" if mapping.startswith("group") else mapping
+    if mapping == "group2":
+        cfg.log_reduction = "every_step"
     env = RoverEnv(cfg, terrain=ter)
+    if mapping == "groupf":
+        ff = C.CDLL(env._lib._name).rover_debug_set_fused; ff.argtypes = [C.c_void_p, C.c_int]
+        assert ff(env._h, 1) == 0
     fn = C.CDLL(env._lib._name).rover_debug_set_scan_form
     fn.argtypes = [C.c_void_p, C.c_int]
     assert fn(env._h, FORMS[form]) == 0
@@ -37,7 +45,7 @@ for case in CASES:
     a = b = 0.0
     for k in range(20):
         x, y = env.profile_step(acts[k % 16]); a += x; b += y
-    r = {"num_envs": n, "mapping": mapping, "scan_form": form, "env_steps_per_s": n * steps / dt, "us_per_step": dt / steps * 1e6,
+    r = {"num_envs": n, "mapping": mapping, "kernels": list(env.kernel_names()), "scan_form": form, "env_steps_per_s": n * steps / dt, "us_per_step": dt / steps * 1e6,
          "step_kernel_us": a / 20 * 1e3, "scan_kernel_us": b / 20 * 1e3}
     print(json.dumps(r)); out.append(r)
     env.close(); del env; torch.cuda.empty_cache()

@@ -20,10 +20,15 @@ if os.environ.get("ROVER_SCAN_FORM"):   # 3 = 8 x 8 ray blocks per wave, 4 = lin
     import ctypes as C
     fn = C.CDLL(env._lib._name).rover_debug_set_scan_form; fn.argtypes = [C.c_void_p, C.c_int]
     assert fn(env._h, int(os.environ["ROVER_SCAN_FORM"])) == 0
-env.reset()
-g = torch.Generator(device="cuda").manual_seed(0)
-acts = torch.rand(min(steps, 64), n, 2, device="cuda", generator=g) * 2 - 1
-for k in range(steps):
-    env.step(acts[k % acts.shape[0]])
-torch.cuda.synchronize()
-env.close()
+def run(env):
+    env.reset()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    acts = torch.rand(min(steps, 64), n, 2, device="cuda", generator=g) * 2 - 1
+    for k in range(steps):
+        env.step(acts[k % acts.shape[0]])
+    torch.cuda.synchronize()
+    env.close()
+run(env)
+if os.environ.get("ROVER_ALSO_TWO_LAUNCH"):   # the same workload on the two-launch path (the traffic of the step kernel alone)
+    cfg2 = RoverEnvCfg(); cfg2.scene.num_envs = n; cfg2.terrain.kind = "custom"; cfg2.log_reduction = "every_step"
+    run(RoverEnv(cfg2, terrain=ter))

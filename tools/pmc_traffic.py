@@ -28,7 +28,8 @@ def per_kernel(d):
         rows = list(csv.DictReader(open(f)))
         for r in rows:
             key = short_name(r["Kernel_Name"])
-            if key.startswith(("rover_scan_step_kernel", "rover_scan_obs_kernel<2", "rover_step_kernel", "lift_step_kernel")):
+            if key.startswith(("rover_scan_step_kernel", "rover_scan_obs_kernel<2", "rover_step_kernel", "rover_step_scan_kernel",
+                               "lift_step_kernel")):
                 acc[key][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
     out = {}
     for k, d2 in acc.items():
@@ -52,11 +53,20 @@ res = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT
                "value.  Keys = kernel names exactly as rocprofv3 prints them (minus qualifiers / parameter list) = "
                "rover_kernel_names().",
        "round": 3, "_build": sys.argv[5] if len(sys.argv) > 5 else ""}
+# The one-launch kernel (rover_step_scan_kernel) contains both read streams: the step phase's 4-byte terrain gathers (raw value)
+# and the scan phase's 16-byte window staging (x 2).  Its corrected fetch = 2 x raw - the step phase's share, taken from the
+# two-launch step kernel measured in the same passes (tools/pmc_run.py with ROVER_FUSED=0 runs behind the product run).
+step_raw = fetch.get("rover_step_kernel_group", {}).get("FETCH_SIZE")
 for k in sorted(set(fetch) & set(write) & set(tcc)):
-    corr = 2.0 if k.startswith("rover_scan") else 1.0
     f, w = fetch[k]["FETCH_SIZE"], write[k]["WRITE_SIZE"]
     h, m = tcc[k].get("TCC_HIT_sum", 0.0), tcc[k].get("TCC_MISS_sum", 0.0)
+    if k.startswith("rover_step_scan_kernel"):
+        corr = "2 x raw - step-phase share" if step_raw is not None else "2 (upper bound: the step phase's gathers doubled too)"
+        fetch_kib = 2.0 * f - (step_raw or 0.0)
+    else:
+        corr = 2.0 if k.startswith("rover_scan") else 1.0
+        fetch_kib = f * corr
     res[k] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "fetch_correction": corr,
-              "bytes_per_launch": int((f * corr + w) * 1024), "l2_hit_rate": h / max(h + m, 1.0)}
+              "bytes_per_launch": int((fetch_kib + w) * 1024), "l2_hit_rate": h / max(h + m, 1.0)}
 json.dump(res, open(sys.argv[4], "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -1,8 +1,9 @@
 #!/bin/bash
 # Dev tool (GPU box): the round-3 final measurement set (needs `python tools/build_diag.py LIFTSTAMP POLSTAMP K1STAMP` first).  Every step writes under gpurun_out/r03f; the chain stops at the first failing GPU step.
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03f; mkdir -p $O
-TAG="r03_f build (13-body contact report, tagged log partials reduced by scan workgroup 0, XCD-aware pair dealing; lift: 8 lanes per env, two pipelined waves, log reduced on demand; policy: reference-architecture kernel)"
+TAG="r03_f build (one launch per step: step + scan kernel with copy waves, log on demand; 13-body contact report; lift: 8 lanes per env, two pipelined waves, log reduced on demand; policy: reference-architecture kernel)"
 cd /tmp && export TMPDIR=/tmp
+export ROVER_ALSO_TWO_LAUNCH=1   # pmc_run.py: the two-launch path behind the product run (traffic of both forms)
 python3 -c "import sys; sys.path.insert(0,'$R'); import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 && \
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/tools/pmc_run.py 4096 20 > $O/pmc_fetch.log 2>&1 && \
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/tools/pmc_run.py 4096 20 > $O/pmc_write.log 2>&1 && \
