@@ -644,6 +644,15 @@ def test_kernel_names_markers_and_spawn_table_check():
     env.close()
     env = make_env(64, ter, step_mapping="group")                            # the tests' "group" forces the one-launch form
     assert env.kernel_names() == ("rover_step_scan_kernel<true>", "")        # ... whose log is reduced on demand
+    env.close()
+    # the product's own choice: one launch while one round of workgroups holds the batch and fills at least half the chip
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    for n_envs, fused in ((8 * cus - 16, False), (8 * cus, True), (16 * cus, True), (16 * cus + 16, False)):
+        env = make_env(n_envs, ter)
+        assert env.kernel_names()[0].startswith("rover_step_scan_kernel") == fused, (n_envs, env.kernel_names())
+        env.close()
+    env = make_env(16 * cus, ter, log_reduction="every_step")                # ... and only with the log reduced on demand
+    assert env.kernel_names()[0] == "rover_step_kernel_group"
     env.set_markers(True)
     env.reset()
     o1 = env.step(torch.zeros(64, 2, device="cuda"))[0]["policy"].clone()
