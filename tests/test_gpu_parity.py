@@ -655,7 +655,7 @@ def test_kernel_names_markers_and_spawn_table_check():
     assert env.kernel_names()[0] == "rover_step_kernel_group"
     env.set_markers(True)
     env.reset()
-    o1 = env.step(torch.zeros(64, 2, device="cuda"))[0]["policy"].clone()
+    o1 = env.step(torch.zeros(env.num_envs, 2, device="cuda"))[0]["policy"].clone()
     env.set_markers(False)
     env.close()
     from isaac_rover_orbit_amd.cfg import RoverEnvCfg
