@@ -1755,6 +1755,9 @@ __device__ __forceinline__ void private_cast(const RvParams &p, const PrivateWin
                                              float *__restrict__ out, int row_stride, int col0, const float (&ox)[PRIVATE_ROUNDS],
                                              const float (&oy)[PRIVATE_ROUNDS], const float2 *__restrict__ ray_xy)
 {
+    if constexpr (M1 <= M0) {   // an empty share
+        return;
+    } else {
     constexpr int CC = 8, G = PRIVATE_GROUP < M1 - M0 ? PRIVATE_GROUP : M1 - M0;
     static_assert((M1 - M0) % G == 0, "whole groups");
     const int th = w.pk[j] & 0x7FFF;
@@ -1788,6 +1791,7 @@ __device__ __forceinline__ void private_cast(const RvParams &p, const PrivateWin
                 if (r < p.rays) row[r] = o;
             }
         }
+    }
     }
 }
 // ray_xy: 1024 x (x, y) pattern offsets of ray m * 64 + lane (rays past the pattern repeat ray 0), built by the host
@@ -1870,7 +1874,13 @@ __device__ __forceinline__ void windows_from_lds(const float *win, PrivateWindow
     }
 }
 // rounds of an env's sixteen cast by the step wave; the copy wave takes the rest (it also has a window to stage under envs 1, 2)
-constexpr int SHARE_FREE = 8, SHARE_COPY = 12;
+#ifndef RV_SHARE_FREE
+#define RV_SHARE_FREE 8
+#endif
+#ifndef RV_SHARE_COPY
+#define RV_SHARE_COPY 12
+#endif
+constexpr int SHARE_FREE = RV_SHARE_FREE, SHARE_COPY = RV_SHARE_COPY;
 template <bool TRI>
 __device__ __forceinline__ void scan_copy_wave(const RvParams &p, float *lds, int partner, int lane, float *__restrict__ obs,
                                                const float2 *__restrict__ ray_xy)

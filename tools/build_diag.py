@@ -29,7 +29,13 @@ VARIANTS = {"STAMP": ("rover_kernels.hip", "-DRV_K2_STAMP"), "K1STAMP": ("rover_
             "K1_INK": ("rover_kernels.hip", "-DRV_K1_CONSTS_IN_KERNEL"),
             "NOSLP": ("rover_kernels.hip", "-fno-slp-vectorize"),
             "NOSLP_STAMP": ("rover_kernels.hip", "-fno-slp-vectorize -DRV_K1_STAMP"),
-            "POLSTAMP": ("policy_kernels.hip", "-DPOL_STAMP")}
+            "POLSTAMP": ("policy_kernels.hip", "-DPOL_STAMP"),
+            # split of an env's sixteen ray rounds between a step wave and its copy wave (one-launch kernel)
+            "SHARE_8_14": ("rover_kernels.hip", "-DRV_SHARE_FREE=8 -DRV_SHARE_COPY=14"),
+            "SHARE_8_16": ("rover_kernels.hip", "-DRV_SHARE_FREE=8 -DRV_SHARE_COPY=16"),
+            "SHARE_7_14": ("rover_kernels.hip", "-DRV_SHARE_FREE=7 -DRV_SHARE_COPY=14"),
+            "SHARE_6_13": ("rover_kernels.hip", "-DRV_SHARE_FREE=6 -DRV_SHARE_COPY=13"),
+            "SHARE_16_16": ("rover_kernels.hip", "-DRV_SHARE_FREE=16 -DRV_SHARE_COPY=16")}
 
 
 def main():

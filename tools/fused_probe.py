@@ -4,6 +4,9 @@ import os, sys, time, ctypes as C
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if os.environ.get("ABLTAG"):   # diagnostic build of tools/build_diag.py
+    from isaac_rover_orbit_amd import _lib
+    _lib.LIB_PATH = os.path.join(ROOT, "build", "abl", f"librover_abl{os.environ['ABLTAG']}.so")
 from isaac_rover_orbit_amd import terrain as T
 from isaac_rover_orbit_amd.cfg import RoverEnvCfg
 from isaac_rover_orbit_amd.envs import RoverEnv
