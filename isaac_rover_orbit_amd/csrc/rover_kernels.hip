@@ -2928,7 +2928,6 @@ struct rover_sim {
     uint32_t log_serial; // tag of the log-partial rows of the launch under way
     int fused;           // one launch per step (rover_step_scan_kernel): -1 = decide (group mapping, int16 terrain copy, <= 1024 rays,
                          // the four waves' eight tiles fit the LDS, one workgroup per CU holds the batch), 0 = off, 1 = on where possible
-    size_t fused_lds_set; // dynamic-LDS limit already raised to this many bytes for the fused kernels
     bool log_deferred;   // rover_set_log_deferred: rover_step leaves `log` alone, rover_flush_log reduces it on demand
     float2 *ray_xy;      // [1024] pattern offsets of ray i (rays past the pattern repeat ray 0): the wave-private scan's table (workspace)
 };
@@ -3085,10 +3084,15 @@ static void launch_step_kernels(rover_sim *sim, hipStream_t st, const float *act
     if (fused_step(sim)) {
         MarkerRange k1(sim, "rover_step_scan_kernel");
         const size_t lds = fused_lds_bytes(sim);
-        if (sim->fused_lds_set != lds) {   // once per handle and tile size (the attribute call costs tens of microseconds of host time)
+        // The limit is a property of the kernel (per device), shared by every handle of the process: only ever RAISE it -- a handle
+        // with smaller tiles must not lower it under another handle's launches.  (Not per launch: the call costs tens of
+        // microseconds of host time.)
+        static size_t raised[64] = {0};
+        size_t &have = raised[sim->device & 63];
+        if (lds > have) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rover_step_scan_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rover_step_scan_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            sim->fused_lds_set = lds;
+            have = lds;
         }
         if (p.cfg.scan_surface == 0) {
             hipLaunchKernelGGL((rover_step_scan_kernel<true>), dim3(sim->step_blocks), dim3(2 * RV_K1G_THREADS), lds, st, p, sim->state, action, obs,
@@ -3194,7 +3198,6 @@ int rover_create(const rover_config *cfg, int32_t num_envs, int32_t env_id_offse
     s->ws_bytes = (((s->ws_log_floats + (size_t)num_envs * 8) * sizeof(float) + 127) & ~(size_t)127) + 1024 * sizeof(float2) + 128;
     s->ray_xy = nullptr;
     s->fused = -1;
-    s->fused_lds_set = 0;
     s->log_deferred = false;
     *out = s;
     return ROVER_OK;

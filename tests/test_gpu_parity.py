@@ -681,6 +681,32 @@ def test_kernel_names_markers_and_spawn_table_check():
     assert torch.isfinite(o1[:, :4]).all()
 
 
+def test_one_launch_handles_with_different_tile_sizes():
+    """Two envs of one process whose one-launch kernels need different amounts of dynamic LDS (31 x 31 rays @ 0.1 m: 152 KB per
+    workgroup; 9 x 9 rays @ 0.1 m: a fraction), stepped alternately, the small one created last: the LDS limit of the kernel is
+    shared by the handles and must only ever be raised.  Each against its own two-launch twin, bit for bit."""
+    ter = small_procedural()
+    def pair(size):
+        envs = []
+        for mapping in ("group", "group2"):
+            from isaac_rover_orbit_amd.cfg import RoverEnvCfg
+            cfg = RoverEnvCfg()
+            cfg.height_scanner.size = (size, size)
+            envs.append(make_env(96, ter, seed=5, step_mapping=mapping, height_scanner=cfg.height_scanner))
+            envs[-1].reset()
+        assert envs[0].kernel_names()[0].startswith("rover_step_scan_kernel") and envs[1].kernel_names()[0] == "rover_step_kernel_group"
+        return envs
+    big, small = pair(3.0), pair(0.8)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for k in range(6):
+        a = torch.rand(96, 2, device="cuda", generator=g) * 2 - 1
+        for one, two in (big, small, big):
+            o1, o2 = one.step(a)[0]["policy"], two.step(a)[0]["policy"]
+            assert torch.equal(o1.view(torch.int32), o2.view(torch.int32)), k
+    for e in big + small:
+        e.close()
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
 def test_random_configurations_match_oracle(oracle, seed):
     """Config fuzz: ray pattern (3 x 3 ... 45 x 37 rays, 0.05-0.25 m spacing: one to three rays per thread, windows from
