@@ -6,7 +6,7 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one ``RoverEnv.step()`` over the rank's batch of envs: the hot path's HIP kernel -- ONE launch per step at the
-benchmark's 4096 envs per GPU (step + height scan), two launches outside 2048..4096 envs -- launched
+benchmark's 4096 envs per GPU (step + height scan), two launches below 2048 envs -- launched
 through the C ABI exactly as a trainer would (random actions pre-generated in HBM, in-kernel resets included).  Weak scaling:
 every rank simulates ``--num-envs`` envs (global ids sharded by rank, terrain replicated, no data-path collective).
 Rank 0 prints ONE JSON line.  Extra legs (not in the timed region):

@@ -176,7 +176,7 @@ int rover_step(rover_sim *sim, const float *action, float *obs, float *reward, u
  * latest step in which an env reset, [13] = the number of envs reset in the latest step (0 when the latest resets are older).
  * Flush at most once per step (a second flush without a step in between reports [13] = 0).  Deferral is also what lets
  * rover_step run as ONE kernel launch -- the height scan as the last phase of the step kernel's waves (group mapping, int16
- * terrain copy, a batch that one workgroup per compute unit holds): without it a second launch would follow for the log alone.
+ * terrain copy, a batch of at least eight envs per compute unit): without it a second launch would follow for the log alone.
  * Default: not deferred (two launches; the scan kernel's first workgroup reduces the log). */
 int rover_set_log_deferred(rover_sim *sim, int32_t deferred);
 int rover_flush_log(rover_sim *sim, float *log, void *stream);
@@ -197,7 +197,8 @@ int rover_profile_event_overhead(rover_sim *sim, void *stream, int32_t reps, flo
  * library is resolved with dlopen at the first enabling call (ROVER_ERR_UNSUPPORTED when none is installed).  Host only. */
 int rover_set_markers(rover_sim *sim, int32_t enabled);
 
-/* (One-launch form: step_kernel = "rover_step_scan_kernel<true|false>", scan_kernel = "rover_log_kernel" or "" when deferred.)
+/* (One-launch forms: step_kernel = "rover_step_scan_kernel<true|false>" / "rover_step_scan1_kernel<...>", scan_kernel =
+ * "rover_log_kernel", or "" when the log is deferred.)
  * Names of the two kernels rover_step launches for the current configuration / terrain, exactly as rocprofv3's kernel trace
  * prints them minus the "(anonymous namespace)::" qualifier and the parameter list (e.g. "rover_step_kernel_group",
  * "rover_scan_step_kernel<true, true, 1024, 2>"): the keys of bench.py's roofline block and of profiles/hbm_traffic.json.

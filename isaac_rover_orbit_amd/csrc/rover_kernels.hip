@@ -1842,6 +1842,38 @@ __device__ __forceinline__ void scan_private_wave(const RvParams &p, int16_t *ti
     }
 }
 
+// ---- the fused step kernel's scan phase WITHOUT copy waves, ONE tile per wave: for batches of more than one round of workgroups
+// (N > 16 x CUs).  Copy waves would put four 256-VGPR waves on a SIMD (two workgroups per CU); here a workgroup is the four step
+// waves with 4 x 18.9 KB of LDS, two workgroups share a CU as on the two-launch path, and what fills one wave's copy stalls
+// (2.5 k cycles per window) and LDS latencies is the other workgroup's wave on the same SIMD.
+template <bool TRI>
+__device__ __forceinline__ void scan_single_tile_wave(const RvParams &p, int16_t *tile, int lane, int n_env, int e_base,
+                                                      const PrivateWindows &w, float *__restrict__ out, int row_stride, int col0,
+                                                      const float2 *__restrict__ ray_xy)
+{
+    if (n_env <= 0) return;
+    private_issue(p, w, 0, tile, lane);
+    float ox[PRIVATE_ROUNDS], oy[PRIVATE_ROUNDS];
+#pragma unroll
+    for (int m = 0; m < PRIVATE_ROUNDS; ++m) {
+        const float2 v = ray_xy[m * 64 + lane];
+        ox[m] = v.x;
+        oy[m] = v.y;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j < n_env) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            private_cast<TRI>(p, w, j, tile, lane, e_base, out, row_stride, col0, ox, oy, ray_xy);
+            if (j + 1 < n_env) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile's last reads have returned
+                private_issue(p, w, j + 1, tile, lane);
+            }
+        }
+    }
+}
+
 // ---- the fused step kernel's scan phase with COPY WAVES.  One wave issues a global_load_lds_dwordx4 every ~145 cycles and
 // nothing else meanwhile (2.5 k cycles per window, measured with a stamp that does not wait), so the four step waves of a
 // workgroup are paired with four copy waves (waves 4..7, one per SIMD, asleep at a barrier during the physics): copy wave k + 4
@@ -1993,7 +2025,7 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
     K1_STAMP(20);
     if (!id.wheel_active) { Fw[0] = 0.0f; Fw[1] = 0.0f; Fw[2] = 0.0f; Fw[3] = 0.0f; }
     if (active) group_store(state, N, e, id, g);
-    if constexpr (FUSE != 0) {   // the physics has fixed the pose (unless the env resets below): its windows go to the copy wave
+    if constexpr (FUSE == 1 || FUSE == 2) {   // the physics has fixed the pose (unless the env resets below): its windows go to the copy wave
         const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         float *win = reinterpret_cast<float *>(reinterpret_cast<int16_t *>(lds) + (size_t)8 * p.tile_dim * p.tile_pitch) + wv * 64;
         windows_to_lds(win, scan_window(p, g.pos, g.quat), lane);
@@ -2143,7 +2175,16 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
         truncated[e] = time_out ? 1 : 0;
     }
     K1_STAMP(25);
-    if constexpr (FUSE != 0) {
+    if constexpr (FUSE == 3 || FUSE == 4) {   // no copy waves, one tile per wave (more than one round of workgroups)
+        const int tile_cells = p.tile_dim * p.tile_pitch;
+        const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        int16_t *tile = reinterpret_cast<int16_t *>(lds) + (size_t)wv * tile_cells;
+        PrivateWindows pw;
+        private_windows(scan_window(p, S + ROVER_POS, S + ROVER_QUAT), pw);
+        scan_single_tile_wave<FUSE == 4>(p, tile, lane, max(0, min(4, p.n - wave * 4)), wave * 4, pw, obs, p.obs_w, 4, ray_xy);
+        K1_STAMP(26);
+    }
+    if constexpr (FUSE == 1 || FUSE == 2) {
         // ---- height scan of the wave's four envs (see scan_copy_wave for the protocol).  Every lane of an env's row holds the
         // env's final pose: the window is formed in all lanes, lane 16 j's copy goes to LDS (set 1) and becomes wave-uniform.
         const int tile_cells = p.tile_dim * p.tile_pitch;
@@ -2783,6 +2824,16 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8), 
     }
 }
 
+// The same without copy waves (scan_single_tile_wave): 256-thread workgroups, two per CU.
+template <bool TRI>
+__global__ __launch_bounds__(RV_K1G_THREADS) __attribute__((target("no-unaligned-access-mode"))) void rover_step_scan1_kernel(
+    RvParams p, float *__restrict__ state, const float *__restrict__ action, float *__restrict__ obs, float *__restrict__ reward,
+    uint8_t *__restrict__ terminated, uint8_t *__restrict__ truncated, float *__restrict__ force, float *__restrict__ log_partial,
+    const float2 *__restrict__ ray_xy)
+{
+    extern __shared__ __align__(16) float lds[];
+    step_group_body<TRI ? 4 : 3>(p, state, action, obs, reward, terminated, truncated, force, log_partial, lds, ray_xy);
+}
 // extras["log"] behind the fused step kernel (the scan kernel's workgroup 0 does this on the two-launch path)
 // (1024 threads: the summation order of the scan kernel's reduction, so that both paths produce the same bits)
 __global__ __launch_bounds__(1024) void rover_log_kernel(RvParams p, const float *__restrict__ log_partial, int n_waves,
@@ -2928,6 +2979,7 @@ struct rover_sim {
     uint32_t log_serial; // tag of the log-partial rows of the launch under way
     int fused;           // one launch per step (rover_step_scan_kernel): -1 = decide (group mapping, int16 terrain copy, <= 1024 rays,
                          // the four waves' eight tiles fit the LDS, one workgroup per CU holds the batch), 0 = off, 1 = on where possible
+    bool single_tile_ok; // the single-tile one-launch form may be chosen automatically beyond one round of workgroups (measured: see fused_form)
     bool log_deferred;   // rover_set_log_deferred: rover_step leaves `log` alone, rover_flush_log reduces it on demand
     float2 *ray_xy;      // [1024] pattern offsets of ray i (rays past the pattern repeat ray 0): the wave-private scan's table (workspace)
 };
@@ -2983,20 +3035,43 @@ static ScanForm scan_form_of(const rover_sim *sim, int mode)
 }
 
 // Does rover_step run as ONE launch (rover_step_scan_kernel: the scan is the last phase of the step kernel's waves)?
+static size_t single_tile_lds_bytes(const rover_sim *sim) { return (size_t)(RV_K1G_THREADS / 64) * (size_t)sim->p.tile_dim * sim->p.tile_pitch * 2; }
 // eight tiles (two per step wave) + the windows' hand-over area (4 waves x 2 sets x 4 envs x 32 B)
 static size_t fused_lds_bytes(const rover_sim *sim) { return (size_t)(RV_K1G_THREADS / 64) * 2 * (size_t)sim->p.tile_dim * sim->p.tile_pitch * 2 + 1024; }
-static bool fused_step(const rover_sim *sim)
+// 0 = two launches, 1 = one launch with copy waves (one workgroup per CU), 2 = one launch, one tile per wave (two workgroups per CU)
+static int fused_form(const rover_sim *sim)
 {
-    if (sim->fused == 0 || !sim->group_mapping || sim->scan_form != 0) return false;
+    if (sim->fused == 0 || !sim->group_mapping || sim->scan_form != 0) return 0;
     const ScanForm f = scan_form_of(sim, 2);
-    if (!f.simple || !f.q16 || sim->p.rays > 1024 || sim->p.ray_blocks) return false;
-    if (fused_lds_bytes(sim) > 160 * 1024) return false;
-    // the tiles leave room for ONE workgroup per CU: past one round of workgroups the two-launch path (two step-kernel
-    // workgroups per CU, a scan kernel with eight waves per SIMD) is the faster one
-    // ... not far below it either: the scan phase of a wave is four envs long whatever the batch, while the scan KERNEL shrinks
-    // with it (N sweep: 1024 envs 36.7 vs 34.6 us, 4096 envs 42.0 vs 47.1 us per step; break-even near 2048 envs on 256 CUs);
-    // and without the on-demand log reduction the one launch would need a second one after all (4 us behind the boundary)
-    return sim->fused == 1 || (sim->step_blocks <= sim->n_cu && 2 * sim->step_blocks >= sim->n_cu && sim->log_deferred);
+    if (!f.simple || !f.q16 || sim->p.rays > 1024 || sim->p.ray_blocks) return 0;
+    const bool fits1 = fused_lds_bytes(sim) <= 160 * 1024, fits2 = 2 * single_tile_lds_bytes(sim) <= 160 * 1024;
+    if (sim->fused == 1) return fits1 ? 1 : 0;        // measurement hooks: force a form wherever its tiles fit
+    if (sim->fused == 2) return fits2 ? 2 : 0;
+    // without the on-demand log reduction the one launch would need a second one after all (4 us behind the boundary)
+    if (!sim->log_deferred) return 0;
+    // The copy-wave form holds ONE workgroup per CU: it is the one to use while one round of workgroups holds the batch -- and
+    // not far below that either: the scan phase of a wave is four envs long whatever the batch, while the scan KERNEL shrinks
+    // with it (N sweep: 1024 envs 36.7 vs 34.6 us, 4096 envs 42.0 vs 47.1 us per step; break-even near 2048 envs on 256 CUs).
+    if (fits1 && sim->step_blocks <= sim->n_cu) return 2 * sim->step_blocks >= sim->n_cu ? 1 : 0;
+    // More than one round of workgroups: the single-tile form keeps the two-launch path's two workgroups per CU (N sweep, us per
+    // step, one launch / two: 8192 envs 62.7 / 70.4, 16384 envs 112.0 / 125.6, 32768 envs 197.6 / 228.6).
+    return (sim->single_tile_ok && fits2) ? 2 : 0;
+}
+static bool fused_step(const rover_sim *sim) { return fused_form(sim) != 0; }
+// The automatic mapping (cfg.step_mapping = 0) from RV_GROUP_MAPPING_BELOW envs on: sixteen lanes per env if that runs as one
+// launch (single-tile form: 178 / 185 M env-steps/s at 65536 / 131072 envs), else one env per lane (165 / 168 M; the TWO-launch
+// group mapping is the slowest of the three there: 151 / 153 M).  Re-evaluated before a launch: the int16 terrain copy and the
+// on-demand log may be set after rover_create.  Both mappings produce the same bits from the same state layout.
+static void refresh_mapping(rover_sim *sim)
+{
+    if (sim->p.cfg.step_mapping != 0 || sim->p.n < RV_GROUP_MAPPING_BELOW) return;
+    auto set = [&](bool group) {
+        sim->group_mapping = group;
+        sim->step_blocks = group ? (sim->p.n + RV_K1G_ENVS - 1) / RV_K1G_ENVS : (sim->p.n + 63) / 64;
+        sim->n_waves = group ? sim->step_blocks * (RV_K1G_THREADS / 64) : sim->step_blocks;
+    };
+    set(true);
+    if (fused_form(sim) == 0) set(false);
 }
 // the kernel launches of one env step (rover_step / rover_profile_step); ev: optional event recorded between the two launches
 static void launch_step_kernels(rover_sim *sim, hipStream_t st, const float *action, float *obs, float *reward, uint8_t *terminated,
@@ -3080,8 +3155,31 @@ struct MarkerRange {
 static void launch_step_kernels(rover_sim *sim, hipStream_t st, const float *action, float *obs, float *reward, uint8_t *terminated,
                                 uint8_t *truncated, float *force, float *log, hipEvent_t mid)
 {
+    refresh_mapping(sim);
     const RvParams &p = sim->p;
-    if (fused_step(sim)) {
+    const int form = fused_form(sim);
+    if (form == 2) {
+        MarkerRange k1(sim, "rover_step_scan1_kernel");
+        const size_t lds = single_tile_lds_bytes(sim);
+        static size_t raised1[64] = {0};
+        size_t &have = raised1[sim->device & 63];
+        if (lds > have) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rover_step_scan1_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rover_step_scan1_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            have = lds;
+        }
+        if (p.cfg.scan_surface == 0)
+            hipLaunchKernelGGL((rover_step_scan1_kernel<true>), dim3(sim->step_blocks), dim3(RV_K1G_THREADS), lds, st, p, sim->state, action, obs,
+                               reward, terminated, truncated, force, sim->log_partial, sim->ray_xy);
+        else
+            hipLaunchKernelGGL((rover_step_scan1_kernel<false>), dim3(sim->step_blocks), dim3(RV_K1G_THREADS), lds, st, p, sim->state, action, obs,
+                               reward, terminated, truncated, force, sim->log_partial, sim->ray_xy);
+        if (mid) (void)hipEventRecord(mid, st);
+        if (!sim->log_deferred)
+            hipLaunchKernelGGL(rover_log_kernel, dim3(1), dim3(1024), 0, st, p, sim->log_partial, sim->n_waves, log);
+        return;
+    }
+    if (form == 1) {
         MarkerRange k1(sim, "rover_step_scan_kernel");
         const size_t lds = fused_lds_bytes(sim);
         // The limit is a property of the kernel (per device), shared by every handle of the process: only ever RAISE it -- a handle
@@ -3198,6 +3296,7 @@ int rover_create(const rover_config *cfg, int32_t num_envs, int32_t env_id_offse
     s->ws_bytes = (((s->ws_log_floats + (size_t)num_envs * 8) * sizeof(float) + 127) & ~(size_t)127) + 1024 * sizeof(float2) + 128;
     s->ray_xy = nullptr;
     s->fused = -1;
+    s->single_tile_ok = true;
     s->log_deferred = false;
     *out = s;
     return ROVER_OK;
@@ -3421,8 +3520,10 @@ int rover_kernel_names(const rover_sim *sim, char *step_kernel, char *scan_kerne
     // and of profiles/hbm_traffic.json.
     if (!sim || !step_kernel || !scan_kernel || cap < 8) return fail(ROVER_ERR_INVALID, "bad argument");
     if (!sim->have_terrain) return fail(ROVER_ERR_STATE, "rover_set_terrain has not been called");
+    refresh_mapping(const_cast<rover_sim *>(sim));
     if (fused_step(sim)) {   // one launch: the scan is the last phase of the step kernel; the second name is the log reduction's
-        snprintf(step_kernel, cap, "rover_step_scan_kernel<%s>", sim->p.cfg.scan_surface == 0 ? "true" : "false");
+        snprintf(step_kernel, cap, "%s<%s>", fused_form(sim) == 2 ? "rover_step_scan1_kernel" : "rover_step_scan_kernel",
+                 sim->p.cfg.scan_surface == 0 ? "true" : "false");
         snprintf(scan_kernel, cap, "%s", sim->log_deferred ? "" : "rover_log_kernel");
         return ROVER_OK;
     }
@@ -3535,10 +3636,10 @@ int rover_debug_set_scan_form(rover_sim *sim, int form)
     sim->scan_form = form;
     return ROVER_OK;
 }
-// measurement hook: -1 = automatic, 0 = two launches per step, 1 = one launch wherever the fused kernel can run
+// measurement hook: -1 = automatic, 0 = two launches per step, 1 / 2 = one launch (copy-wave form / single-tile form) wherever it can run
 int rover_debug_set_fused(rover_sim *sim, int fused)
 {
-    if (!sim || fused < -1 || fused > 1) return ROVER_ERR_INVALID;
+    if (!sim || fused < -1 || fused > 2) return ROVER_ERR_INVALID;   // 2 = the single-tile form (no copy waves)
     sim->fused = fused;
     return ROVER_OK;
 }

@@ -25,6 +25,9 @@ def make_env(n, ter, **over):
     cfg.terrain.kind = "custom"
     if over.get("step_mapping") == "group2":     # the group mapping as TWO launches (log reduced behind every step by the scan kernel)
         over = dict(over, step_mapping="group", log_reduction="every_step")
+    fused_form = 2 if over.get("step_mapping") == "group1" else 1   # "group1": one launch, single-tile form (no copy waves)
+    if over.get("step_mapping") == "group1":
+        over = dict(over, step_mapping="group")
     for k, v in over.items():
         setattr(cfg, k, v)
     if ter.spawn_locations is None or ter.spawn_locations.shape[0] != 2 * (cfg.global_num_envs or n):
@@ -35,7 +38,7 @@ def make_env(n, ter, **over):
         import ctypes as C
         fn = C.CDLL(env._lib._name).rover_debug_set_fused
         fn.argtypes = [C.c_void_p, C.c_int]
-        assert fn(env._h, 1) == 0
+        assert fn(env._h, fused_form) == 0
     return env
 
 
@@ -222,7 +225,8 @@ def test_reset_matches_oracle(oracle):
 # ------------------------------------------------------------------------------------------------ physics
 # one env per lane | sixteen lanes per env, ONE launch per step (height scan = last phase of the step kernel, log on demand: the
 # product form up to 4096 envs) | sixteen lanes per env, two launches: all must reproduce the oracle bit for bit
-MAPPINGS = ["lane", "group", "group2"]
+# | sixteen lanes per env, one launch, one tile per wave and no copy waves (the product form above 4096 envs per GPU)
+MAPPINGS = ["lane", "group", "group2", "group1"]
 
 
 @pytest.mark.parametrize("mapping", MAPPINGS)
@@ -506,7 +510,7 @@ def test_boundary_surface():
 
 
 @pytest.mark.parametrize("mapping,reset_velocities", [("lane", "reference"), ("group", "reference"), ("group", "zero"),
-                                                     ("lane", "zero")])
+                                                     ("lane", "zero"), ("group1", "reference"), ("group2", "zero")])
 def test_timeout_truncation_and_success(oracle, mapping, reset_velocities):
     """Force the time-out and the success branches (rare in random rollouts) and compare with the oracle."""
     ter = small_procedural()
@@ -647,10 +651,18 @@ def test_kernel_names_markers_and_spawn_table_check():
     env.close()
     # the product's own choice: one launch while one round of workgroups holds the batch and fills at least half the chip
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    for n_envs, fused in ((8 * cus - 16, False), (8 * cus, True), (16 * cus, True), (16 * cus + 16, False)):
+    for n_envs, name in ((8 * cus - 16, "rover_step_kernel_group"), (8 * cus, "rover_step_scan_kernel<true>"),
+                         (16 * cus, "rover_step_scan_kernel<true>"), (16 * cus + 16, "rover_step_scan1_kernel<true>")):
         env = make_env(n_envs, ter)
-        assert env.kernel_names()[0].startswith("rover_step_scan_kernel") == fused, (n_envs, env.kernel_names())
+        assert env.kernel_names()[0] == name, (n_envs, env.kernel_names())
         env.close()
+    # the automatic mapping at 32768 envs and more: sixteen lanes per env when that is one launch, else one env per lane
+    env = make_env(32768, ter)
+    assert env.kernel_names() == ("rover_step_scan1_kernel<true>", "")
+    env.close()
+    env = make_env(32768, ter, log_reduction="every_step")
+    assert env.kernel_names()[0] == "rover_step_kernel"
+    env.close()
     env = make_env(16 * cus, ter, log_reduction="every_step")                # ... and only with the log reduced on demand
     assert env.kernel_names()[0] == "rover_step_kernel_group"
     env.set_markers(True)

@@ -15,6 +15,9 @@ def make(mode):
     cfg = RoverEnvCfg(); cfg.scene.num_envs = n; cfg.terrain.kind = "custom"; cfg.step_mapping = "group"; cfg.log_reduction = mode
     env = RoverEnv(cfg, terrain=ter); env.reset(); return env
 a, b = make("every_step"), make("on_demand")
+if os.environ.get("FUSED_FORM"):      # 1 = copy-wave form, 2 = single-tile form, whatever the batch size
+    ff = C.CDLL(b._lib._name).rover_debug_set_fused; ff.argtypes = [C.c_void_p, C.c_int]
+    assert ff(b._h, int(os.environ["FUSED_FORM"])) == 0
 print(a.kernel_names(), b.kernel_names(), flush=True)
 g = torch.Generator(device="cuda").manual_seed(0)
 acts = torch.rand(64, n, 2, device="cuda", generator=g) * 2 - 1

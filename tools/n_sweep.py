@@ -12,10 +12,12 @@ if os.environ.get("ABLTAG"):
     _lib.LIB_PATH = os.path.join(ROOT, "build", "abl", f"librover_abl{os.environ['ABLTAG']}.so")
 ter = T.make_procedural_terrain((2048, 2048))
 out = []
-# mapping: group = the product's choice for the group mapping (one launch per step while one round of workgroups holds the batch),
-# group2 = the group mapping as two launches (log reduced behind every step), groupf = one launch forced beyond that batch size
-CASES = [(1024, "group"), (1024, "group2"), (4096, "group"), (4096, "group2"), (4096, "lane"), (8192, "group"), (8192, "groupf"),
-         (16384, "group"), (16384, "groupf"), (32768, "group"), (32768, "lane"), (65536, "group"), (65536, "lane"), (131072, "group"),
+# mapping: auto = the product's choice (mapping and launch form),
+# group2 = the group mapping as two launches (log reduced behind every step), groupf / group1 = one launch forced beyond that
+# batch size: the copy-wave form / the single-tile form (no copy waves, two workgroups per CU)
+CASES = [(1024, "auto"), (1024, "group1"), (2048, "auto"), (2048, "group2"), (4096, "auto"), (4096, "group1"), (4096, "group2"),
+         (4096, "lane"), (8192, "auto"), (8192, "groupf"), (8192, "group2"), (16384, "auto"), (16384, "group2"), (32768, "auto"),
+         (32768, "group2"), (32768, "lane"), (65536, "auto"), (65536, "group2"), (65536, "lane"), (131072, "auto"), (131072, "group2"),
          (131072, "lane")]
 if len(sys.argv) > 1:   # e.g. 1024:group 2048:group:wave  (third field: scan kernel of the step path, auto | generic | epi1)
     CASES = [tuple(a.split(":")) for a in sys.argv[1:]]
@@ -24,13 +26,13 @@ FORMS = {"auto": 0, "generic": 1, "epi1": 2, "blocks": 3, "lines": 4}   # blocks
 for case in CASES:
     n, mapping, form = int(case[0]), case[1], (case[2] if len(case) > 2 else "auto")
     ter.make_spawns(2 * n)
-    cfg = RoverEnvCfg(); cfg.scene.num_envs = n; cfg.terrain.kind = "custom"; cfg.step_mapping = "group" if mapping.startswith("group") else mapping
+    cfg = RoverEnvCfg(); cfg.scene.num_envs = n; cfg.terrain.kind = "custom"; cfg.step_mapping = "group" if mapping.startswith("group") else mapping   # "auto" = the product's own choice
     if mapping == "group2":
         cfg.log_reduction = "every_step"
     env = RoverEnv(cfg, terrain=ter)
-    if mapping == "groupf":
+    if mapping in ("groupf", "group1"):      # one launch forced: copy-wave form / single-tile form
         ff = C.CDLL(env._lib._name).rover_debug_set_fused; ff.argtypes = [C.c_void_p, C.c_int]
-        assert ff(env._h, 1) == 0
+        assert ff(env._h, 1 if mapping == "groupf" else 2) == 0
     fn = C.CDLL(env._lib._name).rover_debug_set_scan_form
     fn.argtypes = [C.c_void_p, C.c_int]
     assert fn(env._h, FORMS[form]) == 0
