@@ -19,7 +19,7 @@ def make(fused):
     assert fn(env._h, fused) == 0
     env.reset()
     return env
-a, b = make(0), make(1)
+a, b = make(0), make(int(os.environ.get("FUSED_FORM", "1")))      # 1 = copy-wave form, 2 = single-tile form
 print(a.kernel_names(), b.kernel_names())
 g = torch.Generator(device="cuda").manual_seed(0)
 acts = torch.rand(16, n, 2, device="cuda", generator=g) * 2 - 1
