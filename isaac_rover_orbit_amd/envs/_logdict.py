@@ -30,3 +30,15 @@ class LogDict(dict):
     def copy(self):
         self._env.flush_log()
         return dict(super().items())
+
+    # copies and pickles are plain dicts of the current values: they must not drag the env (a native handle) along
+    def __copy__(self):
+        return self.copy()
+
+    def __deepcopy__(self, memo):
+        self._env.flush_log()
+        return {k: v.clone() for k, v in super().items()}
+
+    def __reduce__(self):
+        self._env.flush_log()
+        return (dict, (dict(super().items()),))
