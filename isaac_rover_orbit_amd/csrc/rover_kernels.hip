@@ -1878,7 +1878,7 @@ __device__ __forceinline__ void scan_single_tile_wave(const RvParams &p, int16_t
 // nothing else meanwhile (2.5 k cycles per window, measured with a stamp that does not wait), so the four step waves of a
 // workgroup are paired with four copy waves (waves 4..7, one per SIMD, asleep at a barrier during the physics): copy wave k + 4
 // stages the windows of step wave k -- the first two under k's manager tail, the third and fourth under k's rays.
-// The copy wave also casts: rounds 8..15 of envs 0 and 3 (nothing to stage beside them), 12..15 of envs 1 and 2.
+// The copy wave also casts: rounds 10..15 of envs 0 and 3 (nothing to stage beside them).
 // Windows travel through LDS (win[wave][set][env][8 words]: set 0 = after the physics, set 1 = final); SIX workgroup barriers,
 // executed by all eight waves on every path (B2 right after B: the step wave has restaged windows 0, 1 if one of its envs reset):
 //   A  set 0 written            | copy: stage windows 0, 1 (set 0), wait        | step: manager tail, set 1, ray table
@@ -1905,12 +1905,13 @@ __device__ __forceinline__ void windows_from_lds(const float *win, PrivateWindow
         w.pk[j] = __builtin_amdgcn_readfirstlane(__float_as_int(d1.w));
     }
 }
-// rounds of an env's sixteen cast by the step wave; the copy wave takes the rest (it also has a window to stage under envs 1, 2)
+// rounds of an env's sixteen cast by the step wave; the copy wave takes the rest -- of envs 0 and 3 only: beside envs 1 and 2 it
+// has a window to stage (tools/r03_share.sh: 10 / 16 39.6 us per step, 8 / 12 40.1, no sharing 40.9)
 #ifndef RV_SHARE_FREE
-#define RV_SHARE_FREE 8
+#define RV_SHARE_FREE 10
 #endif
 #ifndef RV_SHARE_COPY
-#define RV_SHARE_COPY 12
+#define RV_SHARE_COPY 16
 #endif
 constexpr int SHARE_FREE = RV_SHARE_FREE, SHARE_COPY = RV_SHARE_COPY;
 template <bool TRI>

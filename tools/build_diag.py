@@ -35,7 +35,10 @@ VARIANTS = {"STAMP": ("rover_kernels.hip", "-DRV_K2_STAMP"), "K1STAMP": ("rover_
             "SHARE_8_16": ("rover_kernels.hip", "-DRV_SHARE_FREE=8 -DRV_SHARE_COPY=16"),
             "SHARE_7_14": ("rover_kernels.hip", "-DRV_SHARE_FREE=7 -DRV_SHARE_COPY=14"),
             "SHARE_6_13": ("rover_kernels.hip", "-DRV_SHARE_FREE=6 -DRV_SHARE_COPY=13"),
-            "SHARE_16_16": ("rover_kernels.hip", "-DRV_SHARE_FREE=16 -DRV_SHARE_COPY=16")}
+            "SHARE_16_16": ("rover_kernels.hip", "-DRV_SHARE_FREE=16 -DRV_SHARE_COPY=16"),
+            "SHARE_6_16": ("rover_kernels.hip", "-DRV_SHARE_FREE=6 -DRV_SHARE_COPY=16"),
+            "SHARE_10_16": ("rover_kernels.hip", "-DRV_SHARE_FREE=10 -DRV_SHARE_COPY=16"),
+            "SHARE_12_16": ("rover_kernels.hip", "-DRV_SHARE_FREE=12 -DRV_SHARE_COPY=16")}
 
 
 def main():
