@@ -1798,17 +1798,15 @@ __device__ __forceinline__ void private_cast(const RvParams &p, const PrivateWin
 template <bool TRI>
 __device__ __forceinline__ void scan_private_wave(const RvParams &p, int16_t *tile0, int16_t *tile1, int lane, int n_env, int e_base,
                                                   const PrivateWindows &w, float *__restrict__ out, int row_stride, int col0,
-                                                  const float2 *__restrict__ ray_xy, bool issued01 = false)
+                                                  const float2 *__restrict__ ray_xy)
 {
     constexpr int ROUNDS = PRIVATE_ROUNDS;
     auto issue = [&](int j, int16_t *tile) { private_issue(p, w, j, tile, lane); };
     float ox[ROUNDS], oy[ROUNDS];
     auto cast = [&](int j, const int16_t *tile) { private_cast<TRI>(p, w, j, tile, lane, e_base, out, row_stride, col0, ox, oy, ray_xy); };
     if (n_env <= 0) return;
-    if (!issued01) {   // (the fused step kernel stages the first two windows before its manager tail)
-        issue(0, tile0);
-        if (n_env > 1) issue(1, tile1);
-    }
+    issue(0, tile0);
+    if (n_env > 1) issue(1, tile1);
 #pragma unroll
     for (int m = 0; m < ROUNDS; ++m) {
         const float2 v = ray_xy[m * 64 + lane];
