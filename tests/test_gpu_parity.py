@@ -438,6 +438,22 @@ def test_scan_step_kernel_forms(oracle, quantize, res, grid_m, n):
     env.close()
 
 
+def test_private_scan_kernel_measurement_form(oracle):
+    """rover_debug_set_scan_form(sim, 7): the wave-private scan (the scan phase of the one-launch kernels) as a kernel of its own
+    behind the group-mapped step kernel -- a measurement form, kept honest: closed loop against the oracle, ragged batch."""
+    import ctypes as C
+    ter = small_procedural()
+    n = 203
+    env = make_env(n, ter, seed=8, step_mapping="group2")
+    fn = C.CDLL(env._lib._name).rover_debug_set_scan_form
+    fn.argtypes = [C.c_void_p, C.c_int]
+    assert fn(env._h, 7) == 0
+    rng = np.random.RandomState(4)
+    actions = rng.uniform(-1, 1, (10, n, 2)).astype(np.float32)
+    assert rollout_compare(oracle, env, 10, actions, 0.0, 0.0, resync=False) == 0
+    env.close()
+
+
 def test_sharding_invariance_gpu(oracle):
     """Two shards with env_id_offset reproduce the corresponding rows of one big env (RNG keyed by global id)."""
     ter = small_procedural()
