@@ -1713,7 +1713,7 @@ __device__ __forceinline__ void private_issue(const RvParams &p, const PrivateWi
     typedef float v4f __attribute__((ext_vector_type(4)));
     const int16_t *hsrc = p.height_q;
     const int th = w.pk[j] & 0x7FFF, tw4 = max(w.pk[j] >> 16, 1);
-    const int rpi = 64 / tw4;                                          // wave-uniform
+    const int rpi = max(64 / tw4, 1);                                  // wave-uniform (tw4 <= 64: checked by the host; never 0: no endless loop)
     const int lr = (int)(((float)lane + 0.5f) * (1.0f / (float)tw4));  // lane / tw4, exact
     const int lc = lane - (int)__umul24(lr, tw4);
     const v4f *src = reinterpret_cast<const v4f *>(hsrc + (size_t)w.i_lo[j] * p.W + w.j_lo[j]) + (size_t)(__umul24(lr, p.wq) + lc);
@@ -3043,6 +3043,7 @@ static int fused_form(const rover_sim *sim)
     if (sim->fused == 0 || !sim->group_mapping || sim->scan_form != 0) return 0;
     const ScanForm f = scan_form_of(sim, 2);
     if (!f.simple || !f.q16 || sim->p.rays > 1024 || sim->p.ray_blocks) return 0;
+    if (sim->p.tile_pitch / 8 > 64) return 0;   // private_issue stages whole rows per instruction: a row must fit a wave's 64 lanes
     const bool fits1 = fused_lds_bytes(sim) <= 160 * 1024, fits2 = 2 * single_tile_lds_bytes(sim) <= 160 * 1024;
     if (sim->fused == 1) return fits1 ? 1 : 0;        // measurement hooks: force a form wherever its tiles fit
     if (sim->fused == 2) return fits2 ? 2 : 0;
