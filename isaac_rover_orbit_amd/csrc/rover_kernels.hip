@@ -2976,6 +2976,7 @@ struct rover_sim {
     int scan_form;     // measurement hook: 1 = the generic scan kernel on the step path too
     bool markers;      // roctx ranges around the launches of rover_step (rover_set_markers)
     uint32_t log_serial; // tag of the log-partial rows of the launch under way
+    size_t max_lds;      // LDS a workgroup may allocate on this device (hipDeviceAttributeMaxSharedMemoryPerBlock)
     int fused;           // one launch per step (rover_step_scan_kernel): -1 = decide (group mapping, int16 terrain copy, <= 1024 rays,
                          // the four waves' eight tiles fit the LDS, one workgroup per CU holds the batch), 0 = off, 1 = on where possible
     bool single_tile_ok; // the single-tile one-launch form may be chosen automatically beyond one round of workgroups (measured: see fused_form)
@@ -3044,7 +3045,8 @@ static int fused_form(const rover_sim *sim)
     const ScanForm f = scan_form_of(sim, 2);
     if (!f.simple || !f.q16 || sim->p.rays > 1024 || sim->p.ray_blocks) return 0;
     if (sim->p.tile_pitch / 8 > 64) return 0;   // private_issue stages whole rows per instruction: a row must fit a wave's 64 lanes
-    const bool fits1 = fused_lds_bytes(sim) <= 160 * 1024, fits2 = 2 * single_tile_lds_bytes(sim) <= 160 * 1024;
+    // (the device's own limit: 160 KiB per workgroup on gfx950)
+    const bool fits1 = fused_lds_bytes(sim) <= sim->max_lds, fits2 = 2 * single_tile_lds_bytes(sim) <= sim->max_lds;
     if (sim->fused == 1) return fits1 ? 1 : 0;        // measurement hooks: force a form wherever its tiles fit
     if (sim->fused == 2) return fits2 ? 2 : 0;
     // without the on-demand log reduction the one launch would need a second one after all (4 us behind the boundary)
@@ -3282,6 +3284,9 @@ int rover_create(const rover_config *cfg, int32_t num_envs, int32_t env_id_offse
         int n_cu = 0;
         if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n_cu <= 0) n_cu = 256;
         s->n_cu = n_cu;
+        int lds = 0;
+        if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess || lds <= 0) lds = 64 * 1024;
+        s->max_lds = (size_t)lds;
     }
     if (cfg->step_mapping < 0 || cfg->step_mapping > 2) { delete s; return fail(ROVER_ERR_INVALID, "step_mapping must be 0, 1 or 2"); }
     // latency mapping (16 lanes per env) while one-env-per-lane would leave most SIMDs without a wave
