@@ -1134,7 +1134,9 @@ __device__ __forceinline__ void solver_iterations_group(const StepConsts &K, Con
 #endif
 }
 
-template <bool RECORD_FORCE>
+// LINK_ELSEWHERE: the lane's link-body sample point is evaluated by the lane's twin in the copy wave (one-launch kernel): Fw[3]
+// is left alone here.
+template <bool RECORD_FORCE, bool LINK_ELSEWHERE = false>
 __device__ __forceinline__ void physics_substep_group(const RvParams &p, const StepConsts &K, GroupLane &g,
                                                       float *Fw /* 3: this wheel's force, [3]: this lane's link-point force */,
                                                       int sidx = 0)
@@ -1159,9 +1161,9 @@ __device__ __forceinline__ void physics_substep_group(const RvParams &p, const S
     const bool at_hi = bq >= RV_BOGIE_QLIM - 1.0e-5f, at_lo = bq <= -RV_BOGIE_QLIM + 1.0e-5f;
     Contact ct;
     LinkSample ls;
-    if (RECORD_FORCE) ls = link_point_fetch(p, R, g.pos, g.P, g.ax, bq, g.lp);      // pose of the substep's start, like the wheel rows
+    if (RECORD_FORCE && !LINK_ELSEWHERE) ls = link_point_fetch(p, R, g.pos, g.P, g.ax, bq, g.lp);      // pose of the substep's start, like the wheel rows
     wheel_geometry<RECORD_FORCE, true>(p, K, R, g.pos, com_w, g.arm, g.P, g.ax, g.b_winv, bq, at_hi, at_lo, g.steerable, g.sq, ct, g.role_b);
-    if (RECORD_FORCE) Fw[3] = link_point_eval(ls);
+    if (RECORD_FORCE && !LINK_ELSEWHERE) Fw[3] = link_point_eval(ls);
     K1_STAMP(3 + 3 * sidx);
     ct.ln = RV_WARM_START * g.lam;
     ct.lt = 0.0f;
@@ -1877,7 +1879,7 @@ __device__ __forceinline__ void scan_single_tile_wave(const RvParams &p, int16_t
 // workgroup are paired with four copy waves (waves 4..7, one per SIMD, asleep at a barrier during the physics): copy wave k + 4
 // stages the windows of step wave k -- the first two under k's manager tail, the third and fourth under k's rays.
 // The copy wave also casts: rounds 10..15 of envs 0 and 3 (nothing to stage beside them).
-// Windows travel through LDS (win[wave][set][env][8 words]: set 0 = after the physics, set 1 = final); SIX workgroup barriers,
+// Windows travel through LDS (win[wave][set][env][8 words]: set 0 = after the physics, set 1 = final); SEVEN workgroup barriers (L in front of the last substep, see step_group_body; then)
 // executed by all eight waves on every path (B2 right after B: the step wave has restaged windows 0, 1 if one of its envs reset):
 //   A  set 0 written            | copy: stage windows 0, 1 (set 0), wait        | step: manager tail, set 1, ray table
 //   B  windows 0, 1 landed, set 1 written                                        | step: (reset in the wave: restage 0, 1 itself) rays of env 0
@@ -1903,6 +1905,14 @@ __device__ __forceinline__ void windows_from_lds(const float *win, PrivateWindow
         w.pk[j] = __builtin_amdgcn_readfirstlane(__float_as_int(d1.w));
     }
 }
+// LDS of the copy-wave form behind the eight tiles: windows [4 waves][2 sets][4 envs][8] floats (1 KB), then per step wave 192
+// floats of link-point hand-over: [0, 48) rotation matrix + position of its four envs at the START of the last substep,
+// [64, 128) the bogie angle of every lane, [128, 192) the lane's link-point force, written by its twin in the copy wave.
+__device__ __forceinline__ float *fused_win(float *lds, const RvParams &p, int wv)
+{
+    return reinterpret_cast<float *>(reinterpret_cast<int16_t *>(lds) + (size_t)8 * p.tile_dim * p.tile_pitch) + wv * 64;
+}
+__device__ __forceinline__ float *fused_link(float *lds, const RvParams &p, int wv) { return fused_win(lds, p, 0) + 256 + wv * 192; }
 // rounds of an env's sixteen cast by the step wave; the copy wave takes the rest -- of envs 0 and 3 only: beside envs 1 and 2 it
 // has a window to stage (tools/r03_share.sh: 10 / 16 39.6 us per step, 8 / 12 40.1, no sharing 40.9)
 #ifndef RV_SHARE_FREE
@@ -1918,10 +1928,26 @@ __device__ __forceinline__ void scan_copy_wave(const RvParams &p, float *lds, in
 {
     const int tile_cells = p.tile_dim * p.tile_pitch;
     int16_t *tile0 = reinterpret_cast<int16_t *>(lds) + (size_t)(2 * partner) * tile_cells, *tile1 = tile0 + tile_cells;
-    const float *win = reinterpret_cast<const float *>(reinterpret_cast<int16_t *>(lds) + (size_t)8 * tile_cells) + partner * 64;
+    const float *win = fused_win(lds, p, partner);
     const int e_base = (int)(blockIdx.x * 4 + partner) * 4;
     const int n_env = max(0, min(4, p.n - e_base));
     PrivateWindows w;
+    {   // L: the step wave has left the pose of the last substep's start; this lane evaluates the link-body sample point of its
+        // twin (same slot, same role: same constants, same arithmetic -- link_point_fetch / link_point_eval) while the twin solves
+        __syncthreads();                                                // L
+        const float *lk = fused_link(lds, p, partner);
+        const SlotConst sc = d_SLOT[lane & 7];
+        const bool role_b = (lane & 8) != 0;
+        const float *pe = lk + (lane >> 4) * 12;
+        const float R[3][3] = {{pe[0], pe[1], pe[2]}, {pe[3], pe[4], pe[5]}, {pe[6], pe[7], pe[8]}};
+        const float pos[3] = {pe[9], pe[10], pe[11]};
+        const float P[3] = {sc.P[0], sc.P[1], sc.P[2]}, ax[3] = {sc.ax[0], sc.ax[1], sc.ax[2]};
+        float lp[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) lp[i] = role_b ? sc.lp[1][i] : sc.lp[0][i];
+        const float force = link_point_eval(link_point_fetch(p, R, pos, P, ax, lk[64 + lane], lp));
+        const_cast<float *>(lk)[128 + lane] = force;
+    }
     __syncthreads();                                                    // A
     windows_from_lds(win, w);
     if (n_env > 0) private_issue(p, w, 0, tile0, lane);
@@ -2020,16 +2046,32 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
     float Fw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     K1_STAMP(1);
     for (int s = 0; s < c.decimation - 1; ++s) physics_substep_group<false>(p, K, g, nullptr, s);
-    if (c.decimation > 0) physics_substep_group<true>(p, K, g, Fw, c.decimation - 1);
+    if constexpr (FUSE == 1 || FUSE == 2) {
+        // copy-wave form: the link-body sample points of the contact report (evaluated at the pose of the last substep's START)
+        // are the copy wave's work -- it is asleep until now; this wave goes straight into the substep
+        const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        float *lk = fused_link(lds, p, wv);
+        if ((lane & 15) == 0) {
+            float4 *d = reinterpret_cast<float4 *>(lk + (lane >> 4) * 12);
+            d[0] = make_float4(g.R[0][0], g.R[0][1], g.R[0][2], g.R[1][0]);
+            d[1] = make_float4(g.R[1][1], g.R[1][2], g.R[2][0], g.R[2][1]);
+            d[2] = make_float4(g.R[2][2], g.pos[0], g.pos[1], g.pos[2]);
+        }
+        lk[64 + lane] = g.bq;
+        __syncthreads();                                                // L
+        if (c.decimation > 0) physics_substep_group<true, true>(p, K, g, Fw, c.decimation - 1);
+    } else {
+        if (c.decimation > 0) physics_substep_group<true>(p, K, g, Fw, c.decimation - 1);
+    }
     K1_STAMP(20);
-    if (!id.wheel_active) { Fw[0] = 0.0f; Fw[1] = 0.0f; Fw[2] = 0.0f; Fw[3] = 0.0f; }
-    if (active) group_store(state, N, e, id, g);
     if constexpr (FUSE == 1 || FUSE == 2) {   // the physics has fixed the pose (unless the env resets below): its windows go to the copy wave
         const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-        float *win = reinterpret_cast<float *>(reinterpret_cast<int16_t *>(lds) + (size_t)8 * p.tile_dim * p.tile_pitch) + wv * 64;
-        windows_to_lds(win, scan_window(p, g.pos, g.quat), lane);
+        windows_to_lds(fused_win(lds, p, wv), scan_window(p, g.pos, g.quat), lane);
         __syncthreads();                                                // A
+        if (c.decimation > 0) Fw[3] = fused_link(lds, p, wv)[128 + lane];
     }
+    if (!id.wheel_active) { Fw[0] = 0.0f; Fw[1] = 0.0f; Fw[2] = 0.0f; Fw[3] = 0.0f; }
+    if (active) group_store(state, N, e, id, g);
     // contact report: gather the six Drive-body forces and the twelve link-point forces of the env (sensor body order) into
     // every lane -- only in waves where some body touches the obstacle layer (otherwise every force is the +0 the array holds)
     float F[ROVER_NUM_BODIES * 3];
@@ -2189,7 +2231,7 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
         const int tile_cells = p.tile_dim * p.tile_pitch;
         const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         int16_t *tile0 = reinterpret_cast<int16_t *>(lds) + (size_t)(2 * wv) * tile_cells, *tile1 = tile0 + tile_cells;
-        float *win = reinterpret_cast<float *>(reinterpret_cast<int16_t *>(lds) + (size_t)8 * tile_cells) + wv * 64;
+        float *win = fused_win(lds, p, wv);
         const int n_scan = max(0, min(4, p.n - wave * 4));
         const int e_base = wave * 4;
         PrivateWindows pw;
@@ -3036,8 +3078,8 @@ static ScanForm scan_form_of(const rover_sim *sim, int mode)
 
 // Does rover_step run as ONE launch (rover_step_scan_kernel: the scan is the last phase of the step kernel's waves)?
 static size_t single_tile_lds_bytes(const rover_sim *sim) { return (size_t)(RV_K1G_THREADS / 64) * (size_t)sim->p.tile_dim * sim->p.tile_pitch * 2; }
-// eight tiles (two per step wave) + the windows' hand-over area (4 waves x 2 sets x 4 envs x 32 B)
-static size_t fused_lds_bytes(const rover_sim *sim) { return (size_t)(RV_K1G_THREADS / 64) * 2 * (size_t)sim->p.tile_dim * sim->p.tile_pitch * 2 + 1024; }
+// eight tiles (two per step wave) + the windows' hand-over area (4 waves x 2 sets x 4 envs x 32 B) + the link points' (4 x 768 B)
+static size_t fused_lds_bytes(const rover_sim *sim) { return (size_t)(RV_K1G_THREADS / 64) * 2 * (size_t)sim->p.tile_dim * sim->p.tile_pitch * 2 + 1024 + 4 * 192 * sizeof(float); }
 // 0 = two launches, 1 = one launch with copy waves (one workgroup per CU), 2 = one launch, one tile per wave (two workgroups per CU)
 static int fused_form(const rover_sim *sim)
 {
