@@ -1878,10 +1878,12 @@ __device__ __forceinline__ void scan_single_tile_wave(const RvParams &p, int16_t
 // nothing else meanwhile (2.5 k cycles per window, measured with a stamp that does not wait), so the four step waves of a
 // workgroup are paired with four copy waves (waves 4..7, one per SIMD, asleep at a barrier during the physics): copy wave k + 4
 // stages the windows of step wave k -- the first two under k's manager tail, the third and fourth under k's rays.
-// The copy wave also casts: rounds 10..15 of envs 0 and 3 (nothing to stage beside them).
-// Windows travel through LDS (win[wave][set][env][8 words]: set 0 = after the physics, set 1 = final); SEVEN workgroup barriers (L in front of the last substep, see step_group_body; then)
+// The copy wave also casts (rounds 10..15 of envs 0 and 3: nothing to stage beside them) and, during the LAST substep, evaluates
+// the link-body sample points of the contact report for its twin lanes.
+// Windows travel through LDS (win[wave][set][env][8 words]: set 0 = after the physics, set 1 = final); SEVEN workgroup barriers,
 // executed by all eight waves on every path (B2 right after B: the step wave has restaged windows 0, 1 if one of its envs reset):
-//   A  set 0 written            | copy: stage windows 0, 1 (set 0), wait        | step: manager tail, set 1, ray table
+//   L  pose + bogie angles of the last substep's start written | copy: link-point forces | step: the last substep
+//   A  set 0 written, link forces written | copy: stage windows 0, 1 (set 0), wait | step: manager tail, set 1, ray table
 //   B  windows 0, 1 landed, set 1 written                                        | step: (reset in the wave: restage 0, 1 itself) rays of env 0
 //   C  tile 0 free              | copy: stage window 2 (set 1) into tile 0, wait | step: rays of env 1
 //   D  window 2 landed, tile 1 free | copy: stage window 3 into tile 1, wait     | step: rays of env 2
