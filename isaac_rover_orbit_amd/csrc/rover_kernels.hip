@@ -582,6 +582,12 @@ __device__ __forceinline__ float link_point_eval(const LinkSample &s)
     const float pen = hgt - s.z;
     return (obst > RV_OBSTACLE_EPS && pen > 0.0f) ? RV_LINK_STIFFNESS * pen : 0.0f;
 }
+// the obstacle-layer height of a sample (terrain_sample<true>'s `obst`: same cell, same weights, same operations)
+__device__ __forceinline__ float link_sample_obstacle(const LinkSample &s)
+{
+    const float o0 = s.o00 + s.fx * (s.o01 - s.o00), o1 = s.o10 + s.fx * (s.o11 - s.o10);
+    return o0 + s.fy * (o1 - o0);
+}
 __device__ __forceinline__ float link_point_force(const RvParams &p, const float R[3][3], const float *pos, const float *P,
                                                   const float *ax, float bq, const float *p0)
 {
@@ -1134,7 +1140,9 @@ __device__ __forceinline__ void solver_iterations_group(const StepConsts &K, Con
 #endif
 }
 
-// LINK_ELSEWHERE: the lane's link-body sample point is evaluated by the lane's twin in the copy wave (one-launch kernel): Fw[3]
+// LINK_ELSEWHERE: the lane's link-body sample point AND the obstacle-layer height under its wheel are evaluated by the lane's twin
+// in the copy wave (one-launch kernel): no obstacle gathers here, Fw[0..2] hold the wheel's force unconditionally (the caller
+// zeroes them where the twin found no obstacle layer -- `on ? x : 0` either way), Fw[3]
 // is left alone here.
 template <bool RECORD_FORCE, bool LINK_ELSEWHERE = false>
 __device__ __forceinline__ void physics_substep_group(const RvParams &p, const StepConsts &K, GroupLane &g,
@@ -1162,7 +1170,7 @@ __device__ __forceinline__ void physics_substep_group(const RvParams &p, const S
     Contact ct;
     LinkSample ls;
     if (RECORD_FORCE && !LINK_ELSEWHERE) ls = link_point_fetch(p, R, g.pos, g.P, g.ax, bq, g.lp);      // pose of the substep's start, like the wheel rows
-    wheel_geometry<RECORD_FORCE, true>(p, K, R, g.pos, com_w, g.arm, g.P, g.ax, g.b_winv, bq, at_hi, at_lo, g.steerable, g.sq, ct, g.role_b);
+    wheel_geometry<RECORD_FORCE && !LINK_ELSEWHERE, true>(p, K, R, g.pos, com_w, g.arm, g.P, g.ax, g.b_winv, bq, at_hi, at_lo, g.steerable, g.sq, ct, g.role_b);
     if (RECORD_FORCE && !LINK_ELSEWHERE) Fw[3] = link_point_eval(ls);
     K1_STAMP(3 + 3 * sidx);
     ct.ln = RV_WARM_START * g.lam;
@@ -1203,7 +1211,7 @@ __device__ __forceinline__ void physics_substep_group(const RvParams &p, const S
     wheel_motor(K, g.wheel_t, ct.lt, g.wq, g.wqd);
     g.lam = ct.ln;
     if (RECORD_FORCE) {
-        const bool on = ct.obst > RV_OBSTACLE_EPS;
+        const bool on = LINK_ELSEWHERE ? true : ct.obst > RV_OBSTACLE_EPS;
 #pragma unroll
         for (int i = 0; i < 3; ++i) Fw[i] = on ? fmaf(ct.s[i], ct.ls, fmaf(ct.t[i], ct.lt, ct.n[i] * ct.ln)) * K.inv_h : 0.0f;
     }
@@ -1221,9 +1229,9 @@ struct ResetDraws {
     float heading_u;       // :93-95                 uniform_(lo, hi) = u * (hi - lo) + lo
 };
 
-// target on the 9 m circle with rejection on the safe rock mask (terrain_importer.py:134-175), heading ~ U(lo, hi)
-__device__ __forceinline__ void resample_command(const RvParams &p, float *S, uint32_t gid, uint32_t count, float heading_u,
-                                                 const float *inj_theta = nullptr)
+// target on the 9 m circle around (ox, oy) with rejection on the safe rock mask (terrain_importer.py:134-175)
+__device__ __forceinline__ void sample_target(const RvParams &p, float ox, float oy, uint32_t gid, uint32_t count, const float *inj_theta,
+                                              float &tx_out, float &ty_out, float &tz_out)
 {
     const rover_config &c = p.cfg;
     float tx = 0.0f, ty = 0.0f;
@@ -1240,8 +1248,8 @@ __device__ __forceinline__ void resample_command(const RvParams &p, float *S, ui
             u = u01(w == 0 ? r[0] : (w == 1 ? r[1] : (w == 2 ? r[2] : r[3])));
         }
         const float theta = u * 2.0f * RV_PI_F;
-        tx = rv_cosf(theta) * c.target_distance + S[ROVER_ENV_ORIGIN + 0];
-        ty = rv_sinf(theta) * c.target_distance + S[ROVER_ENV_ORIGIN + 1];
+        tx = rv_cosf(theta) * c.target_distance + ox;
+        ty = rv_sinf(theta) * c.target_distance + oy;
         int cx, cy;
         quirk_cell(p, tx, ty, cx, cy);
         ++tries;
@@ -1249,18 +1257,31 @@ __device__ __forceinline__ void resample_command(const RvParams &p, float *S, ui
     }
     int cx, cy;
     quirk_cell(p, tx, ty, cx, cy);
-    S[ROVER_TARGET_W + 0] = tx;
-    S[ROVER_TARGET_W + 1] = ty;
-    S[ROVER_TARGET_W + 2] = p.lookup[(size_t)cy * p.W + cx] + 0.0f;
+    tx_out = tx;
+    ty_out = ty;
+    tz_out = p.lookup[(size_t)cy * p.W + cx] + 0.0f;
+}
+// heading ~ U(lo, hi) (terrain_importer.py:93-95); TerrainBasedPositionCommand._resample_command
+__device__ __forceinline__ void resample_command(const RvParams &p, float *S, uint32_t gid, uint32_t count, float heading_u,
+                                                 const float *inj_theta = nullptr)
+{
+    const rover_config &c = p.cfg;
+    sample_target(p, S[ROVER_ENV_ORIGIN + 0], S[ROVER_ENV_ORIGIN + 1], gid, count, inj_theta, S[ROVER_TARGET_W + 0], S[ROVER_TARGET_W + 1],
+                  S[ROVER_TARGET_W + 2]);
     S[ROVER_HEADING_CMD_W] = heading_u * (c.heading_hi - c.heading_lo) + c.heading_lo;
     S[ROVER_TIME_LEFT] = c.resample_time;
 }
 
-// reset_root_state_rover (randomizations.py:12-39) + ORBIT manager resets (RLTaskEnv._reset_idx)
-__device__ __forceinline__ void reset_one(const RvParams &p, float *S, uint32_t gid, const ResetDraws *inj = nullptr)
+// reset_root_state_rover (randomizations.py:12-39) + ORBIT manager resets (RLTaskEnv._reset_idx), in two halves: everything
+// that is DRAWN or looked up (spawn row, yaw, target with its rejection loop, heading) depends on (global id, reset count) and
+// the terrain only -- not on the step under way -- so the one-launch kernel's copy wave evaluates it during the physics, for
+// every env, and the step wave's reset is the assignments of reset_apply (no Philox, no dependent loads on its path).
+struct ResetOutcome {
+    float px, py, pz, qw, qz, tx, ty, tz, heading_cmd;
+};
+__device__ __forceinline__ void reset_draw(const RvParams &p, uint32_t gid, uint32_t count, const ResetDraws *inj, ResetOutcome &o)
 {
     const rover_config &c = p.cfg;
-    const uint32_t count = __float_as_uint(S[ROVER_RESET_COUNT]);
     uint32_t r[4];
     philox4x32(gid, count, 0u, 0u, c.seed_lo, c.seed_hi, r);
     uint32_t row;
@@ -1268,13 +1289,24 @@ __device__ __forceinline__ void reset_one(const RvParams &p, float *S, uint32_t 
     else if (c.spawn_draw == 1)   // distinct rows inside one reset batch (randomizations.py:22: a randperm prefix)
         row = (uint32_t)(((uint64_t)p.spawn_a * (uint64_t)(gid % (uint32_t)p.n_spawns) + (uint64_t)p.spawn_b) % (uint64_t)p.n_spawns);
     else row = r[0] % (uint32_t)p.n_spawns;
-    const float px = p.spawns[3 * row + 0], py = p.spawns[3 * row + 1];
-    const float pz = p.spawns[3 * row + 2] + c.reset_z_offset;
+    o.px = p.spawns[3 * row + 0];
+    o.py = p.spawns[3 * row + 1];
+    o.pz = p.spawns[3 * row + 2] + c.reset_z_offset;
     const float angle = (inj ? inj->yaw_u : u01(r[1])) * 2.0f * RV_PI_F;
-    S[ROVER_POS + 0] = px; S[ROVER_POS + 1] = py; S[ROVER_POS + 2] = pz;
-    S[ROVER_QUAT + 0] = rv_cosf(angle / 2.0f); S[ROVER_QUAT + 1] = 0.0f; S[ROVER_QUAT + 2] = 0.0f;
-    S[ROVER_QUAT + 3] = rv_sinf(angle / 2.0f);
-    S[ROVER_ENV_ORIGIN + 0] = px; S[ROVER_ENV_ORIGIN + 1] = py; S[ROVER_ENV_ORIGIN + 2] = pz;
+    o.qw = rv_cosf(angle / 2.0f);
+    o.qz = rv_sinf(angle / 2.0f);
+    sample_target(p, o.px, o.py, gid, count, inj ? inj->theta_u : nullptr, o.tx, o.ty, o.tz);
+    const float heading_u = inj ? inj->heading_u : u01(r[2]);
+    o.heading_cmd = heading_u * (c.heading_hi - c.heading_lo) + c.heading_lo;
+}
+__device__ __forceinline__ void reset_apply(const RvParams &p, float *S, const ResetOutcome &o)
+{
+    const rover_config &c = p.cfg;
+    const uint32_t count = __float_as_uint(S[ROVER_RESET_COUNT]);
+    S[ROVER_POS + 0] = o.px; S[ROVER_POS + 1] = o.py; S[ROVER_POS + 2] = o.pz;
+    S[ROVER_QUAT + 0] = o.qw; S[ROVER_QUAT + 1] = 0.0f; S[ROVER_QUAT + 2] = 0.0f;
+    S[ROVER_QUAT + 3] = o.qz;
+    S[ROVER_ENV_ORIGIN + 0] = o.px; S[ROVER_ENV_ORIGIN + 1] = o.py; S[ROVER_ENV_ORIGIN + 2] = o.pz;
     if (c.reset_mode == 1) {
 #pragma unroll
         for (int i = ROVER_LINVEL; i < ROVER_TARGET_W; ++i) S[i] = 0.0f;
@@ -1287,9 +1319,17 @@ __device__ __forceinline__ void reset_one(const RvParams &p, float *S, uint32_t 
     for (int i = 0; i < ROVER_NUM_REW; ++i) S[ROVER_EP_SUM + i] = 0.0f;
     S[ROVER_METRIC_POS] = 0.0f;
     S[ROVER_METRIC_HEAD] = 0.0f;
-    resample_command(p, S, gid, count, inj ? inj->heading_u : u01(r[2]), inj ? inj->theta_u : nullptr);
+    S[ROVER_TARGET_W + 0] = o.tx; S[ROVER_TARGET_W + 1] = o.ty; S[ROVER_TARGET_W + 2] = o.tz;
+    S[ROVER_HEADING_CMD_W] = o.heading_cmd;
+    S[ROVER_TIME_LEFT] = c.resample_time;
     S[ROVER_EP_LEN] = __int_as_float(0);
     S[ROVER_RESET_COUNT] = __uint_as_float(count + 1u);
+}
+__device__ __forceinline__ void reset_one(const RvParams &p, float *S, uint32_t gid, const ResetDraws *inj = nullptr)
+{
+    ResetOutcome o;
+    reset_draw(p, gid, __float_as_uint(S[ROVER_RESET_COUNT]), inj, o);
+    reset_apply(p, S, o);
 }
 
 // CommandTerm.compute: metrics -> timer -> (resample) -> update (terrain_importer.py:97-106)
@@ -1708,28 +1748,52 @@ __device__ __forceinline__ float private_ray(const RvParams &p, const int16_t *t
     return pz - hgt - p.cfg.scan_height_offset;  // observations.py:45
 }
 // Window copy by ONE wave, whole rows per instruction: with tw4 chunks per row a global_load_lds moves rpi = 64 / tw4 rows
-// (lanes rpi * tw4 .. 63 idle); lane -> (row in the group, chunk in the row) is formed once per tile, an iteration costs one
-// 64-bit add, one compare and the load.  LDS chunk index of (row r, chunk c) = r * tw4 + c, as in the scan kernels.
+// (lanes rpi * tw4 .. 63 idle); lane -> (row in the group, chunk in the row) is formed once per tile.  LDS chunk index of
+// (row r, chunk c) = r * tw4 + c, as in the scan kernels.
+// The loop is written out: the execution mask is set ONCE (whole groups of rows: lanes with lr < rpi; the last, partial group:
+// lanes whose row exists), an iteration is the load, one v_add of the lanes' 32-bit byte offset, one s_add of M0 and the
+// compare-and-branch on M0 -- five instructions.  (hipcc's loop around the builtin took fifteen per load -- a mask and a branch
+// around every load, a 64-bit address add, M0 through a move and a nop -- and one wave per SIMD issues them one by one: 2.5 k
+// cycles per window, which round 3 read as the cost of the LDS-DMA instruction itself.)
 __device__ __forceinline__ void private_issue(const RvParams &p, const PrivateWindows &w, int j, int16_t *tile, int lane)
 {
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    const int16_t *hsrc = p.height_q;
     const int th = w.pk[j] & 0x7FFF, tw4 = max(w.pk[j] >> 16, 1);
-    const int rpi = max(64 / tw4, 1);                                  // wave-uniform (tw4 <= 64: checked by the host; never 0: no endless loop)
+    const int rpi = max(64 / tw4, 1);                                  // wave-uniform (tw4 <= 64: checked by the host)
     const int lr = (int)(((float)lane + 0.5f) * (1.0f / (float)tw4));  // lane / tw4, exact
     const int lc = lane - (int)__umul24(lr, tw4);
-    const v4f *src = reinterpret_cast<const v4f *>(hsrc + (size_t)w.i_lo[j] * p.W + w.j_lo[j]) + (size_t)(__umul24(lr, p.wq) + lc);
-    v4f *dst = reinterpret_cast<v4f *>(tile);
-    const size_t src_step = (size_t)__umul24(rpi, p.wq);
-    const int dst_step = rpi * tw4;
-    const bool lane_on = lr < rpi;
-    for (int r0 = 0; r0 < th; r0 += rpi) {
-        if (lane_on && r0 + lr < th)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-        src += src_step;
-        dst += dst_step;
-    }
+    unsigned voff = (unsigned)(__umul24(lr, p.wq) + lc) * 16u;        // the lane's byte offset from the window's first chunk
+    const int16_t *base = p.height_q + ((size_t)w.i_lo[j] * p.W + w.j_lo[j]);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) int16_t *)tile;
+    const int n_full = th / rpi, n_last = th - n_full * rpi;           // whole groups of rpi rows, rows of the last group
+    const unsigned dstep = (unsigned)(rpi * tw4) * 16u, vstep = (unsigned)__umul24(rpi, p.wq) * 16u;
+    const unsigned lds_end = lds0 + (unsigned)n_full * dstep;
+    const unsigned long long m_full = __builtin_amdgcn_ballot_w64(lr < rpi), m_last = __builtin_amdgcn_ballot_w64(lr < n_last);
+    unsigned long long saved;
+    unsigned m0_saved;
+    asm volatile(
+        "s_mov_b64 %[saved], exec\n\t"
+        "s_mov_b32 %[m0s], m0\n\t"
+        "s_mov_b32 m0, %[lds0]\n\t"
+        "s_mov_b64 exec, %[mfull]\n\t"
+        "s_cmp_lt_u32 m0, %[lend]\n\t"
+        "s_cbranch_scc0 2f\n"
+        "1:\n\t"
+        "global_load_lds_dwordx4 %[voff], %[base]\n\t"
+        "v_add_u32 %[voff], %[vstep], %[voff]\n\t"
+        "s_add_u32 m0, m0, %[dstep]\n\t"
+        "s_cmp_lt_u32 m0, %[lend]\n\t"
+        "s_cbranch_scc1 1b\n"
+        "2:\n\t"
+        "s_mov_b64 exec, %[mlast]\n\t"
+        "s_cbranch_execz 3f\n\t"
+        "global_load_lds_dwordx4 %[voff], %[base]\n"
+        "3:\n\t"
+        "s_mov_b32 m0, %[m0s]\n\t"
+        "s_mov_b64 exec, %[saved]"
+        : [saved] "=&s"(saved), [m0s] "=&s"(m0_saved), [voff] "+v"(voff)
+        : [lds0] "s"(lds0), [lend] "s"(lds_end), [mfull] "s"(m_full), [mlast] "s"(m_last), [base] "s"(base), [vstep] "s"(vstep),
+          [dstep] "s"(dstep)
+        : "memory", "scc");
 }
 // (Measured and not kept: the same copy through registers -- 16-byte global loads issued before the rays of the env that still
 // occupies the tile, LDS writes afterwards.  A single wave issues one global_load_lds_dwordx4 every ~145 cycles, 2.6 k cycles per
@@ -1747,56 +1811,194 @@ __device__ __forceinline__ void private_windows(const ScanWindow &sw, PrivateWin
         w.pk[j] = __builtin_amdgcn_readlane(pk, 16 * j);
     }
 }
-constexpr int PRIVATE_ROUNDS = 16, PRIVATE_GROUP = 16;
-// A lane without a ray in round m repeats ray 0 (the table says so) and stores the same bits to row[0] again: no execution
-// masks, no branches inside a group of GROUP rounds -- one basic block whose 4 GROUP LDS reads the scheduler can put in
-// flight together (with a branch per round the fused kernel spent 600 cycles per round, three times its VALU work).
-// Rounds [M0, M1) of the env's sixteen (the step wave and its copy wave share an env's rays).
+#ifdef RV_FUSED_UNALIGNED   // experiment: let hipcc merge the two cells of a row into one (2-byte-aligned) ds_read_b32
+#define RV_FUSED_ATTR
+#else
+#define RV_FUSED_ATTR __attribute__((target("no-unaligned-access-mode")))
+#endif
+constexpr int PRIVATE_ROUNDS = 16, PRIVATE_GROUP = 4;   // a pipeline group is a quad of rounds (one 16-byte store per lane)
+// Ray -> (round m, lane): ray = 256 (m >> 2) + 4 lane + (m & 3).  A lane's four rays of a QUAD of rounds are neighbours in the
+// observation row, so a quad ends in ONE 16-byte store per lane (row pointer in SGPRs, the lane's byte offset in one VGPR shared
+// by all quads, the quad in the immediate offset); a 4-byte store per round cost the wave ~45 cycles each.  Rows are only 4-byte
+// aligned (965 floats): the 16-byte stores straddle cache lines, which the one-wave-per-SIMD scan does not notice.
+// (a.y, a.y) * b as one v_pk_mul_f32 (op_sel picks the high half of `a` for both lanes: no move into the low half first)
+__device__ __forceinline__ f2 pk_mul_hi(f2 a, f2 b)
+{
+    f2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "s"(b));
+    return r;
+}
+__device__ __forceinline__ int private_ray_index(int m, int lane) { return ((m >> 2) << 8) + (lane << 2) + (m & 3); }
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef float v4f_u4 __attribute__((ext_vector_type(4), aligned(4)));   // a row is 4-byte aligned
+// (The stores are plain C++ on purpose: written as inline asm they were invisible to hipcc's hazard recogniser, and a 16-byte
+// store reads its data registers for several cycles after issue -- the next group's first packed multiply overwrote the second
+// dword of lanes 12 .. 15 of every row.)
+template <int Q>
+__device__ __forceinline__ void private_store4(float *row /* wave-uniform */, unsigned lane_bytes16, v4f_t v)
+{
+#ifdef RV_X_NOSTORE   // timing experiment (wrong values): no observation stores, the values kept alive
+    asm volatile("" : : "v"(v));
+    return;
+#endif
+    // (address space 1: `row` was rebuilt from two readfirstlanes, and a generic pointer would make this a FLAT store, which
+    // also counts in lgkmcnt -- the counter the pipeline's LDS reads are waited on)
+    typedef __attribute__((address_space(1))) v4f_u4 *global_v4;
+    typedef __attribute__((address_space(1))) char *global_bytes;
+    *(global_v4)((global_bytes)row + 1024 * Q + lane_bytes16) = v;
+}
+// A lane without a ray in round m repeats ray 0 (the table says so) and stores nothing: no branches inside an env's rounds --
+// one basic block.  Rounds [M0, M1) of the env's sixteen (the step wave and its copy wave share an env's rays).
+// The pipelined path is for interior windows of DENSE patterns (961 .. 1024 rays: 31 x 31 and 32 x 32, every round but the last
+// full -- its stores need no lane mask, and a mask costs scalar instructions that one wave per SIMD issues no faster than vector
+// ones); anything else takes the rolled loop below.
+//
+// The interior path is a software pipeline over groups of PRIVATE_GROUP rounds, held in place with scheduling barriers (one
+// wave per SIMD: nothing but the wave's own instruction stream hides the LDS latency, and left to itself the scheduler waits
+// for a pair of rays right after issuing their reads):   coordinates(g + 1) | reads(g + 1) | triangle + store(g).
+// Same arithmetic per ray as private_ray<TRI, true> -- written for instruction count (45 -> 26 VALU per ray):
+//   * rotation, translation and cell coordinates as packed pairs: (cy, sy) rx, (-sy, cy) ry, their sum, + (px, py),
+//     + (-min_x, -min_y), * inv_res -- six v_pk_*_f32, each the IEEE operation of the scalar form (a - b = a + (-b),
+//     (-s) r = -(s r));
+//   * fx = u - (float)(int)u is v_fract_f32(u) for 0 <= u < 2^23 (the difference is exact, and below 1);
+//   * cell address = ((i0 * pitch + j0) << 1) + (tile - 2 (i_lo * pitch + j_lo)): one v_mad_u32_u24, one v_lshl_add_u32;
+//   * pz - hgt * q_scale as ONE fma: q_scale is a power of two (rover_set_terrain_q16 checks), so the product is exact and the
+//     fused form rounds the same real number once, like the subtraction did.
 template <bool TRI, int M0 = 0, int M1 = PRIVATE_ROUNDS>
 __device__ __forceinline__ void private_cast(const RvParams &p, const PrivateWindows &w, int j, const int16_t *tile, int lane, int e_base,
-                                             float *__restrict__ out, int row_stride, int col0, const float (&ox)[PRIVATE_ROUNDS],
-                                             const float (&oy)[PRIVATE_ROUNDS], const float2 *__restrict__ ray_xy)
+                                             float *__restrict__ out, int row_stride, int col0, const f2 (&oxy)[PRIVATE_ROUNDS],
+                                             const float2 *__restrict__ ray_xy)
 {
     if constexpr (M1 <= M0) {   // an empty share
         return;
     } else {
-    constexpr int CC = 8, G = PRIVATE_GROUP < M1 - M0 ? PRIVATE_GROUP : M1 - M0;
-    static_assert((M1 - M0) % G == 0, "whole groups");
+    constexpr int CC = 8, G = PRIVATE_GROUP;
+    static_assert(G == 4 && M0 % 4 == 0 && M1 % 4 == 0, "a share is whole quads of rounds");
     const int th = w.pk[j] & 0x7FFF;
     const int pitch = (w.pk[j] >> 16) * CC;
     float *row = out + (size_t)(e_base + j) * row_stride + col0;
-    if ((w.pk[j] >> 15) & 1) {
+    {   // wave-uniform by construction (e_base is the wave's first env); the compiler must know it: private_store wants SGPRs
+        const unsigned long long a = (unsigned long long)row;
+        row = (float *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                        (unsigned)__builtin_amdgcn_readfirstlane((int)a));
+    }
+    if (M0 * 64 >= p.rays) return;
+    if (((w.pk[j] >> 15) & 1) && p.rays > 64 * (PRIVATE_ROUNDS - 1)) {
+        typedef const __attribute__((address_space(3))) int16_t *lds_cell_ptr;
+        const f2 A = {w.cy[j], w.sy[j]}, BN = {-w.sy[j], w.cy[j]}, P = {w.px[j], w.py[j]}, NMIN = {-p.min_x, -p.min_y};
+        const f2 IR = {p.inv_res, p.inv_res};
+        const unsigned tile_lds = (unsigned)(size_t)(lds_cell_ptr)tile;
+        const unsigned base = tile_lds - 2u * (unsigned)(w.i_lo[j] * pitch + w.j_lo[j]);   // wraps like the per-ray subtraction did
+        const unsigned lane_bytes16 = (unsigned)lane * 16u;
+        // dense pattern (checked above): quads 0 .. 2 are full; in the last quad lanes below n3 / 4 hold four rays, lane n3 / 4 the
+        // n3 % 4 that remain (n3 = rays - 768: 193 .. 256)
+        const int n3 = p.rays - 64 * (PRIVATE_ROUNDS - 4);
+        // uniforms of the epilogue pinned in VGPRs: under SGPR pressure hipcc re-loads them from the kernel arguments in the middle
+        // of the pipeline, and a scalar load's s_waitcnt lgkmcnt(0) also waits for every LDS read in flight
+        float nqs = -p.q_scale, pz = w.pz[j], hoff = p.cfg.scan_height_offset;
+        asm volatile("" : "+v"(nqs), "+v"(pz), "+v"(hoff));
+        float fx[2][G], fy[2][G];
+        int h00[2][G], h01[2][G], h10[2][G], h11[2][G];
+        constexpr int NG = (M1 - M0 + G - 1) / G;
 #pragma unroll
-        for (int m0 = M0; m0 < M1; m0 += G) {
-            if (m0 * 64 < p.rays) {      // wave-uniform, once per group of rounds
-                float o[G];
-#pragma unroll
-                for (int q = 0; q < G; ++q)
-                    o[q] = private_ray<TRI, true>(p, tile, pitch, th, w.px[j], w.py[j], w.pz[j], w.cy[j], w.sy[j], w.i_lo[j],
-                                                  w.j_lo[j], ox[m0 + q], oy[m0 + q]);
+        for (int g = 0; g <= NG; ++g) {
+            const int b = g & 1;
+            if (g < NG) {
+                unsigned a0[G];
+                f2 t0[G], t1[G];
+                // stage-major over the group's rays: no packed op reads the result of the one before it
+#define RV_CAST_STAGE(...)                                                                                         \
+    _Pragma("unroll") for (int q = 0; q < G; ++q) { const int m = M0 + g * G + q; if (m < M1) { __VA_ARGS__ } }
+                RV_CAST_STAGE(t0[q] = A * (f2){oxy[m].x, oxy[m].x};)
+                RV_CAST_STAGE(t1[q] = pk_mul_hi(oxy[m], BN);)
+                RV_CAST_STAGE(t0[q] = t0[q] + t1[q];)
+                RV_CAST_STAGE(t0[q] = P + t0[q];)
+                RV_CAST_STAGE(t0[q] = t0[q] + NMIN;)
+                RV_CAST_STAGE(t0[q] = t0[q] * IR;)
+                RV_CAST_STAGE(t1[q] = (f2){__builtin_amdgcn_fractf(t0[q].x), __builtin_amdgcn_fractf(t0[q].y)};
+                              fx[b][q] = t1[q].x; fy[b][q] = t1[q].y;)
+                RV_CAST_STAGE(a0[q] = __umul24((int)t0[q].y, pitch) + (unsigned)(int)t0[q].x;)
+                RV_CAST_STAGE(a0[q] = (a0[q] << 1) + base;)
+#undef RV_CAST_STAGE
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < G; ++q) {
-                    const int r = lane + 64 * (m0 + q);
-                    row[r < p.rays ? r : 0] = o[q];
+                    const int m = M0 + g * G + q;
+                    if (m < M1) {
+#ifdef RV_X_NOLDS   // timing experiment (wrong values): no LDS reads
+                        h00[b][q] = a0[q]; h01[b][q] = a0[q] + 1; h10[b][q] = a0[q] + 2; h11[b][q] = a0[q] + 3;
+#else
+                        const lds_cell_ptr c0 = (lds_cell_ptr)(size_t)a0[q], c1 = (lds_cell_ptr)(size_t)(a0[q] + 2u * (unsigned)pitch);
+                        h00[b][q] = c0[0]; h01[b][q] = c0[1]; h10[b][q] = c1[0]; h11[b][q] = c1[1];
+#endif
+                    }
                 }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (g > 0) {
+                const int pb = b ^ 1;
+                float ov[G];
+#pragma unroll
+                for (int q = 0; q < G; ++q) {
+                    const int m = M0 + (g - 1) * G + q;
+                    if (m < M1) {
+                        float hgt;
+                        const float f00 = (float)h00[pb][q], f11 = (float)h11[pb][q];
+                        if (TRI) {
+                            const bool lower = fx[pb][q] >= fy[pb][q];
+                            const float pm = (float)(lower ? h01[pb][q] : h10[pb][q]);
+                            const float d1 = pm - f00, d2 = f11 - pm;
+                            const float ta = lower ? d1 : d2, tb = lower ? d2 : d1;
+                            hgt = fmaf(fy[pb][q], tb, fmaf(fx[pb][q], ta, f00));
+                        } else {
+                            const float f01 = (float)h01[pb][q], f10 = (float)h10[pb][q];
+                            const float dx0 = f01 - f00, dx1 = f11 - f10;
+                            const float hx0 = f00 + fx[pb][q] * dx0;
+                            const float hx1 = f10 + fx[pb][q] * dx1;
+                            hgt = hx0 + fy[pb][q] * (hx1 - hx0);
+                        }
+                        ov[q] = fmaf(nqs, hgt, pz) - hoff;   // observations.py:45
+                    }
+                }
+                {
+                    const v4f_t o4 = {ov[0], ov[1], ov[2], ov[3]};
+                    switch ((M0 >> 2) + g - 1) {   // the quad is the store's immediate offset
+                    case 0: private_store4<0>(row, lane_bytes16, o4); break;
+                    case 1: private_store4<1>(row, lane_bytes16, o4); break;
+                    case 2: private_store4<2>(row, lane_bytes16, o4); break;
+                    default:   // the last quad: lanes below n3 / 4 hold four rays, lane n3 / 4 the n3 % 4 that remain
+                        if (lane < (n3 >> 2)) {
+                            private_store4<3>(row, lane_bytes16, o4);
+                        } else if (lane == (n3 >> 2)) {
+#ifndef RV_X_NOSTORE
+                            __attribute__((address_space(1))) float *tail = (__attribute__((address_space(1))) float *)row + 256 * 3 + 4 * lane;
+                            if ((n3 & 3) > 0) tail[0] = ov[0];
+                            if ((n3 & 3) > 1) tail[1] = ov[1];
+                            if ((n3 & 3) > 2) tail[2] = ov[2];
+#endif
+                        }
+                        break;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     } else {
 #pragma unroll 1
         for (int m = M0; m < M1; ++m) {
-            if (m * 64 < p.rays) {
-                // (ox / oy indexed by a loop counter would leave the registers: the slow path re-reads the table)
+            if (private_ray_index(m, 0) < p.rays) {
+                // (the table registers indexed by a loop counter would leave the registers: the slow path re-reads the table)
                 const float2 xy = ray_xy[m * 64 + lane];
                 const float o = private_ray<TRI, false>(p, tile, pitch, th, w.px[j], w.py[j], w.pz[j], w.cy[j], w.sy[j], w.i_lo[j],
-                                                        w.j_lo[j], xy.x, xy.y);
-                const int r = lane + 64 * m;
+                                                        w.j_lo[j], xy.x, xy.y);   // (also right for an interior window: the bounds tests pass)
+                const int r = private_ray_index(m, lane);
                 if (r < p.rays) row[r] = o;
             }
         }
     }
     }
 }
-// ray_xy: 1024 x (x, y) pattern offsets of ray m * 64 + lane (rays past the pattern repeat ray 0), built by the host
+// ray_xy: 1024 x (x, y) pattern offsets, entry m * 64 + lane = ray private_ray_index(m, lane) (rays past the pattern repeat ray 0), built by the host
 template <bool TRI>
 __device__ __forceinline__ void scan_private_wave(const RvParams &p, int16_t *tile0, int16_t *tile1, int lane, int n_env, int e_base,
                                                   const PrivateWindows &w, float *__restrict__ out, int row_stride, int col0,
@@ -1804,16 +2006,15 @@ __device__ __forceinline__ void scan_private_wave(const RvParams &p, int16_t *ti
 {
     constexpr int ROUNDS = PRIVATE_ROUNDS;
     auto issue = [&](int j, int16_t *tile) { private_issue(p, w, j, tile, lane); };
-    float ox[ROUNDS], oy[ROUNDS];
-    auto cast = [&](int j, const int16_t *tile) { private_cast<TRI>(p, w, j, tile, lane, e_base, out, row_stride, col0, ox, oy, ray_xy); };
+    f2 oxy[ROUNDS];
+    auto cast = [&](int j, const int16_t *tile) { private_cast<TRI>(p, w, j, tile, lane, e_base, out, row_stride, col0, oxy, ray_xy); };
     if (n_env <= 0) return;
     issue(0, tile0);
     if (n_env > 1) issue(1, tile1);
 #pragma unroll
     for (int m = 0; m < ROUNDS; ++m) {
         const float2 v = ray_xy[m * 64 + lane];
-        ox[m] = v.x;
-        oy[m] = v.y;
+        oxy[m] = (f2){v.x, v.y};
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -1853,19 +2054,18 @@ __device__ __forceinline__ void scan_single_tile_wave(const RvParams &p, int16_t
 {
     if (n_env <= 0) return;
     private_issue(p, w, 0, tile, lane);
-    float ox[PRIVATE_ROUNDS], oy[PRIVATE_ROUNDS];
+    f2 oxy[PRIVATE_ROUNDS];
 #pragma unroll
     for (int m = 0; m < PRIVATE_ROUNDS; ++m) {
         const float2 v = ray_xy[m * 64 + lane];
-        ox[m] = v.x;
-        oy[m] = v.y;
+        oxy[m] = (f2){v.x, v.y};
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (j < n_env) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            private_cast<TRI>(p, w, j, tile, lane, e_base, out, row_stride, col0, ox, oy, ray_xy);
+            private_cast<TRI>(p, w, j, tile, lane, e_base, out, row_stride, col0, oxy, ray_xy);
             if (j + 1 < n_env) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile's last reads have returned
                 private_issue(p, w, j + 1, tile, lane);
@@ -1907,26 +2107,29 @@ __device__ __forceinline__ void windows_from_lds(const float *win, PrivateWindow
         w.pk[j] = __builtin_amdgcn_readfirstlane(__float_as_int(d1.w));
     }
 }
-// LDS of the copy-wave form behind the eight tiles: windows [4 waves][2 sets][4 envs][8] floats (1 KB), then per step wave 192
-// floats of link-point hand-over: [0, 48) rotation matrix + position of its four envs at the START of the last substep,
-// [64, 128) the bogie angle of every lane, [128, 192) the lane's link-point force, written by its twin in the copy wave.
+// LDS of the copy-wave form behind the eight tiles: windows [4 waves][2 sets][4 envs][8] floats (1 KB), then per step wave
+// RV_HAND floats of hand-over: [0, 48) rotation matrix + position of its four envs at the START of the last substep,
+// [64, 128) the bogie angle of every lane, [128, 192) the lane's link-point force and [192, 256) the obstacle-layer height under
+// the lane's wheel, both written by its twin in the copy wave, [256, 304) the reset outcomes of the four envs (12 floats each:
+// reset_draw evaluated by the copy wave during the physics).
+constexpr int RV_HAND = 320;
 __device__ __forceinline__ float *fused_win(float *lds, const RvParams &p, int wv)
 {
     return reinterpret_cast<float *>(reinterpret_cast<int16_t *>(lds) + (size_t)8 * p.tile_dim * p.tile_pitch) + wv * 64;
 }
-__device__ __forceinline__ float *fused_link(float *lds, const RvParams &p, int wv) { return fused_win(lds, p, 0) + 256 + wv * 192; }
+__device__ __forceinline__ float *fused_link(float *lds, const RvParams &p, int wv) { return fused_win(lds, p, 0) + 256 + wv * RV_HAND; }
 // rounds of an env's sixteen cast by the step wave; the copy wave takes the rest -- of envs 0 and 3 only: beside envs 1 and 2 it
 // has a window to stage (tools/r03_share.sh: 10 / 16 39.6 us per step, 8 / 12 40.1, no sharing 40.9)
 #ifndef RV_SHARE_FREE
-#define RV_SHARE_FREE 10
+#define RV_SHARE_FREE 8
 #endif
 #ifndef RV_SHARE_COPY
 #define RV_SHARE_COPY 16
 #endif
 constexpr int SHARE_FREE = RV_SHARE_FREE, SHARE_COPY = RV_SHARE_COPY;
 template <bool TRI>
-__device__ __forceinline__ void scan_copy_wave(const RvParams &p, float *lds, int partner, int lane, float *__restrict__ obs,
-                                               const float2 *__restrict__ ray_xy)
+__device__ __forceinline__ void scan_copy_wave(const RvParams &p, const float *__restrict__ state, float *lds, int partner, int lane,
+                                               float *__restrict__ obs, const float2 *__restrict__ ray_xy)
 {
     const int tile_cells = p.tile_dim * p.tile_pitch;
     int16_t *tile0 = reinterpret_cast<int16_t *>(lds) + (size_t)(2 * partner) * tile_cells, *tile1 = tile0 + tile_cells;
@@ -1934,8 +2137,23 @@ __device__ __forceinline__ void scan_copy_wave(const RvParams &p, float *lds, in
     const int e_base = (int)(blockIdx.x * 4 + partner) * 4;
     const int n_env = max(0, min(4, p.n - e_base));
     PrivateWindows w;
+    {   // before anything of this step is known: what a reset of each of the partner's envs WOULD draw (spawn row, yaw, target with
+        // its rejection loop, heading: functions of (global id, reset count) and the terrain).  The copy wave is asleep during the
+        // physics anyway; the step wave's reset becomes a handful of LDS reads instead of Philox rounds and dependent loads.
+        const int e = min(e_base + (lane >> 4), p.n - 1);
+        const uint32_t count = __float_as_uint(state[(size_t)ROVER_RESET_COUNT * p.n + e]);
+        ResetOutcome ro;
+        reset_draw(p, (uint32_t)(p.env_id_offset + e), count, nullptr, ro);
+        if ((lane & 15) == 0) {
+            float4 *d = reinterpret_cast<float4 *>(fused_link(lds, p, partner) + 256 + (lane >> 4) * 12);
+            d[0] = make_float4(ro.px, ro.py, ro.pz, ro.qw);
+            d[1] = make_float4(ro.qz, ro.tx, ro.ty, ro.tz);
+            d[2] = make_float4(ro.heading_cmd, 0.0f, 0.0f, 0.0f);
+        }
+    }
     {   // L: the step wave has left the pose of the last substep's start; this lane evaluates the link-body sample point of its
-        // twin (same slot, same role: same constants, same arithmetic -- link_point_fetch / link_point_eval) while the twin solves
+        // twin (same slot, same role: same constants, same arithmetic -- link_point_fetch / link_point_eval) and the obstacle
+        // layer under the twin's wheel (the patch terrain_sample<true> would gather: same cell, same weights) while the twin solves
         __syncthreads();                                                // L
         const float *lk = fused_link(lds, p, partner);
         const SlotConst sc = d_SLOT[lane & 7];
@@ -1947,39 +2165,42 @@ __device__ __forceinline__ void scan_copy_wave(const RvParams &p, float *lds, in
         float lp[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) lp[i] = role_b ? sc.lp[1][i] : sc.lp[0][i];
-        const float force = link_point_eval(link_point_fetch(p, R, pos, P, ax, lk[64 + lane], lp));
-        const_cast<float *>(lk)[128 + lane] = force;
+        const float bq = lk[64 + lane];
+        const LinkSample ls = link_point_fetch(p, R, pos, P, ax, bq, lp);
+        const float wbp[3] = {sc.wb[0], sc.wb[1], sc.wb[2]};
+        const LinkSample ws = link_point_fetch(p, R, pos, P, ax, bq, wbp);   // the wheel centre rides on the bogie like a link point
+        const_cast<float *>(lk)[128 + lane] = link_point_eval(ls);
+        const_cast<float *>(lk)[192 + lane] = link_sample_obstacle(ws);
     }
     __syncthreads();                                                    // A
     windows_from_lds(win, w);
     if (n_env > 0) private_issue(p, w, 0, tile0, lane);
     if (n_env > 1) private_issue(p, w, 1, tile1, lane);
-    float ox[PRIVATE_ROUNDS], oy[PRIVATE_ROUNDS];
+    f2 oxy[PRIVATE_ROUNDS];
 #pragma unroll
     for (int m = 0; m < PRIVATE_ROUNDS; ++m) {
-        ox[m] = 0.0f; oy[m] = 0.0f;
+        oxy[m] = (f2){0.0f, 0.0f};
         if (m >= SHARE_FREE) {
             const float2 v = ray_xy[m * 64 + lane];
-            ox[m] = v.x;
-            oy[m] = v.y;
+            oxy[m] = (f2){v.x, v.y};
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                                    // B
     windows_from_lds(win + 32, w);
     __syncthreads();                                                    // B2 (a reset in the step wave: it has restaged windows 0, 1)
-    if (n_env > 0) private_cast<TRI, SHARE_FREE, PRIVATE_ROUNDS>(p, w, 0, tile0, lane, e_base, obs, p.obs_w, 4, ox, oy, ray_xy);
+    if (n_env > 0) private_cast<TRI, SHARE_FREE, PRIVATE_ROUNDS>(p, w, 0, tile0, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();                                                    // C
     if (n_env > 2) private_issue(p, w, 2, tile0, lane);
-    if (n_env > 1) private_cast<TRI, SHARE_COPY, PRIVATE_ROUNDS>(p, w, 1, tile1, lane, e_base, obs, p.obs_w, 4, ox, oy, ray_xy);
+    if (n_env > 1) private_cast<TRI, SHARE_COPY, PRIVATE_ROUNDS>(p, w, 1, tile1, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();                                                    // D
     if (n_env > 3) private_issue(p, w, 3, tile1, lane);
-    if (n_env > 2) private_cast<TRI, SHARE_COPY, PRIVATE_ROUNDS>(p, w, 2, tile0, lane, e_base, obs, p.obs_w, 4, ox, oy, ray_xy);
+    if (n_env > 2) private_cast<TRI, SHARE_COPY, PRIVATE_ROUNDS>(p, w, 2, tile0, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();                                                    // E
-    if (n_env > 3) private_cast<TRI, SHARE_FREE, PRIVATE_ROUNDS>(p, w, 3, tile1, lane, e_base, obs, p.obs_w, 4, ox, oy, ray_xy);
+    if (n_env > 3) private_cast<TRI, SHARE_FREE, PRIVATE_ROUNDS>(p, w, 3, tile1, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
 }
 
 // ================================================================================================ K1g: step, group mapping
@@ -2046,6 +2267,7 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
     }
     // rover_env.py:64-72 decimation loop
     float Fw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    f2 oxy[PRIVATE_ROUNDS];   // the scan phase's ray table (one-launch forms)
     K1_STAMP(1);
     for (int s = 0; s < c.decimation - 1; ++s) physics_substep_group<false>(p, K, g, nullptr, s);
     if constexpr (FUSE == 1 || FUSE == 2) {
@@ -2070,7 +2292,20 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
         const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         windows_to_lds(fused_win(lds, p, wv), scan_window(p, g.pos, g.quat), lane);
         __syncthreads();                                                // A
-        if (c.decimation > 0) Fw[3] = fused_link(lds, p, wv)[128 + lane];
+        if (c.decimation > 0) {
+            const float *lk = fused_link(lds, p, wv);
+            Fw[3] = lk[128 + lane];
+            if (!(lk[192 + lane] > RV_OBSTACLE_EPS)) { Fw[0] = 0.0f; Fw[1] = 0.0f; Fw[2] = 0.0f; }   // the wheel is not on the obstacle layer
+        }
+        // the ray table of the scan phase: requested now, so that it arrives under the manager tail
+#pragma unroll
+        for (int m = 0; m < PRIVATE_ROUNDS; ++m) {
+            oxy[m] = (f2){0.0f, 0.0f};
+            if (m < SHARE_COPY) {
+                const float2 v = ray_xy[m * 64 + lane];
+                oxy[m] = (f2){v.x, v.y};
+            }
+        }
     }
     if (!id.wheel_active) { Fw[0] = 0.0f; Fw[1] = 0.0f; Fw[2] = 0.0f; Fw[3] = 0.0f; }
     if (active) group_store(state, N, e, id, g);
@@ -2158,7 +2393,15 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
     }
     const uint32_t gid = (uint32_t)(p.env_id_offset + e);
     if (do_reset) {
-        reset_one(p, S, gid);
+        if constexpr (FUSE == 1 || FUSE == 2) {   // drawn by the copy wave during the physics (scan_copy_wave)
+            const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+            const float4 *d = reinterpret_cast<const float4 *>(fused_link(lds, p, wv) + 256 + (lane >> 4) * 12);
+            const float4 d0 = d[0], d1 = d[1], d2 = d[2];
+            const ResetOutcome ro = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w, d2.x};
+            reset_apply(p, S, ro);
+        } else {
+            reset_one(p, S, gid);
+        }
         if (active) {
             // the reset rewrites the root pose (lane 0 stores it below), the contact cache of every wheel and, in
             // reset_mode 1, all velocities / joint words
@@ -2236,23 +2479,22 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
         float *win = fused_win(lds, p, wv);
         const int n_scan = max(0, min(4, p.n - wave * 4));
         const int e_base = wave * 4;
+        const bool restage = __ballot(do_reset) != 0ull;   // a reset moved a rover of this wave: windows 0 / 1 were staged for the old pose
         PrivateWindows pw;
-        {
+        if (restage) {
             const ScanWindow sw = scan_window(p, S + ROVER_POS, S + ROVER_QUAT);
             windows_to_lds(win + 32, sw, lane);
             private_windows(sw, pw);
-        }
-        float ox[PRIVATE_ROUNDS], oy[PRIVATE_ROUNDS];
-#pragma unroll
-        for (int m = 0; m < PRIVATE_ROUNDS; ++m) {
-            ox[m] = 0.0f; oy[m] = 0.0f;
-            if (m < SHARE_COPY) {
-                const float2 v = ray_xy[m * 64 + lane];
-                ox[m] = v.x;
-                oy[m] = v.y;
+        } else {   // the pose the physics left is final: set 1 = set 0, and the windows come back from there (same bits)
+            if ((lane & 15) == 0) {
+                const float4 *s0 = reinterpret_cast<const float4 *>(win + (lane >> 4) * 8);
+                float4 *s1 = reinterpret_cast<float4 *>(win + 32 + (lane >> 4) * 8);
+                const float4 a0 = s0[0], a1 = s0[1];
+                s1[0] = a0;
+                s1[1] = a1;
             }
+            windows_from_lds(win, pw);
         }
-        const bool restage = __ballot(do_reset) != 0ull;   // a reset moved a rover of this wave: windows 0 / 1 were staged for the old pose
         __syncthreads();                                                // B
         if (restage) {
             if (n_scan > 0) private_issue(p, pw, 0, tile0, lane);
@@ -2261,19 +2503,19 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the ray table (and a restaged window)
         __syncthreads();                                                // B2
         K1_STAMP(27);
-        if (n_scan > 0) private_cast<FUSE == 2, 0, SHARE_FREE>(p, pw, 0, tile0, lane, e_base, obs, p.obs_w, 4, ox, oy, ray_xy);
+        if (n_scan > 0) private_cast<FUSE == 2, 0, SHARE_FREE>(p, pw, 0, tile0, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         K1_STAMP(28);
         __syncthreads();                                                // C
-        if (n_scan > 1) private_cast<FUSE == 2, 0, SHARE_COPY>(p, pw, 1, tile1, lane, e_base, obs, p.obs_w, 4, ox, oy, ray_xy);
+        if (n_scan > 1) private_cast<FUSE == 2, 0, SHARE_COPY>(p, pw, 1, tile1, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         K1_STAMP(29);
         __syncthreads();                                                // D
-        if (n_scan > 2) private_cast<FUSE == 2, 0, SHARE_COPY>(p, pw, 2, tile0, lane, e_base, obs, p.obs_w, 4, ox, oy, ray_xy);
+        if (n_scan > 2) private_cast<FUSE == 2, 0, SHARE_COPY>(p, pw, 2, tile0, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         K1_STAMP(31);
         __syncthreads();                                                // E
-        if (n_scan > 3) private_cast<FUSE == 2, 0, SHARE_FREE>(p, pw, 3, tile1, lane, e_base, obs, p.obs_w, 4, ox, oy, ray_xy);
+        if (n_scan > 3) private_cast<FUSE == 2, 0, SHARE_FREE>(p, pw, 3, tile1, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
         K1_STAMP(26);
     }
 }
@@ -2287,7 +2529,7 @@ __global__ __launch_bounds__(RV_K1G_THREADS) void rover_step_kernel_group(RvPara
 }
 // One launch per env step: the group-mapped step with the height scan as its last phase (TRI: triangle-mesh surface).
 template <bool TRI>
-__global__ __launch_bounds__(2 * RV_K1G_THREADS) __attribute__((target("no-unaligned-access-mode"))) void rover_step_scan_kernel(
+__global__ __launch_bounds__(2 * RV_K1G_THREADS) RV_FUSED_ATTR void rover_step_scan_kernel(
     RvParams p, float *__restrict__ state, const float *__restrict__ action, float *__restrict__ obs, float *__restrict__ reward,
     uint8_t *__restrict__ terminated, uint8_t *__restrict__ truncated, float *__restrict__ force, float *__restrict__ log_partial,
     const float2 *__restrict__ ray_xy)
@@ -2297,7 +2539,7 @@ __global__ __launch_bounds__(2 * RV_K1G_THREADS) __attribute__((target("no-unali
     if (wv < RV_K1G_THREADS / 64)   // waves 0..3: the step (threadIdx.x < 256: the group kernel's own indexing); waves 4..7: their copy waves
         step_group_body<TRI ? 2 : 1>(p, state, action, obs, reward, terminated, truncated, force, log_partial, lds, ray_xy);
     else
-        scan_copy_wave<TRI>(p, lds, wv - RV_K1G_THREADS / 64, (int)(threadIdx.x & 63), obs, ray_xy);
+        scan_copy_wave<TRI>(p, state, lds, wv - RV_K1G_THREADS / 64, (int)(threadIdx.x & 63), obs, ray_xy);
 }
 
 __global__ __launch_bounds__(RV_K1G_THREADS) void rover_physics_kernel_group(RvParams p, float *__restrict__ state,
@@ -2869,7 +3111,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8), 
 
 // The same without copy waves (scan_single_tile_wave): 256-thread workgroups, two per CU.
 template <bool TRI>
-__global__ __launch_bounds__(RV_K1G_THREADS) __attribute__((target("no-unaligned-access-mode"))) void rover_step_scan1_kernel(
+__global__ __launch_bounds__(RV_K1G_THREADS) RV_FUSED_ATTR void rover_step_scan1_kernel(
     RvParams p, float *__restrict__ state, const float *__restrict__ action, float *__restrict__ obs, float *__restrict__ reward,
     uint8_t *__restrict__ terminated, uint8_t *__restrict__ truncated, float *__restrict__ force, float *__restrict__ log_partial,
     const float2 *__restrict__ ray_xy)
@@ -2886,7 +3128,7 @@ __global__ __launch_bounds__(1024) void rover_log_kernel(RvParams p, const float
     reduce_log_partials<1024>(p, lds, threadIdx.x, log_partial, n_waves, log_out);
 }
 template <bool TRI>
-__global__ __launch_bounds__(RV_K1G_THREADS) __attribute__((target("no-unaligned-access-mode"))) void rover_scan_private_kernel(
+__global__ __launch_bounds__(RV_K1G_THREADS) RV_FUSED_ATTR void rover_scan_private_kernel(
     RvParams p, float *__restrict__ out, int row_stride, int col0, const float *__restrict__ log_partial, int n_waves,
     float *__restrict__ log_out, const float *__restrict__ scan_desc, const float2 *__restrict__ ray_xy)
 {
@@ -3081,7 +3323,7 @@ static ScanForm scan_form_of(const rover_sim *sim, int mode)
 // Does rover_step run as ONE launch (rover_step_scan_kernel: the scan is the last phase of the step kernel's waves)?
 static size_t single_tile_lds_bytes(const rover_sim *sim) { return (size_t)(RV_K1G_THREADS / 64) * (size_t)sim->p.tile_dim * sim->p.tile_pitch * 2; }
 // eight tiles (two per step wave) + the windows' hand-over area (4 waves x 2 sets x 4 envs x 32 B) + the link points' (4 x 768 B)
-static size_t fused_lds_bytes(const rover_sim *sim) { return (size_t)(RV_K1G_THREADS / 64) * 2 * (size_t)sim->p.tile_dim * sim->p.tile_pitch * 2 + 1024 + 4 * 192 * sizeof(float); }
+static size_t fused_lds_bytes(const rover_sim *sim) { return (size_t)(RV_K1G_THREADS / 64) * 2 * (size_t)sim->p.tile_dim * sim->p.tile_pitch * 2 + 1024 + 4 * RV_HAND * sizeof(float); }
 // 0 = two launches, 1 = one launch with copy waves (one workgroup per CU), 2 = one launch, one tile per wave (two workgroups per CU)
 static int fused_form(const rover_sim *sim)
 {
@@ -3428,7 +3670,8 @@ int rover_bind(rover_sim *sim, float *state, void *workspace, size_t workspace_b
         std::vector<float2> tab(1024);
         const int rays = c.scan_nx * c.scan_ny;
         for (int i = 0; i < 1024; ++i) {
-            const int r = i < rays ? i : 0;
+            const int m = i >> 6, ln = i & 63, ri = ((m >> 2) << 8) + (ln << 2) + (m & 3);   // = private_ray_index(m, lane)
+            const int r = ri < rays ? ri : 0;
             tab[i].x = (float)(-0.5 * (double)c.scan_size_x + (double)c.scan_resolution * (double)(r % c.scan_nx));
             tab[i].y = (float)(-0.5 * (double)c.scan_size_y + (double)c.scan_resolution * (double)(r / c.scan_nx));
         }

@@ -34,6 +34,13 @@ for k in range(40):
         if bad < 3:
             d = (ra[0]["policy"].view(torch.int32) != rb[0]["policy"].view(torch.int32)).nonzero()
             print("step", k, "obs differ at", d[:5].tolist(), "log", a.episode_log_vector.tolist()[:14], b.episode_log_vector.tolist()[:14])
+            envs = torch.unique(d[:, 0]); cols = torch.unique(d[:, 1])
+            e0 = int(d[0, 0]); A = ra[0]["policy"][e0].cpu(); B = rb[0]["policy"][e0].cpu()
+            for c in d[d[:, 0] == e0][:12, 1].tolist():
+                where = (A == B[c]).nonzero().flatten().tolist()[:4]
+                print(f"   env {e0} col {c} (ray {c - 4}): two-launch {A[c].item():.6f} one-launch {B[c].item():.6f}; the one-launch value sits in the two-launch row at cols {where}")
+            print("   differing elements", d.shape[0], "envs", envs.numel(), "env % 4 histogram", torch.bincount(envs % 4, minlength=4).tolist(),
+                  "cols min/max", cols.min().item(), cols.max().item(), "first cols", cols[:12].tolist(), "resets this step", int((ra[2] | ra[3]).sum()))
 print("steps with different observations / rewards / log:", bad, "of 40; states equal:", torch.equal(a.get_state().view(torch.int32), b.get_state().view(torch.int32)))
 for name, env in (("two launches", a), ("one launch", b)):
     for k in range(20): env.step(acts[k % 16])

@@ -45,4 +45,12 @@ for k in keys:
         d = s[:, k] - s[:, prev]
         print(f"{names[k]:28s} +{np.median(d):8.0f} cycles (p90 {np.percentile(d, 90):8.0f})")
     prev = k
-print("total start->end median", np.median(s[:, keys[-1]] - s[:, 0]), "cycles")
+tot = s[:, keys[-1]] - s[:, 0]
+print("total start->end median", np.median(tot), "cycles")
+# the kernel ends with its SLOWEST workgroup: the tail of the distribution (workgroups in which an env reset) is what the launch pays
+print("total start->end percentiles  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f   (workgroups %d)" % (np.percentile(tot, 50), np.percentile(tot, 90), np.percentile(tot, 99), tot.max(), len(tot)))
+slow = np.argsort(tot)[-4:]
+for wg in slow:
+    d = [s[wg, keys[i + 1]] - s[wg, keys[i]] for i in range(len(keys) - 1)]
+    print("  slow workgroup %4d total %6.0f: " % (wg, tot[wg]) + " ".join("%s=%d" % (names[keys[i + 1]].split()[0][:6] + str(keys[i + 1]), d[i]) for i in range(len(d)) if d[i] > 1.3 * np.median(s[:, keys[i + 1]] - s[:, keys[i]])))
+print("last stamp - first stamp over the whole grid: %.0f cycles" % (s[:, keys[-1]].max() - s[:, 0].min()))
