@@ -1828,6 +1828,24 @@ __device__ __forceinline__ f2 pk_mul_hi(f2 a, f2 b)
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "s"(b));
     return r;
 }
+// The four cells of a ray as inline asm: hipcc moves its own LDS loads next to their first use (past scheduling barriers), which
+// undoes the software pipeline below.  The loads are asynchronous -- the registers they name are defined only after the
+// lds_cell_wait that lists them (its "+v" ties make every later use depend on the wait).
+__device__ __forceinline__ void lds_cell4_issue(unsigned row0, unsigned row1, int &h00, int &h01, int &h10, int &h11)
+{
+    asm volatile("ds_read_i16 %0, %4\n\t"
+                 "ds_read_i16 %1, %4 offset:2\n\t"
+                 "ds_read_i16 %2, %5\n\t"
+                 "ds_read_i16 %3, %5 offset:2"
+                 : "=&v"(h00), "=&v"(h01), "=&v"(h10), "=&v"(h11) : "v"(row0), "v"(row1));
+}
+template <int CNT>
+__device__ __forceinline__ void lds_cell_wait(int (&h00)[4], int (&h01)[4], int (&h10)[4], int (&h11)[4])
+{
+    // (an asm statement takes at most 30 operands: the wait carries half of the group, an empty statement behind it the rest)
+    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(h00[0]), "+v"(h01[0]), "+v"(h10[0]), "+v"(h11[0]), "+v"(h00[1]), "+v"(h01[1]), "+v"(h10[1]), "+v"(h11[1]) : "n"(CNT));
+    asm volatile("" : "+v"(h00[2]), "+v"(h01[2]), "+v"(h10[2]), "+v"(h11[2]), "+v"(h00[3]), "+v"(h01[3]), "+v"(h10[3]), "+v"(h11[3]));
+}
 __device__ __forceinline__ int private_ray_index(int m, int lane) { return ((m >> 2) << 8) + (lane << 2) + (m & 3); }
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 typedef float v4f_u4 __attribute__((ext_vector_type(4), aligned(4)));   // a row is 4-byte aligned
@@ -1928,8 +1946,7 @@ __device__ __forceinline__ void private_cast(const RvParams &p, const PrivateWin
 #ifdef RV_X_NOLDS   // timing experiment (wrong values): no LDS reads
                         h00[b][q] = a0[q]; h01[b][q] = a0[q] + 1; h10[b][q] = a0[q] + 2; h11[b][q] = a0[q] + 3;
 #else
-                        const lds_cell_ptr c0 = (lds_cell_ptr)(size_t)a0[q], c1 = (lds_cell_ptr)(size_t)(a0[q] + 2u * (unsigned)pitch);
-                        h00[b][q] = c0[0]; h01[b][q] = c0[1]; h10[b][q] = c1[0]; h11[b][q] = c1[1];
+                        lds_cell4_issue(a0[q], a0[q] + 2u * (unsigned)pitch, h00[b][q], h01[b][q], h10[b][q], h11[b][q]);
 #endif
                     }
                 }
@@ -1938,6 +1955,12 @@ __device__ __forceinline__ void private_cast(const RvParams &p, const PrivateWin
             if (g > 0) {
                 const int pb = b ^ 1;
                 float ov[G];
+#ifndef RV_X_NOLDS
+                // the previous group's sixteen reads have returned when at most the fifteen youngest LDS operations are outstanding
+                // (LDS returns in order; the group issued just above is sixteen operations); after the last group: all of them
+                if (g < NG) lds_cell_wait<15>(h00[pb], h01[pb], h10[pb], h11[pb]);
+                else lds_cell_wait<0>(h00[pb], h01[pb], h10[pb], h11[pb]);
+#endif
 #pragma unroll
                 for (int q = 0; q < G; ++q) {
                     const int m = M0 + (g - 1) * G + q;
@@ -2120,6 +2143,9 @@ __device__ __forceinline__ float *fused_win(float *lds, const RvParams &p, int w
 __device__ __forceinline__ float *fused_link(float *lds, const RvParams &p, int wv) { return fused_win(lds, p, 0) + 256 + wv * RV_HAND; }
 // rounds of an env's sixteen cast by the step wave; the copy wave takes the rest -- of envs 0 and 3 only: beside envs 1 and 2 it
 // has a window to stage (tools/r03_share.sh: 10 / 16 39.6 us per step, 8 / 12 40.1, no sharing 40.9)
+#ifndef RV_TAIL_PRIO
+#define RV_TAIL_PRIO 0
+#endif
 #ifndef RV_SHARE_FREE
 #define RV_SHARE_FREE 8
 #endif
@@ -2288,6 +2314,9 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
         if (c.decimation > 0) physics_substep_group<true>(p, K, g, Fw, c.decimation - 1);
     }
     K1_STAMP(20);
+#ifndef RV_NO_SETPRIO
+    if constexpr (FUSE == 1 || FUSE == 2) __builtin_amdgcn_s_setprio(RV_TAIL_PRIO);
+#endif
     if constexpr (FUSE == 1 || FUSE == 2) {   // the physics has fixed the pose (unless the env resets below): its windows go to the copy wave
         const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         windows_to_lds(fused_win(lds, p, wv), scan_window(p, g.pos, g.quat), lane);
@@ -2536,10 +2565,16 @@ __global__ __launch_bounds__(2 * RV_K1G_THREADS) RV_FUSED_ATTR void rover_step_s
 {
     extern __shared__ __align__(16) float lds[];
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (wv < RV_K1G_THREADS / 64)   // waves 0..3: the step (threadIdx.x < 256: the group kernel's own indexing); waves 4..7: their copy waves
+    if (wv < RV_K1G_THREADS / 64) {  // waves 0..3: the step (threadIdx.x < 256: the group kernel's own indexing); waves 4..7: their copy waves
+#ifndef RV_NO_SETPRIO
+        // the step wave is the critical path and issues VALU nearly back to back; with the higher priority its copy wave (reset
+        // draws, link points) only gets the issue slots it leaves empty
+        __builtin_amdgcn_s_setprio(3);
+#endif
         step_group_body<TRI ? 2 : 1>(p, state, action, obs, reward, terminated, truncated, force, log_partial, lds, ray_xy);
-    else
+    } else {
         scan_copy_wave<TRI>(p, state, lds, wv - RV_K1G_THREADS / 64, (int)(threadIdx.x & 63), obs, ray_xy);
+    }
 }
 
 __global__ __launch_bounds__(RV_K1G_THREADS) void rover_physics_kernel_group(RvParams p, float *__restrict__ state,
@@ -3267,6 +3302,7 @@ struct rover_sim {
                          // the four waves' eight tiles fit the LDS, one workgroup per CU holds the batch), 0 = off, 1 = on where possible
     bool single_tile_ok; // the single-tile one-launch form may be chosen automatically beyond one round of workgroups (measured: see fused_form)
     bool log_deferred;   // rover_set_log_deferred: rover_step leaves `log` alone, rover_flush_log reduces it on demand
+    int launch_error;    // set by launch_step_kernels when a launch could not be made (rover_step returns it)
     float2 *ray_xy;      // [1024] pattern offsets of ray i (rays past the pattern repeat ray 0): the wave-private scan's table (workspace)
 };
 
@@ -3310,7 +3346,7 @@ static ScanForm scan_form_of(const rover_sim *sim, int mode)
     f.simple = mode == 2 && (sim->p.W & (cc - 1)) == 0 && (base & 15) == 0 && sim->p.rays <= 1024 && sim->scan_form != 1;
     const size_t tile_bytes = (size_t)sim->p.tile_dim * sim->p.tile_pitch * (f.q16 ? 2 : 4);
     // two envs per iteration when two workgroups with two tiles each fit the CU's LDS (measurement hook: form 2 = one env)
-    f.epi = (sim->scan_form != 2 && 2 * (192 * sizeof(float) + 2 * tile_bytes) <= 160 * 1024) ? 2 : 1;
+    f.epi = (sim->scan_form != 2 && 2 * (192 * sizeof(float) + 2 * tile_bytes) <= sim->max_lds) ? 2 : 1;
     f.step_lds = 192 * sizeof(float) + f.epi * tile_bytes < (1024 + 16) * sizeof(float) ? (1024 + 16) * sizeof(float)
                                                                                          : 192 * sizeof(float) + f.epi * tile_bytes;
     if (f.simple) {
@@ -3378,7 +3414,7 @@ static void launch_scan(rover_sim *sim, int grid, hipStream_t st, float *out, in
         const size_t tile_bytes = (size_t)sim->p.tile_dim * sim->p.tile_pitch * 2;
         size_t lds = (RV_K1G_THREADS / 64) * 2 * tile_bytes;
         if (lds < (RV_K1G_THREADS + 16) * sizeof(float)) lds = (RV_K1G_THREADS + 16) * sizeof(float);
-        if (lds <= 160 * 1024) {
+        if (lds <= sim->max_lds) {
             const int blocks = (sim->p.n + RV_K1G_ENVS - 1) / RV_K1G_ENVS;
             if (tri) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rover_scan_private_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -3440,6 +3476,34 @@ struct MarkerRange {
     ~MarkerRange() { if (on) g_roctx_pop(); }
 };
 
+// The dynamic-LDS limit is a property of the kernel (per device), shared by every handle of the process: only ever RAISE it -- a
+// handle with smaller tiles must not lower it under another handle's launches -- and not per launch (the call costs tens of
+// microseconds of host time).  What has been granted is remembered per device under a mutex (handles may step from different host
+// threads) and only when the runtime said yes; a failure is reported through rover_last_error() and retried by the next call.
+#include <mutex>
+static bool raise_dynamic_lds(rover_sim *sim, int form, size_t lds)
+{
+    static std::mutex mu;
+    static std::vector<size_t> granted[3];   // [form][device]
+    std::lock_guard<std::mutex> lock(mu);
+    std::vector<size_t> &g = granted[form];
+    if ((size_t)sim->device >= g.size()) g.resize((size_t)sim->device + 1, 0);
+    if (lds <= g[sim->device]) return true;
+    hipError_t e1, e2;
+    if (form == 1) {
+        e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&rover_step_scan_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&rover_step_scan_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    } else {
+        e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&rover_step_scan1_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&rover_step_scan1_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+        sim->launch_error = fail(ROVER_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+        return false;
+    }
+    g[sim->device] = lds;
+    return true;
+}
 static void launch_step_kernels(rover_sim *sim, hipStream_t st, const float *action, float *obs, float *reward, uint8_t *terminated,
                                 uint8_t *truncated, float *force, float *log, hipEvent_t mid)
 {
@@ -3449,13 +3513,7 @@ static void launch_step_kernels(rover_sim *sim, hipStream_t st, const float *act
     if (form == 2) {
         MarkerRange k1(sim, "rover_step_scan1_kernel");
         const size_t lds = single_tile_lds_bytes(sim);
-        static size_t raised1[64] = {0};
-        size_t &have = raised1[sim->device & 63];
-        if (lds > have) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rover_step_scan1_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rover_step_scan1_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            have = lds;
-        }
+        if (!raise_dynamic_lds(sim, 2, lds)) return;
         if (p.cfg.scan_surface == 0)
             hipLaunchKernelGGL((rover_step_scan1_kernel<true>), dim3(sim->step_blocks), dim3(RV_K1G_THREADS), lds, st, p, sim->state, action, obs,
                                reward, terminated, truncated, force, sim->log_partial, sim->ray_xy);
@@ -3470,16 +3528,7 @@ static void launch_step_kernels(rover_sim *sim, hipStream_t st, const float *act
     if (form == 1) {
         MarkerRange k1(sim, "rover_step_scan_kernel");
         const size_t lds = fused_lds_bytes(sim);
-        // The limit is a property of the kernel (per device), shared by every handle of the process: only ever RAISE it -- a handle
-        // with smaller tiles must not lower it under another handle's launches.  (Not per launch: the call costs tens of
-        // microseconds of host time.)
-        static size_t raised[64] = {0};
-        size_t &have = raised[sim->device & 63];
-        if (lds > have) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rover_step_scan_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rover_step_scan_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            have = lds;
-        }
+        if (!raise_dynamic_lds(sim, 1, lds)) return;
         if (p.cfg.scan_surface == 0) {
             hipLaunchKernelGGL((rover_step_scan_kernel<true>), dim3(sim->step_blocks), dim3(2 * RV_K1G_THREADS), lds, st, p, sim->state, action, obs,
                                reward, terminated, truncated, force, sim->log_partial, sim->ray_xy);
@@ -3664,6 +3713,9 @@ int rover_bind(rover_sim *sim, float *state, void *workspace, size_t workspace_b
     {
         DeviceGuard guard(sim->device);
         HIP_TRY(hipMemset(sim->p.log_counter, 0, 128));   // init-time, synchronous; the scan kernel returns it to zero after every reduction
+        // the log-partial rows carry the tag of the launch that wrote them in word 15 and log_serial restarts at 1 with every
+        // handle: a workspace that an earlier handle (or nobody) wrote must not hold rows that match this handle's tags
+        HIP_TRY(hipMemset(sim->log_partial, 0, sim->ws_log_floats * sizeof(float)));
         // ORBIT grid_pattern: arange(-size/2, size/2 + 1e-9, res) evaluated in double, x fastest (App. C) -- the values the scan
         // kernels derive per thread
         const rover_config &c = sim->p.cfg;
@@ -3692,7 +3744,7 @@ static void configure_tile(rover_sim *sim, int chunk_cells)
     // 8-wave workgroups: four per CU fill the 32 wave slots and may use 40 KiB of the 160 KiB LDS each
     p.tile_bufs = (192 * sizeof(float) + 2 * tile_bytes <= 40 * 1024) ? 2 : 1;
     sim->lds_bytes = 192 * sizeof(float) + p.tile_bufs * tile_bytes;
-    const int by_lds = (int)((160 * 1024) / (sim->lds_bytes > 0 ? sim->lds_bytes : 1));
+    const int by_lds = (int)(sim->max_lds / (sim->lds_bytes > 0 ? sim->lds_bytes : 1));   // the CU's LDS = what one workgroup may allocate
     const int by_waves = 32 / (RV_K2_THREADS / 64);
     const int per_cu = by_lds < by_waves ? (by_lds < 1 ? 1 : by_lds) : by_waves;
     sim->scan_wgs = sim->n_cu * per_cu;
@@ -3776,7 +3828,9 @@ int rover_step(rover_sim *sim, const float *action, float *obs, float *reward, u
     hipStream_t st = static_cast<hipStream_t>(stream);
     next_batch(sim);
     MarkerRange whole(sim, "rover_step");
+    sim->launch_error = ROVER_OK;
     launch_step_kernels(sim, st, action, obs, reward, terminated, truncated, force, log, nullptr);
+    if (sim->launch_error != ROVER_OK) return sim->launch_error;
     HIP_TRY(hipGetLastError());
     return ROVER_OK;
 }
@@ -3842,7 +3896,12 @@ int rover_profile_step(rover_sim *sim, const float *action, float *obs, float *r
     hipEvent_t ev[3];
     for (int i = 0; i < 3; ++i) HIP_TRY(hipEventCreate(&ev[i]));
     HIP_TRY(hipEventRecord(ev[0], st));
+    sim->launch_error = ROVER_OK;
     launch_step_kernels(sim, st, action, obs, reward, terminated, truncated, force, log, ev[1]);
+    if (sim->launch_error != ROVER_OK) {
+        for (int i = 0; i < 3; ++i) (void)hipEventDestroy(ev[i]);
+        return sim->launch_error;
+    }
     HIP_TRY(hipEventRecord(ev[2], st));
     HIP_TRY(hipEventSynchronize(ev[2]));
     HIP_TRY(hipEventElapsedTime(ms_step_kernel, ev[0], ev[1]));

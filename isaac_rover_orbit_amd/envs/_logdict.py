@@ -5,7 +5,9 @@ from __future__ import annotations
 
 class LogDict(dict):
     """A ``dict`` (ORBIT's ``extras["log"]`` holds 0-d tensors under "Episode Reward/<term>" ... keys) bound to an env with a
-    ``flush_log()`` method.  Iteration over keys alone does not need the values and does not flush."""
+    ``flush_log()`` method.  ``__iter__`` / ``keys`` are overridden as well: CPython's ``dict(d)``, ``{**d}``, ``other.update(d)``
+    and ``d | x`` copy a dict subclass through the C fast path (stored values, no ``__getitem__``) unless the subclass overrides
+    ``__iter__`` -- with the override they go through ``keys()`` + ``__getitem__`` and see flushed values."""
 
     def __init__(self, env, items):
         super().__init__(items)
@@ -18,6 +20,22 @@ class LogDict(dict):
     def get(self, k, default=None):
         self._env.flush_log()
         return super().get(k, default)
+
+    def __iter__(self):
+        self._env.flush_log()
+        return super().__iter__()
+
+    def keys(self):
+        self._env.flush_log()
+        return super().keys()
+
+    def __or__(self, other):
+        self._env.flush_log()
+        return dict(super().items()) | dict(other)
+
+    def __ror__(self, other):
+        self._env.flush_log()
+        return dict(other) | dict(super().items())
 
     def items(self):
         self._env.flush_log()

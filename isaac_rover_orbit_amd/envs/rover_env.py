@@ -367,6 +367,7 @@ class RoverEnv(RLTaskEnv):
         """ORBIT ``RLTaskEnv.reset``: (re-seed,) reset every env, return the first observation."""
         if seed is not None:
             self.seed(seed)
+        self.flush_log()     # a pending on-demand reduction belongs to the step before this reset (the reset advances the launch tag)
         obs = self._obs[self._cur]
         _lib.check(self._lib.rover_reset(self._h, _ptr(obs), self._stream()), "rover_reset")
         self._bump_counter()
@@ -387,6 +388,7 @@ class RoverEnv(RLTaskEnv):
         hd_d = torch.as_tensor(np.ascontiguousarray(heading_u, dtype=np.float32), device=dev)
         if row_d.shape != (n,) or yaw_d.shape != (n,) or hd_d.shape != (n,) or th_d.shape != (n, self._native_cfg.max_target_tries):
             raise ValueError("draw arrays must have one entry (theta: max_target_tries entries) per env")
+        self.flush_log()
         obs = self._obs[self._cur]
         _lib.check(self._lib.rover_reset_with_draws(self._h, _ptr(mask_d), _ptr(row_d), _ptr(yaw_d), _ptr(th_d), _ptr(hd_d),
                                                     _ptr(obs), self._stream()), "rover_reset_with_draws")

@@ -42,11 +42,13 @@ VARIANTS = {"STAMP": ("rover_kernels.hip", "-DRV_K2_STAMP"), "K1STAMP": ("rover_
             # round 4: what bounds the pipelined cast (stamped builds; X_* produce wrong observations)
             "X_NOSTORE": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_X_NOSTORE"), "X_NOLDS": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_X_NOLDS"),
             "X_NOBOTH": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_X_NOLDS -DRV_X_NOSTORE"),
-            "X_G2": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_PRIVATE_GROUP=2"), "X_G8": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_PRIVATE_GROUP=8"),
             "X_S16": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_SHARE_FREE=16 -DRV_SHARE_COPY=16"),
             "X_S8_12": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_SHARE_FREE=8 -DRV_SHARE_COPY=12"),
-            "X_S6_12": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_SHARE_FREE=6 -DRV_SHARE_COPY=12"),
-            "X_S8_14": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_SHARE_FREE=8 -DRV_SHARE_COPY=14")}
+            "X_NOPRIO": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_NO_SETPRIO"), "X_TAILPRIO3": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_TAIL_PRIO=3"),
+            "X_S12_12": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_SHARE_FREE=12 -DRV_SHARE_COPY=12"),
+            "X_S8_16": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_SHARE_FREE=8 -DRV_SHARE_COPY=16"),
+            "X_S4_12": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_SHARE_FREE=4 -DRV_SHARE_COPY=12"),
+            "X_S12_16": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_SHARE_FREE=12 -DRV_SHARE_COPY=16")}
 
 
 def main():
