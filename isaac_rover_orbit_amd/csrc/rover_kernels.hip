@@ -1865,6 +1865,38 @@ __device__ __forceinline__ void private_store4(float *row /* wave-uniform */, un
     typedef __attribute__((address_space(1))) char *global_bytes;
     *(global_v4)((global_bytes)row + 1024 * Q + lane_bytes16) = v;
 }
+// quad `quad` of a row: quads 0 .. 2 of a dense pattern are full; in the last one lanes below n3 / 4 hold four rays, lane n3 / 4
+// the n3 % 4 that remain (n3 = rays - 768: 193 .. 256)
+__device__ __forceinline__ void private_store_quad(float *row, int lane, int rays, int quad, v4f_t o4)
+{
+    const unsigned lane_bytes16 = (unsigned)lane * 16u;
+    switch (quad) {   // the quad is the store's immediate offset
+    case 0: private_store4<0>(row, lane_bytes16, o4); break;
+    case 1: private_store4<1>(row, lane_bytes16, o4); break;
+    case 2: private_store4<2>(row, lane_bytes16, o4); break;
+    default: {
+        const int n3 = rays - 64 * (PRIVATE_ROUNDS - 4);
+        if (lane < (n3 >> 2)) {
+            private_store4<3>(row, lane_bytes16, o4);
+        } else if (lane == (n3 >> 2)) {
+#ifndef RV_X_NOSTORE
+            __attribute__((address_space(1))) float *tail = (__attribute__((address_space(1))) float *)row + 256 * 3 + 4 * lane;
+            if ((n3 & 3) > 0) tail[0] = o4.x;
+            if ((n3 & 3) > 1) tail[1] = o4.y;
+            if ((n3 & 3) > 2) tail[2] = o4.z;
+#endif
+        }
+        break;
+    }
+    }
+}
+// the wave-uniform observation row of env e (rebuilt from two readfirstlanes: the stores want the pointer in SGPRs)
+__device__ __forceinline__ float *private_row(float *out, int e, int row_stride, int col0)
+{
+    const unsigned long long a = (unsigned long long)(out + (size_t)e * row_stride + col0);
+    return (float *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                     (unsigned)__builtin_amdgcn_readfirstlane((int)a));
+}
 // A lane without a ray in round m repeats ray 0 (the table says so) and stores nothing: no branches inside an env's rounds --
 // one basic block.  Rounds [M0, M1) of the env's sixteen (the step wave and its copy wave share an env's rays).
 // The pipelined path is for interior windows of DENSE patterns (961 .. 1024 rays: 31 x 31 and 32 x 32, every round but the last
@@ -1894,12 +1926,7 @@ __device__ __forceinline__ void private_cast(const RvParams &p, const PrivateWin
     static_assert(G == 4 && M0 % 4 == 0 && M1 % 4 == 0, "a share is whole quads of rounds");
     const int th = w.pk[j] & 0x7FFF;
     const int pitch = (w.pk[j] >> 16) * CC;
-    float *row = out + (size_t)(e_base + j) * row_stride + col0;
-    {   // wave-uniform by construction (e_base is the wave's first env); the compiler must know it: private_store wants SGPRs
-        const unsigned long long a = (unsigned long long)row;
-        row = (float *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
-                        (unsigned)__builtin_amdgcn_readfirstlane((int)a));
-    }
+    float *row = private_row(out, e_base + j, row_stride, col0);   // wave-uniform by construction (e_base is the wave's first env)
     if (M0 * 64 >= p.rays) return;
     if (((w.pk[j] >> 15) & 1) && p.rays > 64 * (PRIVATE_ROUNDS - 1)) {
         typedef const __attribute__((address_space(3))) int16_t *lds_cell_ptr;
@@ -1907,10 +1934,6 @@ __device__ __forceinline__ void private_cast(const RvParams &p, const PrivateWin
         const f2 IR = {p.inv_res, p.inv_res};
         const unsigned tile_lds = (unsigned)(size_t)(lds_cell_ptr)tile;
         const unsigned base = tile_lds - 2u * (unsigned)(w.i_lo[j] * pitch + w.j_lo[j]);   // wraps like the per-ray subtraction did
-        const unsigned lane_bytes16 = (unsigned)lane * 16u;
-        // dense pattern (checked above): quads 0 .. 2 are full; in the last quad lanes below n3 / 4 hold four rays, lane n3 / 4 the
-        // n3 % 4 that remain (n3 = rays - 768: 193 .. 256)
-        const int n3 = p.rays - 64 * (PRIVATE_ROUNDS - 4);
         // uniforms of the epilogue pinned in VGPRs: under SGPR pressure hipcc re-loads them from the kernel arguments in the middle
         // of the pipeline, and a scalar load's s_waitcnt lgkmcnt(0) also waits for every LDS read in flight
         float nqs = -p.q_scale, pz = w.pz[j], hoff = p.cfg.scan_height_offset;
@@ -1985,23 +2008,7 @@ __device__ __forceinline__ void private_cast(const RvParams &p, const PrivateWin
                 }
                 {
                     const v4f_t o4 = {ov[0], ov[1], ov[2], ov[3]};
-                    switch ((M0 >> 2) + g - 1) {   // the quad is the store's immediate offset
-                    case 0: private_store4<0>(row, lane_bytes16, o4); break;
-                    case 1: private_store4<1>(row, lane_bytes16, o4); break;
-                    case 2: private_store4<2>(row, lane_bytes16, o4); break;
-                    default:   // the last quad: lanes below n3 / 4 hold four rays, lane n3 / 4 the n3 % 4 that remain
-                        if (lane < (n3 >> 2)) {
-                            private_store4<3>(row, lane_bytes16, o4);
-                        } else if (lane == (n3 >> 2)) {
-#ifndef RV_X_NOSTORE
-                            __attribute__((address_space(1))) float *tail = (__attribute__((address_space(1))) float *)row + 256 * 3 + 4 * lane;
-                            if ((n3 & 3) > 0) tail[0] = ov[0];
-                            if ((n3 & 3) > 1) tail[1] = ov[1];
-                            if ((n3 & 3) > 2) tail[2] = ov[2];
-#endif
-                        }
-                        break;
-                    }
+                    private_store_quad(row, lane, p.rays, (M0 >> 2) + g - 1, o4);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -2141,13 +2148,11 @@ __device__ __forceinline__ float *fused_win(float *lds, const RvParams &p, int w
     return reinterpret_cast<float *>(reinterpret_cast<int16_t *>(lds) + (size_t)8 * p.tile_dim * p.tile_pitch) + wv * 64;
 }
 __device__ __forceinline__ float *fused_link(float *lds, const RvParams &p, int wv) { return fused_win(lds, p, 0) + 256 + wv * RV_HAND; }
-// rounds of an env's sixteen cast by the step wave; the copy wave takes the rest -- of envs 0 and 3 only: beside envs 1 and 2 it
-// has a window to stage (tools/r03_share.sh: 10 / 16 39.6 us per step, 8 / 12 40.1, no sharing 40.9)
-#ifndef RV_TAIL_PRIO
-#define RV_TAIL_PRIO 0
-#endif
+// rounds (whole quads) of an env's sixteen cast by the step wave; the copy wave takes the rest -- of envs 0 and 3 only: beside
+// envs 1 and 2 it has a window to stage.  Round 4 (tools/quick_bench.py, us per step at 4096 envs, step wave's rounds of envs
+// 0, 3 / of envs 1, 2): 4 / 16 35.06, 8 / 16 35.3, 8 / 12 36.0, 4 / 12 36.0, 0 / 12 36.4, 4 / 8 36.4.
 #ifndef RV_SHARE_FREE
-#define RV_SHARE_FREE 8
+#define RV_SHARE_FREE 4
 #endif
 #ifndef RV_SHARE_COPY
 #define RV_SHARE_COPY 16
@@ -2206,7 +2211,7 @@ __device__ __forceinline__ void scan_copy_wave(const RvParams &p, const float *_
 #pragma unroll
     for (int m = 0; m < PRIVATE_ROUNDS; ++m) {
         oxy[m] = (f2){0.0f, 0.0f};
-        if (m >= SHARE_FREE) {
+        if (m >= (SHARE_FREE < SHARE_COPY ? SHARE_FREE : SHARE_COPY)) {
             const float2 v = ray_xy[m * 64 + lane];
             oxy[m] = (f2){v.x, v.y};
         }
@@ -2215,6 +2220,9 @@ __device__ __forceinline__ void scan_copy_wave(const RvParams &p, const float *_
     __syncthreads();                                                    // B
     windows_from_lds(win + 32, w);
     __syncthreads();                                                    // B2 (a reset in the step wave: it has restaged windows 0, 1)
+    // (Measured, round 4: a share for this wave beside envs 1 / 2 as well -- with its stores deferred to the next phase so that the
+    // s_waitcnt vmcnt(0) for the window copy does not wait for their acknowledgement -- is slower, 36.3 vs 35.1 us per step: next to
+    // a window copy in flight the second casting wave gains nothing.  It casts beside envs 0 and 3 only.)
     if (n_env > 0) private_cast<TRI, SHARE_FREE, PRIVATE_ROUNDS>(p, w, 0, tile0, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();                                                    // C
@@ -2314,9 +2322,6 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
         if (c.decimation > 0) physics_substep_group<true>(p, K, g, Fw, c.decimation - 1);
     }
     K1_STAMP(20);
-#ifndef RV_NO_SETPRIO
-    if constexpr (FUSE == 1 || FUSE == 2) __builtin_amdgcn_s_setprio(RV_TAIL_PRIO);
-#endif
     if constexpr (FUSE == 1 || FUSE == 2) {   // the physics has fixed the pose (unless the env resets below): its windows go to the copy wave
         const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         windows_to_lds(fused_win(lds, p, wv), scan_window(p, g.pos, g.quat), lane);
@@ -2330,7 +2335,7 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
 #pragma unroll
         for (int m = 0; m < PRIVATE_ROUNDS; ++m) {
             oxy[m] = (f2){0.0f, 0.0f};
-            if (m < SHARE_COPY) {
+            if (m < (SHARE_FREE > SHARE_COPY ? SHARE_FREE : SHARE_COPY)) {
                 const float2 v = ray_xy[m * 64 + lane];
                 oxy[m] = (f2){v.x, v.y};
             }
@@ -2566,11 +2571,8 @@ __global__ __launch_bounds__(2 * RV_K1G_THREADS) RV_FUSED_ATTR void rover_step_s
     extern __shared__ __align__(16) float lds[];
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (wv < RV_K1G_THREADS / 64) {  // waves 0..3: the step (threadIdx.x < 256: the group kernel's own indexing); waves 4..7: their copy waves
-#ifndef RV_NO_SETPRIO
-        // the step wave is the critical path and issues VALU nearly back to back; with the higher priority its copy wave (reset
-        // draws, link points) only gets the issue slots it leaves empty
-        __builtin_amdgcn_s_setprio(3);
-#endif
+        // (s_setprio 3 for the step wave during the physics, so that its copy wave only gets the issue slots it leaves empty: measured,
+        // 83.8 k vs 84.0 k stamped cycles -- nothing)
         step_group_body<TRI ? 2 : 1>(p, state, action, obs, reward, terminated, truncated, force, log_partial, lds, ray_xy);
     } else {
         scan_copy_wave<TRI>(p, state, lds, wv - RV_K1G_THREADS / 64, (int)(threadIdx.x & 63), obs, ray_xy);

@@ -44,11 +44,16 @@ VARIANTS = {"STAMP": ("rover_kernels.hip", "-DRV_K2_STAMP"), "K1STAMP": ("rover_
             "X_NOBOTH": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_X_NOLDS -DRV_X_NOSTORE"),
             "X_S16": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_SHARE_FREE=16 -DRV_SHARE_COPY=16"),
             "X_S8_12": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_SHARE_FREE=8 -DRV_SHARE_COPY=12"),
-            "X_NOPRIO": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_NO_SETPRIO"), "X_TAILPRIO3": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_TAIL_PRIO=3"),
             "X_S12_12": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_SHARE_FREE=12 -DRV_SHARE_COPY=12"),
             "X_S8_16": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_SHARE_FREE=8 -DRV_SHARE_COPY=16"),
             "X_S4_12": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_SHARE_FREE=4 -DRV_SHARE_COPY=12"),
-            "X_S12_16": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_SHARE_FREE=12 -DRV_SHARE_COPY=16")}
+            "X_S12_16": ("rover_kernels.hip", "-DRV_K1_STAMP -DRV_SHARE_FREE=12 -DRV_SHARE_COPY=16"),
+            # unstamped share variants for tools/quick_bench.py
+            "Q_S4_12": ("rover_kernels.hip", "-DRV_SHARE_FREE=4 -DRV_SHARE_COPY=12"), "Q_S8_12": ("rover_kernels.hip", "-DRV_SHARE_FREE=8 -DRV_SHARE_COPY=12"),
+            "Q_S4_16": ("rover_kernels.hip", "-DRV_SHARE_FREE=4 -DRV_SHARE_COPY=16"), "Q_S8_16": ("rover_kernels.hip", "-DRV_SHARE_FREE=8 -DRV_SHARE_COPY=16"),
+            "Q_S0_12": ("rover_kernels.hip", "-DRV_SHARE_FREE=0 -DRV_SHARE_COPY=12"), "Q_S4_8": ("rover_kernels.hip", "-DRV_SHARE_FREE=4 -DRV_SHARE_COPY=8"),
+            "Q_S8_8": ("rover_kernels.hip", "-DRV_SHARE_FREE=8 -DRV_SHARE_COPY=8"), "Q_S12_12": ("rover_kernels.hip", "-DRV_SHARE_FREE=12 -DRV_SHARE_COPY=12"),
+            "Q_S12_8": ("rover_kernels.hip", "-DRV_SHARE_FREE=12 -DRV_SHARE_COPY=8"), "Q_S4_4": ("rover_kernels.hip", "-DRV_SHARE_FREE=4 -DRV_SHARE_COPY=4")}
 
 
 def main():
