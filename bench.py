@@ -7,12 +7,19 @@
 
 A "step" is one ``RoverEnv.step()`` over the rank's batch of envs: the hot path's HIP kernel -- ONE launch per step at the
 benchmark's 4096 envs per GPU (step + height scan), two launches below 2048 envs -- launched
-through the C ABI exactly as a trainer would (random actions pre-generated in HBM, in-kernel resets included).  Weak scaling:
-every rank simulates ``--num-envs`` envs (global ids sharded by rank, terrain replicated, no data-path collective).
-Rank 0 prints ONE JSON line.  Extra legs (not in the timed region):
-  * roofline      -- HIP-event duration of the dominant kernel vs its algorithmic bytes (SURVEY 8d / DESIGN.md)
+through the C ABI (random actions pre-generated in HBM, in-kernel resets included).  The timed loop is the metric's
+random-action rollout of ``step()``: it does not read ``extras["log"]``, so the on-demand log reduction never runs inside it.
+The reference's TRAINER reads the log after every step (``skrl_utils.py:139-142``: ``.item()`` on every entry of
+``infos["episode"]``): that loop is the ``extra.rollout_loop.trainer_loop`` leg, reported beside the headline, never instead
+of it.  Weak scaling: every rank simulates ``--num-envs`` envs (global ids sharded by rank, terrain replicated, no data-path
+collective).  Rank 0 prints ONE JSON line.  Extra legs (not in the timed region):
+  * roofline      -- duration of the dominant kernel vs its algorithmic bytes (SURVEY 8d / DESIGN.md); ``roofline.issue`` = what
+                     actually bounds the kernel (VALU issue of one to two waves per SIMD), from the committed PMC summary
   * cpu_baseline  -- the CPU oracle ("port") timed on a bounded sample of the same workload (N=1 only)
-  * rollout_gather (N>1) -- one RCCL all_gather of a 60-step rollout shard (BASELINE config 3)
+  * extra         -- (N=1, config 2, unless --no-extra) short runs of BASELINE configs 4 and 5, of the rollout loop with both
+                     networks and the trainer's per-step log read, and of the step at the reference's configured 32 solver iterations
+  * ranks / rollout_gather (N>1) -- which devices the ranks ran on; one RCCL all_gather of a 60-step rollout shard, plain and
+                     overlapped with the next rollout on a side stream (BASELINE config 3)
 """
 from __future__ import annotations
 
@@ -27,6 +34,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+PARITY_NOTE = ("MDP terms / reset / Ackermann / terrain look-ups pinned by reference fixtures; rover dynamics + contact "
+               "(PhysX in the reference) and the mesh ray-caster (Warp) are documented models, parity unpinned (DESIGN.md section 4)")
+
+
 # algorithmic bytes per env-step: obs write 4*(4+R), heightfield reads 4*R, state r+w 2*4*52, action 8,
 # reward+flags 6, wheel samples 6*6*4
 def algorithmic_bytes(rays: int):
@@ -35,57 +46,68 @@ def algorithmic_bytes(rays: int):
     return scan, dyn
 
 
-def bench_lift(args):
+def _load_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return None
+
+
+# ------------------------------------------------------------------------------------------------ config 5 (lift)
+def lift_line(num_envs, steps, warmup, profile_steps, cpu_seconds):
     """BASELINE config 5: FrankaCubeLift-v0, num_envs = 2048, 1 x MI355X; env-steps/s through FrankaCubeLiftEnv.step()."""
     import numpy as np
     import torch
     from isaac_rover_orbit_amd.envs import FrankaCubeLiftEnv, LiftEnvCfg
-    n = args.num_envs if args.num_envs != 4096 else 2048
+    n = num_envs
     torch.cuda.set_device(0)
     cfg = LiftEnvCfg()
     cfg.scene.num_envs = n
     env = FrankaCubeLiftEnv(cfg)
-    total = args.steps + args.warmup
+    total = steps + warmup
     g = torch.Generator(device=env.device).manual_seed(0)
     acts = torch.rand(min(total, 512), n, 8, device=env.device, generator=g) * 2 - 1
     env.reset()
-    for k in range(args.warmup):
+    for k in range(warmup):
         env.step(acts[k % acts.shape[0]])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(args.warmup, total):
+    for k in range(warmup, total):
         env.step(acts[k % acts.shape[0]])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    out = {"metric": "env-steps/sec FrankaCubeLift-v0 (BASELINE config 5)", "value": n * args.steps / dt, "unit": "env-steps/s",
-           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+    out = {"metric": "env-steps/sec FrankaCubeLift-v0 (BASELINE config 5)", "value": n * steps / dt, "unit": "env-steps/s",
+           "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"FrankaCubeLift-v0 num_envs={n}, random U(-1,1) actions, 100 Hz x decimation 2, in-step resets "
                                   "(BASELINE config 5)", "baseline_config": 5, "num_envs_per_gpu": n}}
     # ---- roofline leg.  Algorithmic bytes per env-step of this path (DESIGN.md section 9): state read + write 2 x 4 x 64 B,
     #      observation row 36 x 4 B, action 8 x 4 B, reward + flags 6 B = 694 B.  The kernel is bound by the length of its waves'
     #      instruction streams (512 waves at 2048 envs), not by HBM: the fraction is structurally tiny and says so.
-    ps = max(args.profile_steps, 1)
+    #      Duration = ms_per_step: one kernel per step, so the step time bounds the kernel from above (event intervals minus the
+    #      empty pair read BELOW it and rocprofv3's trace, with its per-dispatch instrumentation, above it: both are kept beside).
+    ps = max(profile_steps, 1)
     ms_raw = ms_ev = 0.0
     for k in range(ps):
         a, b = env.profile_step(acts[k % acts.shape[0]])
         ms_raw += a
         ms_ev += b
     ms_raw, ms_ev = ms_raw / ps, ms_ev / ps
-    ms_k = max(ms_raw - ms_ev, 1e-6)
+    ms_k = out["ms_per_step"]
     alg = (2 * 4 * 64 + 36 * 4 + 8 * 4 + 6) * n
     name = env.kernel_name()
     out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": alg / (ms_k * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": alg / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "event_pair_overhead_ms": ms_ev,
-                       "kernels": {name: {"ms": ms_k, "ms_raw_events": ms_raw, "algorithmic_bytes": alg,
-                                          "GB/s": alg / (ms_k * 1e-3) / 1e9}},
+                       "frac": alg / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "duration_basis": "ms_per_step",
+                       "event_pair_overhead_ms": ms_ev,
+                       "kernels": {name: {"ms": ms_k, "ms_raw_events": ms_raw, "ms_events_minus_empty_pair": max(ms_raw - ms_ev, 1e-6),
+                                          "algorithmic_bytes": alg, "GB/s": alg / (ms_k * 1e-3) / 1e9}},
                        "note": "latency-bound by construction: 8 lanes per env, two pipelined waves per 8 envs = 512 waves on 1024 SIMDs "
                                "at 2048 envs; the time is the critical path arm substep 0 -> cube substeps 0, 1 -> managers "
                                "(~35 k cycles), see DESIGN.md section 9"}
     out["config"]["parity"] = ("reward / observation term functions pinned by the reference fixture (lift_terms.npz); arm / cube / gripper "
                                "simulator is a documented model (PhysX in the reference), parity unpinned; HIP == the separately "
                                "written scalar oracle bit for bit")
-    if not args.no_cpu_baseline:
+    if cpu_seconds > 0:
         try:
             from oracle import lift_oracle as lo
             lo.build()
@@ -96,7 +118,7 @@ def bench_lift(args):
             lo.step(oc, S, a[0])
             t0 = time.perf_counter()
             m = 0
-            while m < 2000 and (m < 4 or time.perf_counter() - t0 < args.cpu_seconds):
+            while m < 2000 and (m < 4 or time.perf_counter() - t0 < cpu_seconds):
                 lo.step(oc, S, a[m % 16])
                 m += 1
             d = time.perf_counter() - t0
@@ -107,7 +129,153 @@ def bench_lift(args):
         except Exception as e:
             out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
     env.close()
-    print(json.dumps(out))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ rover legs
+def make_rover(dev, n, config, shard=None, solver_iterations=None, no_forces=False, terrain_cache=None):
+    """SURVEY 8d config 2 (procedural 2048^2 heightfield @ 0.05 m, fBm sigma_z 0.15 m seed 1234, ~400 rocks) or config 4
+    (same map generator at sigma_z 0.4 m, 32 x 32 rays at 0.05 m spacing)."""
+    from isaac_rover_orbit_amd import terrain as T
+    from isaac_rover_orbit_amd.cfg import RoverEnvCfg
+    from isaac_rover_orbit_amd.envs import RoverEnv
+    sigma_z = 0.15 if config == 2 else 0.4
+    n_global = shard.global_num_envs if shard else n
+    key = (sigma_z, n_global)
+    if terrain_cache is not None and key in terrain_cache:
+        ter = terrain_cache[key]
+    else:
+        ter = T.make_procedural_terrain((2048, 2048), seed=1234, sigma_z=sigma_z, n_rocks=400)
+        ter.make_spawns(2 * n_global, seed=41)
+        if terrain_cache is not None:
+            terrain_cache[key] = ter
+    cfg = RoverEnvCfg()
+    cfg.scene.num_envs = n
+    cfg.sim.device = str(dev)
+    cfg.terrain.kind = "custom"
+    if shard:
+        cfg.env_id_offset = shard.env_id_offset
+        cfg.global_num_envs = shard.global_num_envs
+    cfg.record_contact_forces = not no_forces
+    if solver_iterations is not None:
+        cfg.solver_iterations = int(solver_iterations)
+    if config == 4:
+        cfg.height_scanner.resolution, cfg.height_scanner.size = 0.05, (1.55, 1.55)
+    return RoverEnv(cfg, terrain=ter), ter, cfg, sigma_z
+
+
+def short_rover_run(dev, config, steps=300, warmup=60, solver_iterations=None, terrain_cache=None):
+    """One short run of a rover configuration (an ``extra`` leg): value, ms_per_step, kernel name."""
+    import torch
+    env, _, cfg, _ = make_rover(dev, 4096, config, solver_iterations=solver_iterations, terrain_cache=terrain_cache)
+    g = torch.Generator(device=dev).manual_seed(0)
+    acts = torch.rand(128, 4096, 2, device=dev, generator=g) * 2 - 1
+    env.reset()
+    for k in range(warmup):
+        env.step(acts[k % 128])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        env.step(acts[k % 128])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    scan_b, dyn_b = algorithmic_bytes(env.num_rays)
+    out = {"value": 4096 / dt, "unit": "env-steps/s", "ms_per_step": dt * 1e3, "steps": steps, "warmup": warmup, "num_envs": 4096,
+           "rays": env.num_rays, "solver_iterations": cfg.solver_iterations, "kernel": env.kernel_names()[0],
+           "whole_step_frac": (scan_b + dyn_b) * 4096 / dt / 1e9 / HBM_PEAK_GBS}
+    env.close()
+    return out
+
+
+def rollout_loop_leg(env, dev, steps, profile_steps, ev_ms):
+    """what a trainer runs per env step -- policy mean, value, env.step -- on ONE stream (random-init weights of the
+    reference architecture, get_models.py:36-62), as two launches, as the pair kernel, and as the reference's trainer loop:
+    the pair + env.step + ``.item()`` on every entry of ``infos["episode"]`` after every step (skrl_utils.py:139-142), which runs
+    the on-demand log reduction behind every step and synchronises the host thirteen times."""
+    import numpy as np
+    import torch
+    from isaac_rover_orbit_amd.policy import RoverNet, forward_pair
+    n = env.num_envs
+    rs = np.random.RandomState(7)
+    K, Nn = [961, 80, 64, 256, 160, 128], [80, 60, 256, 160, 128]
+
+    def net(out_dim, act):
+        ws = [(rs.uniform(-1, 1, (nn, kk)) / np.sqrt(kk)).astype(np.float32) for kk, nn in zip(K, Nn + [out_dim])]
+        bs = [(rs.uniform(-1, 1, nn) / np.sqrt(kk)).astype(np.float32) for kk, nn in zip(K, Nn + [out_dim])]
+        return RoverNet(ws, bs, n_enc=2, final_act=act, device=dev)
+    actor, critic = net(2, "tanh"), net(1, "none")
+    obs = env.obs_buf["policy"]
+    # per-kernel event times in the RUNNING loop (one event set per iteration, one synchronisation at the end: a
+    # synchronisation per iteration makes the actor the first kernel on an idle GPU and adds ~8 us to it)
+    t_act = t_val = t_env = 0.0
+    reps = max(profile_steps, 20)
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps + 5)]
+    for ev in evs:
+        ev[0].record(); a_pol = actor(obs); ev[1].record(); critic(obs); ev[2].record()
+        obs = env.step(a_pol)[0]["policy"]; ev[3].record()
+    torch.cuda.synchronize()
+    for ev in evs[5:]:
+        t_act += ev[0].elapsed_time(ev[1]); t_val += ev[1].elapsed_time(ev[2]); t_env += ev[2].elapsed_time(ev[3])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        a_pol = actor(obs); critic(obs)
+        obs = env.step(a_pol)[0]["policy"]
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    # the same loop with both networks in ONE launch on one staged tile (rover_policy_forward_pair)
+    t_pair = 0.0
+    for ev in evs:
+        ev[0].record(); a_pol, _v = forward_pair(actor, critic, obs); ev[1].record()
+        obs = env.step(a_pol)[0]["policy"]
+    torch.cuda.synchronize()
+    for ev in evs[5:]:
+        t_pair += ev[0].elapsed_time(ev[1])
+    t0 = time.perf_counter()
+    for k in range(steps):
+        a_pol, _v = forward_pair(actor, critic, obs)
+        obs = env.step(a_pol)[0]["policy"]
+    torch.cuda.synchronize()
+    dt_pair = (time.perf_counter() - t0) / steps
+    # the pair loop with the log reduced behind every step on the device, no host read (what a trainer that logs on the device pays)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        a_pol, _v = forward_pair(actor, critic, obs)
+        obs = env.step(a_pol)[0]["policy"]
+        env.flush_log()
+    torch.cuda.synchronize()
+    dt_flush = (time.perf_counter() - t0) / steps
+    # the reference's trainer loop: read every scalar of infos["episode"] on the host after every step
+    tracked = 0.0
+    t_steps = max(min(steps, 300), 20)
+    t0 = time.perf_counter()
+    for k in range(t_steps):
+        a_pol, _v = forward_pair(actor, critic, obs)
+        o, _r, _te, _tr, infos = env.step(a_pol)
+        obs = o["policy"]
+        if "episode" in infos:
+            for kk, vv in infos["episode"].items():
+                if isinstance(vv, torch.Tensor) and vv.numel() == 1:
+                    tracked += vv.item()
+    torch.cuda.synchronize()
+    dt_trainer = (time.perf_counter() - t0) / t_steps
+    flops = 2.0 * n * sum(kk * nn for kk, nn in zip(K, Nn + [2]))
+    return {"ms_per_step": dt * 1e3, "env_steps_per_s": n / dt,
+            "kernels_us_events": {"rover_policy_kernel (actor)": t_act / reps * 1e3 - ev_ms * 1e3,
+                                  "rover_policy_kernel (critic)": t_val / reps * 1e3 - ev_ms * 1e3,
+                                  "env.step": t_env / reps * 1e3 - ev_ms * 1e3},
+            "pair": {"ms_per_step": dt_pair * 1e3, "env_steps_per_s": n / dt_pair,
+                     "rover_policy_ref_pair_kernel_us_events": t_pair / reps * 1e3 - ev_ms * 1e3},
+            "pair_with_device_log": {"ms_per_step": dt_flush * 1e3, "env_steps_per_s": n / dt_flush,
+                                     "note": "pair + env.step + rover_flush_log behind every step (the log vector stays on the device)"},
+            "trainer_loop": {"ms_per_step": dt_trainer * 1e3, "env_steps_per_s": n / dt_trainer, "steps": t_steps,
+                             "note": "pair + env.step + .item() on every entry of infos['episode'] after every step, as "
+                                     "skrl_utils.py:139-142 does: the log reduction launches behind every step and the host "
+                                     "synchronises once per entry (13 per step)", "checksum": tracked},
+            "observations_finite": bool(torch.isfinite(obs).all()),
+            "actor_TFLOPs_f32": flops / ((t_act / reps - ev_ms) * 1e-3) / 1e12, "f32_mfma_peak_TFLOPs": 157.0,
+            "note": "closed loop: the actor's mean action drives the env (observations with -inf rays are what the kernel reads; "
+                    "the reference feeds them to torch the same way); none of these loops is `value`"}
 
 
 def main():
@@ -119,26 +287,30 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=200)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--preroll", type=int, default=400,
+                    help="untimed env steps BEFORE the warm-up steps: the rollout reaches its steady state (episodes of mixed age, resets "
+                         "in every step) and the GPU its sustained clock -- the first ~150 steps after an idle device run ~5 %% slower")
+    ap.add_argument("--no-extra", action="store_true", help="skip the `extra` block (configs 4 / 5, rollout loop, 32 solver iterations)")
     ap.add_argument("--no-forces", action="store_true", help="do not materialise contact_sensor.force_matrix_w")
     ap.add_argument("--with-policy", action="store_true",
-                    help="extra leg (outside `value`): the rollout loop a trainer runs -- actor + critic forward passes "
-                         "(fused MFMA kernel, reference architecture, random-init weights) + env.step() on one stream, per-kernel us")
+                    help="top-level `with_policy` leg (outside `value`): the rollout loop a trainer runs -- actor + critic forward "
+                         "passes (fused MFMA kernel, reference architecture, random-init weights) + env.step() on one stream; the "
+                         "default run carries the same leg as extra.rollout_loop")
     ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5),
                     help="BASELINE.json config: 2 = headline (31x31 rays @0.1 m, sigma_z 0.15 m); "
                          "4 = dense scanner stress (32x32 rays @0.05 m, sigma_z 0.4 m); "
                          "5 = manipulation task FrankaCubeLift-v0 (default num_envs 2048)")
     args = ap.parse_args()
     if args.config == 5:
-        return bench_lift(args)
+        n5 = args.num_envs if args.num_envs != 4096 else 2048
+        print(json.dumps(lift_line(n5, args.steps, args.warmup, args.profile_steps, 0.0 if args.no_cpu_baseline else args.cpu_seconds)))
+        return
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
     from isaac_rover_orbit_amd import distributed as rd
-    from isaac_rover_orbit_amd import terrain as T
-    from isaac_rover_orbit_amd.cfg import RoverEnvCfg
-    from isaac_rover_orbit_amd.envs import RoverEnv
 
     rank, world, local_rank = rd.init_from_env()
     if world != args.gpus:
@@ -153,28 +325,16 @@ def main():
     nccl = world > 1 and dist.get_backend() == "nccl"
     n = args.num_envs
     shard = rd.weak_shard(n, rank, world)
-
-    # ---- workload: SURVEY 8d config 2 (procedural 2048^2 heightfield @ 0.05 m, fBm sigma_z 0.15 m seed 1234, ~400 rocks)
-    #      or config 4 (same map generator at sigma_z 0.4 m, 32 x 32 rays at 0.05 m spacing)
-    sigma_z = 0.15 if args.config == 2 else 0.4
-    ter = T.make_procedural_terrain((2048, 2048), seed=1234, sigma_z=sigma_z, n_rocks=400)
-    ter.make_spawns(2 * shard.global_num_envs, seed=41)
-    cfg = RoverEnvCfg()
-    cfg.scene.num_envs = n
-    cfg.sim.device = str(dev)
-    cfg.terrain.kind = "custom"
-    cfg.env_id_offset = shard.env_id_offset
-    cfg.global_num_envs = shard.global_num_envs
-    cfg.record_contact_forces = not args.no_forces
-    if args.config == 4:
-        cfg.height_scanner.resolution, cfg.height_scanner.size = 0.05, (1.55, 1.55)
-    env = RoverEnv(cfg, terrain=ter)
+    terrain_cache = {}
+    env, ter, cfg, sigma_z = make_rover(dev, n, args.config, shard=shard, no_forces=args.no_forces, terrain_cache=terrain_cache)
 
     total = args.steps + args.warmup
     g = torch.Generator(device=dev).manual_seed(rank)          # torch's CUDA generator is Philox; seed 0 on rank 0
     n_act = min(total, 2048)
     actions = torch.rand(n_act, n, 2, device=dev, generator=g) * 2 - 1
     env.reset()
+    for k in range(args.preroll):              # initialisation, like the env construction above: not part of W, not timed
+        env.step(actions[(k * 7) % n_act])
     for k in range(args.warmup):
         env.step(actions[k % n_act])
 
@@ -194,10 +354,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     value = shard.global_num_envs * args.steps / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
 
-    # ---- roofline leg: HIP-event duration of each kernel (on the stream the kernels are launched on).  An event pair
-    #      with nothing between them measures the fixed cost an interval carries (event processing + the dispatch gap);
-    #      it is subtracted so that the kernel durations agree with the rocprofv3 trace and sum to <= ms_per_step.
+    # ---- roofline leg.  HIP-event duration of each kernel (on the stream the kernels are launched on), raw and minus the cost of
+    #      an empty event pair.  One launch per step: the roofline figure uses ms_per_step, which bounds the kernel's duration from
+    #      above (the corrected event interval reads below both the step time and rocprofv3's trace -- round-3 review); two
+    #      launches: the corrected event intervals, which sum to <= ms_per_step.
     ms1 = ms2 = 0.0
     ps = max(args.profile_steps, 1)
     for k in range(ps):
@@ -209,13 +371,16 @@ def main():
     ms1, ms2 = max(ms1_raw - ev_ms, 1e-6), max(ms2_raw - ev_ms, 1e-6)
     scan_b, dyn_b = algorithmic_bytes(env.num_rays)
     k1_name, k2_name = env.kernel_names()       # exactly what rocprofv3's kernel trace prints (rover_kernel_names)
-    if k1_name.startswith("rover_step_scan_kernel"):
-        # one launch per step: the height scan is the last phase of the step kernel's waves, so that kernel moves ALL the
-        # algorithmic bytes of an env step; the second interval is the log reduction (none when extras["log"] is on demand)
-        kernels = {k1_name: {"ms": ms1, "ms_raw_events": ms1_raw, "algorithmic_bytes": (dyn_b + scan_b) * n,
-                             "GB/s": (dyn_b + scan_b) * n / (ms1 * 1e-3) / 1e9}}
+    one_launch = k1_name.startswith("rover_step_scan")
+    if one_launch:
+        # the height scan is the last phase of the step kernel's waves, so that kernel moves ALL the algorithmic bytes of an env
+        # step; the second interval is the log reduction (none when extras["log"] is on demand)
+        ms_k = ms_per_step if world == 1 else max(ms1_raw, ms1)
+        kernels = {k1_name: {"ms": ms_k, "ms_raw_events": ms1_raw, "ms_events_minus_empty_pair": ms1,
+                             "algorithmic_bytes": (dyn_b + scan_b) * n, "GB/s": (dyn_b + scan_b) * n / (ms_k * 1e-3) / 1e9}}
         if k2_name:
             kernels[k2_name] = {"ms": ms2, "ms_raw_events": ms2_raw, "algorithmic_bytes": 0, "GB/s": 0.0}
+        basis = "ms_per_step (one kernel per step: an upper bound of its duration; profiles/*_kernel_stats.csv holds rocprofv3's)"
     else:
         kernels = {
             k1_name: {"ms": ms1, "ms_raw_events": ms1_raw, "algorithmic_bytes": dyn_b * n,
@@ -223,26 +388,37 @@ def main():
             k2_name: {"ms": ms2, "ms_raw_events": ms2_raw, "algorithmic_bytes": scan_b * n,
                       "GB/s": scan_b * n / (ms2 * 1e-3) / 1e9},
         }
+        basis = "HIP events minus the empty event pair"
     dom = max(kernels, key=lambda k: kernels[k]["ms"])
-    traffic = None
-    traffic_build = None
-    tr_path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if args.config == 2 and n == 4096 and os.path.exists(tr_path):
-        try:
-            tr = json.load(open(tr_path))
-            traffic = tr.get(dom, {}).get("bytes_per_launch")
-            traffic_build = tr.get("_build")
-        except Exception:
-            traffic = None
+    traffic = traffic_build = None
+    tr = _load_json("hbm_traffic.json") if (args.config == 2 and n == 4096) else None
+    if tr:
+        traffic = tr.get(dom, {}).get("bytes_per_launch")
+        traffic_build = tr.get("_build")
     roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": kernels[dom]["GB/s"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_build": traffic_build,
-                "event_pair_overhead_ms": ev_ms,
+                "duration_basis": basis, "event_pair_overhead_ms": ev_ms,
                 "whole_step_GB/s": (scan_b + dyn_b) * value / world / 1e9,
                 "whole_step_frac": (scan_b + dyn_b) * value / world / 1e9 / HBM_PEAK_GBS, "kernels": kernels}
+    # what bounds the kernel: at ~12 % of the HBM roofline the honest bound is instruction issue -- one step wave (+ one copy wave)
+    # per SIMD, a wave64 VALU instruction occupies the SIMD's 16 lanes for 4 cycles.  From the committed PMC summary of this build.
+    ic = _load_json("issue_counters.json") if (args.config == 2 and n == 4096) else None
+    if ic and dom in ic:
+        c = ic[dom]
+        simds = float(c.get("simds", 1024))
+        wave_cycles = 4.0 * c["SQ_WAVE_CYCLES"] / c["SQ_WAVES"]
+        roofline["issue"] = {"valu_insts_per_wave": c["SQ_INSTS_VALU"] / c["SQ_WAVES"],
+                             "valu_insts_per_simd": c["SQ_INSTS_VALU"] / simds,
+                             "wave_cycles": wave_cycles,
+                             "cycles_per_valu": wave_cycles / (c["SQ_INSTS_VALU"] / simds),
+                             "valu_busy_frac": 4.0 * c["SQ_ACTIVE_INST_VALU"] / (simds * wave_cycles),
+                             "waves_per_simd": c["SQ_WAVES"] / simds,
+                             "bound": "valu issue (4 cycles per wave64 instruction per SIMD)", "build": ic.get("_build"),
+                             "source": "profiles/issue_counters.json (rocprofv3 --pmc, tools/r04_counters.sh)"}
 
     out = {
         "metric": "env-steps/sec AAURoverEnv-v0 @ num_envs=4096; 1/2/4/8 MI355X", "value": value, "unit": "env-steps/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "AAURoverEnv-v0 num_envs=%d per GPU, procedural heightfield 2048x2048 @0.05 m "
                                "(fBm sigma_z %.2f m seed 1234 + 400 rocks), %dx%d rays @%.2f m, random U(-1,1) actions, "
@@ -254,11 +430,26 @@ def main():
                    "decimation": cfg.decimation, "sim_dt": cfg.sim.dt, "solver_iterations": cfg.solver_iterations,
                    "contact_forces_materialised": cfg.record_contact_forces, "parallelism": f"env-shard x{world}",
                    "scan_surface": env.cfg.height_scanner.surface, "spawn_draw": env.cfg.spawn_draw,
-                   "parity": "MDP terms / reset / Ackermann / terrain look-ups pinned by reference fixtures; rover dynamics + contact "
-                             "(PhysX in the reference) and the mesh ray-caster (Warp) are documented models, parity unpinned "
-                             "(DESIGN.md section 4)"},
+                   "log_reduction": getattr(cfg, "log_reduction", "on_demand"), "preroll_steps": args.preroll,
+                   "parity": PARITY_NOTE},
         "roofline": roofline,
     }
+
+    # ---- which devices did the ranks run on?  (BASELINE config 3 needs one GPU per rank; a rehearsal shares one card)
+    if world > 1:
+        try:
+            props = torch.cuda.get_device_properties(dev)
+            me = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "name": props.name,
+                  "pci_bus_id": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", -1) & 0xFF,
+                                                    getattr(props, "pci_device_id", 0) & 0xFF),
+                  "uuid": str(getattr(props, "uuid", ""))}
+            gathered = [None] * world
+            dist.all_gather_object(gathered, me)
+            ids = [(d["pci_bus_id"], d["uuid"]) for d in gathered]
+            out["ranks"] = {"world": world, "backend": dist.get_backend(), "devices": gathered,
+                            "distinct_devices": len(set(ids)), "one_gpu_per_rank": len(set(ids)) == world}
+        except Exception as e:
+            out["ranks"] = {"world": world, "backend": dist.get_backend(), "failed": repr(e)}
 
     # ---- RCCL rollout gather (BASELINE config 3): one 60-step rollout shard of observations, not in `value`
     if world > 1 and not nccl:
@@ -284,6 +475,29 @@ def main():
             out["rollout_gather"] = {"rollout_steps": T_roll, "shard_bytes": roll.numel() * 4, "ms": dt * 1e3,
                                      "per_rank_recv_GB/s": roll.numel() * 4 * (world - 1) / dt / 1e9,
                                      "ms_per_env_step_equiv": dt * 1e3 / T_roll}
+            # the same gather on a side stream, overlapped with the next rollout's 60 env steps: how much of it stays exposed?
+            side = rd.RolloutGatherer(side_stream=True)
+            def rollout():
+                for k in range(T_roll):
+                    env.step(actions[k % n_act])
+            rollout()
+            torch.cuda.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            rollout()
+            torch.cuda.synchronize()
+            barrier()
+            t_roll = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            side.gather(roll, outbuf)
+            rollout()
+            side.wait()
+            torch.cuda.synchronize()
+            barrier()
+            t_both = time.perf_counter() - t0
+            out["rollout_gather"]["overlapped"] = {"rollout_ms": t_roll * 1e3, "rollout_plus_gather_ms": t_both * 1e3,
+                                                   "exposed_ms": max(t_both - t_roll, 0.0) * 1e3,
+                                                   "hidden_ms": max(dt - max(t_both - t_roll, 0.0), 0.0) * 1e3}
             del roll, outbuf
         except Exception as e:  # the extra leg must never take the headline number down
             out["rollout_gather"] = {"failed": repr(e)}
@@ -331,72 +545,40 @@ def main():
         except Exception as e:  # the baseline must never take the bench down
             out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
 
-    # ---- rollout-loop leg: what a trainer runs per env step -- policy mean, value, env.step -- on ONE stream.
-    #      Random-init weights of the reference architecture (get_models.py:36-62); outside `value`.
+    # ---- rollout-loop leg on request (the default run carries it inside `extra`)
     if args.with_policy and env.num_rays == 961:
         try:
-            from isaac_rover_orbit_amd.policy import RoverNet
-            rs = np.random.RandomState(7)
-            K, Nn = [961, 80, 64, 256, 160, 128], [80, 60, 256, 160, 128]
-            def net(out_dim, act):
-                ws = [(rs.uniform(-1, 1, (nn, kk)) / np.sqrt(kk)).astype(np.float32) for kk, nn in zip(K, Nn + [out_dim])]
-                bs = [(rs.uniform(-1, 1, nn) / np.sqrt(kk)).astype(np.float32) for kk, nn in zip(K, Nn + [out_dim])]
-                return RoverNet(ws, bs, n_enc=2, final_act=act, device=dev)
-            actor, critic = net(2, "tanh"), net(1, "none")
-            if os.environ.get("ROVER_SCAN_FORM"):   # measurement hook: 5 / 6 = XCD-aware pair dealing of the scan kernel off / on
-                import ctypes as C
-                fn = C.CDLL(env._lib._name).rover_debug_set_scan_form
-                fn.argtypes = [C.c_void_p, C.c_int]
-                assert fn(env._h, int(os.environ["ROVER_SCAN_FORM"])) == 0
-            obs = env.obs_buf["policy"]
-            # per-kernel event times in the RUNNING loop (one event set per iteration, one synchronisation at the end: a
-            # synchronisation per iteration makes the actor the first kernel on an idle GPU and adds ~8 us to it)
-            t_act = t_val = t_env = 0.0
-            reps = max(args.profile_steps, 20)
-            evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps + 5)]
-            for ev in evs:
-                ev[0].record(); a_pol = actor(obs); ev[1].record(); critic(obs); ev[2].record()
-                obs = env.step(a_pol)[0]["policy"]; ev[3].record()
-            torch.cuda.synchronize()
-            for ev in evs[5:]:
-                t_act += ev[0].elapsed_time(ev[1]); t_val += ev[1].elapsed_time(ev[2]); t_env += ev[2].elapsed_time(ev[3])
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for k in range(args.steps):
-                a_pol = actor(obs); critic(obs)
-                obs = env.step(a_pol)[0]["policy"]
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / args.steps
-            # the same loop with both networks in ONE launch on one staged tile (rover_policy_forward_pair)
-            from isaac_rover_orbit_amd.policy import forward_pair
-            t_pair = 0.0
-            for ev in evs:
-                ev[0].record(); a_pol, _v = forward_pair(actor, critic, obs); ev[1].record()
-                obs = env.step(a_pol)[0]["policy"]
-            torch.cuda.synchronize()
-            for ev in evs[5:]:
-                t_pair += ev[0].elapsed_time(ev[1])
-            t0 = time.perf_counter()
-            for k in range(args.steps):
-                a_pol, _v = forward_pair(actor, critic, obs)
-                obs = env.step(a_pol)[0]["policy"]
-            torch.cuda.synchronize()
-            dt_pair = (time.perf_counter() - t0) / args.steps
-            flops = 2.0 * n * sum(kk * nn for kk, nn in zip(K, Nn + [2]))
-            out["with_policy"] = {"ms_per_step": dt * 1e3, "env_steps_per_s": n / dt,
-                                  "kernels_us_events": {"rover_policy_kernel (actor)": t_act / reps * 1e3 - ev_ms * 1e3,
-                                                        "rover_policy_kernel (critic)": t_val / reps * 1e3 - ev_ms * 1e3,
-                                                        "env.step (K1 + K2)": t_env / reps * 1e3 - ev_ms * 1e3},
-                                  "pair": {"ms_per_step": dt_pair * 1e3, "env_steps_per_s": n / dt_pair,
-                                           "rover_policy_ref_pair_kernel_us_events": t_pair / reps * 1e3 - ev_ms * 1e3},
-                                  "observations_finite": bool(torch.isfinite(obs).all()),
-                                  "actor_TFLOPs_f32": flops / ((t_act / reps - ev_ms) * 1e-3) / 1e12, "f32_mfma_peak_TFLOPs": 157.0,
-                                  "note": "closed loop: the actor's mean action drives the env (observations with -inf rays are "
-                                          "what the kernel reads; the reference feeds them to torch the same way)"}
+            out["with_policy"] = rollout_loop_leg(env, dev, args.steps, args.profile_steps, ev_ms)
         except Exception as e:  # the extra leg must never take the headline number down
             out["with_policy"] = {"failed": repr(e)}
 
-    env.close()
+    # ---- extra block: the numbers that used to exist only in builder-run files, each a short run outside `value`
+    if rank == 0 and world == 1 and args.config == 2 and n == 4096 and not args.no_extra:
+        extra = {"note": "short runs outside `value` (300 steps after 60 warm-up steps each unless stated)"}
+        try:
+            if "with_policy" in out and "failed" not in out["with_policy"]:
+                extra["rollout_loop"] = out["with_policy"]
+            else:
+                extra["rollout_loop"] = rollout_loop_leg(env, dev, 300, 60, ev_ms)
+        except Exception as e:
+            extra["rollout_loop"] = {"failed": repr(e)}
+        env.close()
+        env = None
+        for key, fn in (("config4", lambda: short_rover_run(dev, 4, terrain_cache=terrain_cache)),
+                        ("solver_iterations_32", lambda: short_rover_run(dev, 2, solver_iterations=32, terrain_cache=terrain_cache)),
+                        ("config5", lambda: {k: v for k, v in lift_line(2048, 300, 60, 40, 0.0).items()
+                                             if k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "roofline")})):
+            try:
+                extra[key] = fn()
+            except Exception as e:
+                extra[key] = {"failed": repr(e)}
+        if isinstance(extra.get("solver_iterations_32"), dict) and "ms_per_step" in extra["solver_iterations_32"]:
+            extra["solver_iterations_32"]["note"] = ("the reference configures 32 position iterations (aau_rover_simple.py:33); the "
+                                                     "headline runs cfg.solver_iterations = 16 (DESIGN.md section 4)")
+        out["extra"] = extra
+
+    if env is not None:
+        env.close()
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

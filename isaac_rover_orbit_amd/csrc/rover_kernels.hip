@@ -2174,7 +2174,11 @@ __device__ __forceinline__ void scan_copy_wave(const RvParams &p, const float *_
         const int e = min(e_base + (lane >> 4), p.n - 1);
         const uint32_t count = __float_as_uint(state[(size_t)ROVER_RESET_COUNT * p.n + e]);
         ResetOutcome ro;
+#ifdef RV_X_NODRAW   // timing experiment (wrong resets): what do the copy wave's reset draws cost the step?
+        ro.px = ro.py = ro.pz = ro.qz = ro.tx = ro.ty = ro.tz = ro.heading_cmd = (float)count; ro.qw = 1.0f;
+#else
         reset_draw(p, (uint32_t)(p.env_id_offset + e), count, nullptr, ro);
+#endif
         if ((lane & 15) == 0) {
             float4 *d = reinterpret_cast<float4 *>(fused_link(lds, p, partner) + 256 + (lane >> 4) * 12);
             d[0] = make_float4(ro.px, ro.py, ro.pz, ro.qw);
@@ -2197,11 +2201,16 @@ __device__ __forceinline__ void scan_copy_wave(const RvParams &p, const float *_
 #pragma unroll
         for (int i = 0; i < 3; ++i) lp[i] = role_b ? sc.lp[1][i] : sc.lp[0][i];
         const float bq = lk[64 + lane];
+#ifdef RV_X_NOLINK   // timing experiment (wrong contact report): what do the link points and the wheel obstacle look-ups cost the step?
+        const_cast<float *>(lk)[128 + lane] = 0.0f;
+        const_cast<float *>(lk)[192 + lane] = bq * 0.0f;
+#else
         const LinkSample ls = link_point_fetch(p, R, pos, P, ax, bq, lp);
         const float wbp[3] = {sc.wb[0], sc.wb[1], sc.wb[2]};
         const LinkSample ws = link_point_fetch(p, R, pos, P, ax, bq, wbp);   // the wheel centre rides on the bogie like a link point
         const_cast<float *>(lk)[128 + lane] = link_point_eval(ls);
         const_cast<float *>(lk)[192 + lane] = link_sample_obstacle(ws);
+#endif
     }
     __syncthreads();                                                    // A
     windows_from_lds(win, w);

@@ -104,4 +104,9 @@ def test_bench_two_ranks_gloo_rehearsal():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_num_envs"] == 2048
     assert d["config"]["parallelism"] == "env-shard x2" and d["value"] > 0
     assert d["rollout_gather"] is None and "gloo" in d["rollout_gather_skipped"]
+    # the record that proves (or here: disproves) one GPU per rank: both rehearsal ranks sit on the one card of this box
+    rk = d["ranks"]
+    assert rk["world"] == 2 and rk["backend"] == "gloo" and len(rk["devices"]) == 2
+    assert [x["rank"] for x in rk["devices"]] == [0, 1]
+    assert rk["distinct_devices"] == 1 and rk["one_gpu_per_rank"] is False
     assert abs(d["value"] - 2048 * 20 / (d["ms_per_step"] * 1e-3 * 20)) < 1e-6 * d["value"]

@@ -52,6 +52,9 @@ VARIANTS = {"STAMP": ("rover_kernels.hip", "-DRV_K2_STAMP"), "K1STAMP": ("rover_
             "Q_S4_12": ("rover_kernels.hip", "-DRV_SHARE_FREE=4 -DRV_SHARE_COPY=12"), "Q_S8_12": ("rover_kernels.hip", "-DRV_SHARE_FREE=8 -DRV_SHARE_COPY=12"),
             "Q_S4_16": ("rover_kernels.hip", "-DRV_SHARE_FREE=4 -DRV_SHARE_COPY=16"), "Q_S8_16": ("rover_kernels.hip", "-DRV_SHARE_FREE=8 -DRV_SHARE_COPY=16"),
             "Q_S0_12": ("rover_kernels.hip", "-DRV_SHARE_FREE=0 -DRV_SHARE_COPY=12"), "Q_S4_8": ("rover_kernels.hip", "-DRV_SHARE_FREE=4 -DRV_SHARE_COPY=8"),
+            "Q_NOLINK": ("rover_kernels.hip", "-DRV_X_NOLINK"), "Q_NODRAW": ("rover_kernels.hip", "-DRV_X_NODRAW"),
+            "Q_NOSTORE": ("rover_kernels.hip", "-DRV_X_NOSTORE"), "Q_NOLDS": ("rover_kernels.hip", "-DRV_X_NOLDS"),
+            "Q_NOBOTH": ("rover_kernels.hip", "-DRV_X_NOLDS -DRV_X_NOSTORE"), "Q_BASE": ("rover_kernels.hip", "-DRV_Q_BASE"),
             "Q_S8_8": ("rover_kernels.hip", "-DRV_SHARE_FREE=8 -DRV_SHARE_COPY=8"), "Q_S12_12": ("rover_kernels.hip", "-DRV_SHARE_FREE=12 -DRV_SHARE_COPY=12"),
             "Q_S12_8": ("rover_kernels.hip", "-DRV_SHARE_FREE=12 -DRV_SHARE_COPY=8"), "Q_S4_4": ("rover_kernels.hip", "-DRV_SHARE_FREE=4 -DRV_SHARE_COPY=4")}
 

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Dev tool: profiles/issue_counters.json from the rocprofv3 --pmc passes of tools/r04_counters.sh -- per-launch means of the
+issue / wait / LDS counters of the step-path kernels (launches 3.. of tools/pmc_run.py), keyed by the kernel name exactly as
+rocprofv3 prints it (= rover_kernel_names()).  bench.py turns them into roofline.issue.
+Usage: pmc_issue.py <dir with p1 p2 p3> <out.json> [build note]"""
+import csv, glob, json, re, sys, collections
+
+
+def short_name(name):
+    """rocprofv3's kernel name without return type, '(anonymous namespace)::' qualifiers and the parameter list."""
+    name = name.replace("(anonymous namespace)::", "")
+    name = re.sub(r"^void\s+", "", name)
+    depth, out = 0, []
+    for ch in name:
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            break
+        out.append(ch)
+    return "".join(out).strip()
+
+
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = short_name(r["Kernel_Name"])
+        if k.startswith(("rover_step", "rover_scan_step", "lift_step")):
+            acc[k][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+out = {"_how": "rocprofv3 --kernel-trace --pmc (three separate passes, tools/r04_counters.sh) -- python3 tools/pmc_run.py 4096 20; "
+               "per-launch means over launches 3..20, N = 4096, 1x MI355X.  SQ_*_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_* count in units "
+               "of 4 shader cycles summed over waves; simds = 4 per CU x 256 CUs.",
+       "_build": sys.argv[3] if len(sys.argv) > 3 else ""}
+for k, d in acc.items():
+    out[k] = {"simds": 1024}
+    for c, v in d.items():
+        v.sort()
+        v = [x for _, x in v][2:] or [x for _, x in v]
+        out[k][c] = sum(v) / len(v)
+json.dump(out, open(sys.argv[2], "w"), indent=1)
+print(json.dumps(out, indent=1))

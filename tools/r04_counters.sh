@@ -8,6 +8,7 @@ rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $O/p3 -- python3 $R/tools/pmc_run.py 4096 20 > $O/p3.log 2>&1
 echo "pmc rc=$?"
 python3 $R/tools/pmc_summarise.py $O > $O/issue_counters.txt 2>&1
+(cd $R/tools && python3 pmc_issue.py $O $O/issue_counters.json "${2:-}") > $O/issue_json.log 2>&1
 rm -rf $O/p1 $O/p2 $O/p3
 cd $R && python3 tools/k1_stamps.py > $O/k1_stamps.txt 2>&1; echo "stamps rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 300 --warmup 50 --no-cpu-baseline > $O/stats_bench.log 2>&1 && \
