@@ -170,8 +170,24 @@ int rover_set_counter(rover_sim *sim, uint64_t counter);
 int rover_step(rover_sim *sim, const float *action, float *obs, float *reward, uint8_t *terminated, uint8_t *truncated,
                float *force, float *log, void *stream);
 
+/* The env step in two halves -- the slow path for USER-WRITTEN reward / termination terms.  The reference's term tables
+ * (rover_env_cfg.py:126-183) hold arbitrary `func=` callables with the signature func(env, **params) (mdp/rewards.py:14-137,
+ * mdp/terminations.py:14-64); ORBIT's managers evaluate them on the state the physics left, BEFORE _reset_idx
+ * (rover_env.py:82-91).  rover_step does physics, terms and reset in one launch, so a caller with its own terms uses
+ *   rover_step_begin   rover_env.py:62-86: action, 6 physics steps, counters, the built-in terms and their episodic sums;
+ *                      stores state, reward (built-in terms), terminated / truncated (built-in terms), force.  No reset.
+ *   ... the caller evaluates its terms on `state` / `force` (device tensors), adds to `reward`, ORs into the flags ...
+ *   rover_step_finish  rover_env.py:89-99 for `reset_mask` (u8 per env: built-in OR user terminations): episodic log of the
+ *                      masked envs, reset, command update, observation rows; `log` is reduced eagerly.
+ * Same arithmetic as rover_step (one env per lane): with a reset mask equal to the built-in flags the two halves produce the bits
+ * rover_step produces.  `force` is required (the built-in collision term of the second half reads it). */
+int rover_step_begin(rover_sim *sim, const float *action, float *reward, uint8_t *terminated, uint8_t *truncated, float *force,
+                     void *stream);
+int rover_step_finish(rover_sim *sim, const uint8_t *reset_mask, float *obs, float *force, float *log, void *stream);
+
 /* extras["log"] on demand.  The reference fills the dictionary inside _reset_idx (rover_env.py:27-39) and its consumers read it
- * now and then (skrl_utils.py:139-142).  With rover_set_log_deferred(sim, 1) rover_step leaves `log` alone; rover_flush_log
+ * when they choose to: the reference's own trainer reads every entry after EVERY step (skrl_utils.py:139-142: .item() in the
+ * training loop), a random-action rollout never does.  With rover_set_log_deferred(sim, 1) rover_step leaves `log` alone; rover_flush_log
  * produces, at any later point on the same stream, exactly the vector the per-step reduction would hold there: [0..12] from the
  * latest step in which an env reset, [13] = the number of envs reset in the latest step (0 when the latest resets are older).
  * Flush at most once per step (a second flush without a step in between reports [13] = 0).  Deferral is also what lets

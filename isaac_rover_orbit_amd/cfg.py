@@ -5,9 +5,16 @@
 * ``AckermannActionCfg``   <- ``rover_envs/mdp/actions/actions_cfg.py:9-51``
 * ``AAURoverEnvCfg``       <- ``rover_envs/envs/navigation/robots/aau_rover/env_cfg.py:10-31``
 
-The term *functions* are fused into the HIP kernels; the cfg carries their names (strings), weights, scales and
-thresholds, which are compiled into the kernel parameter block (``_lib.RoverConfig``).  A term name the kernels do not
-know raises at construction time -- there is no slow Python path.
+The built-in term *functions* are fused into the HIP kernels; the cfg carries their names (strings), weights, scales and
+thresholds, which are compiled into the kernel parameter block (``_lib.RoverConfig``).
+
+**User-written terms** (the normal way to use the reference: ``rover_env_cfg.py:126-183`` are tables of arbitrary ``func=``):
+a reward or termination entry whose ``func`` is a *callable* -- signature ``func(env, **params) -> (num_envs,) tensor``, as in
+``mdp/rewards.py:14-137`` / ``mdp/terminations.py:14-64`` -- is kept and evaluated in torch by ``RoverEnv.step`` on the env's
+manager / scene facades between the two halves of the step (``rover_step_begin`` / ``rover_step_finish``: the SLOW path, three
+launches + the torch ops of the terms).  The built-in entries must stay in the table (a built-in reward is switched off with
+``weight=0``); with the stock table the env takes the one-launch fast path.  Observation terms are fixed (they define the row
+layout the policy checkpoint expects); ``noise`` / ``clip`` are not implemented.
 """
 from __future__ import annotations
 
@@ -20,7 +27,7 @@ from . import _lib
 
 @dataclass
 class TermCfg:
-    func: str
+    func: Any            # the name of a built-in term function (str) or a user callable func(env, **params)
     weight: float = 1.0
     scale: float = 1.0
     params: dict = field(default_factory=dict)
@@ -172,15 +179,32 @@ class RoverEnvCfg:
     global_num_envs: int | None = None
 
     # ------------------------------------------------------------------------------------------------------------
+    def custom_terms(self, table: dict, order: list) -> dict:
+        """The user-written entries of a term table: everything beside the built-in names, ``func`` a callable."""
+        return {k: t for k, t in table.items() if k not in order}
+
+    @property
+    def has_custom_terms(self) -> bool:
+        return bool(self.custom_terms(self.rewards, REWARD_ORDER) or self.custom_terms(self.terminations, TERMINATION_ORDER))
+
     def validate(self):
         for table, order, funcs, what in ((self.rewards, REWARD_ORDER, REWARD_FUNCS, "reward"),
                                           (self.terminations, TERMINATION_ORDER, TERMINATION_FUNCS, "termination"),
                                           (self.observations, OBS_ORDER, OBS_FUNCS, "observation")):
-            if list(table.keys()) != order:
-                raise ValueError(f"{what} terms must be exactly {order} (fused in the HIP kernels); got {list(table)}")
+            builtin = [k for k in table if k in order]
+            if builtin != order:
+                raise ValueError(f"the built-in {what} terms {order} must all be present, in this order (fused in the HIP kernels; "
+                                 f"switch a reward off with weight=0); got {list(table)}")
             for name, fn in zip(order, funcs):
                 if table[name].func != fn:
                     raise ValueError(f"{what} term '{name}' must use func '{fn}' (got '{table[name].func}')")
+            for name, t in self.custom_terms(table, order).items():
+                if what == "observation":
+                    raise ValueError(f"observation term '{name}': the observation row is fixed (4 + rays columns, the layout the policy "
+                                     "checkpoint expects); user-written terms are supported for rewards and terminations")
+                if not callable(t.func):
+                    raise ValueError(f"{what} term '{name}': func must be a callable func(env, **params) (got {t.func!r}); the built-in "
+                                     f"{what} terms are {order}")
         if self.reset_velocities not in ("reference", "zero"):
             raise ValueError("reset_velocities must be 'reference' or 'zero'")
         if self.spawn_draw not in ("distinct", "independent"):

@@ -10,11 +10,15 @@ Field map (reference file:line -> here):
   terminations.<term>.params / time_out            rover_env_cfg.py:166-183      -> terminations[...]
   commands.target_pose.*                           rover_env_cfg.py:187-200      -> commands.*
   scene.height_scanner.pattern_cfg / offset        rover_env_cfg.py:78-86        -> height_scanner.*
-Term functions are matched by ``func.__name__``; a table that uses a function the kernels do not implement raises.
+Built-in term functions are matched by table key and ``func.__name__``.  A reward / termination entry under another key
+is a USER-WRITTEN term (the reference's tables hold arbitrary ``func=``, rover_env_cfg.py:126-183): its callable and params
+are kept as they are (``SceneEntityCfg`` objects included) and ``RoverEnv.step`` evaluates it in torch between the two halves
+of the step (the slow path).  A built-in reward that the cfg omits is switched off (weight 0); an omitted ``is_success`` /
+``far_from_target`` termination gets a threshold no distance can meet; ``time_limit`` and ``collision`` cannot be omitted.
 """
 from __future__ import annotations
 
-from ..cfg import OBS_ORDER, REWARD_ORDER, TERMINATION_ORDER, RoverEnvCfg, TermCfg
+from ..cfg import OBS_ORDER, REWARD_FUNCS, REWARD_ORDER, TERMINATION_FUNCS, TERMINATION_ORDER, RoverEnvCfg, TermCfg
 
 
 def is_reference_cfg(cfg) -> bool:
@@ -32,9 +36,9 @@ def _plain_params(params):
     return out
 
 
-def _terms(table, order, what):
+def _terms(table, order, what, allow_custom=False):
     found = {k: v for k, v in vars(table).items() if hasattr(v, "func")}
-    if list(found) != order:
+    if not allow_custom and list(found) != order:
         raise ValueError(f"{what} terms of the cfg are {list(found)}; the fused kernels implement exactly {order}")
     return found
 
@@ -63,10 +67,39 @@ def from_reference_cfg(ref) -> RoverEnvCfg:
                                          params=_plain_params(t.params))
         if getattr(t, "noise", None) is not None or getattr(t, "clip", None) is not None:
             raise ValueError(f"observation term '{name}': noise / clip are not implemented by the fused kernels")
-    for name, t in _terms(ref.rewards, REWARD_ORDER, "reward").items():
-        out.rewards[name] = TermCfg(_func_name(t.func), weight=float(t.weight), params=_plain_params(t.params))
-    for name, t in _terms(ref.terminations, TERMINATION_ORDER, "termination").items():
-        out.terminations[name] = TermCfg(_func_name(t.func), params=_plain_params(t.params), time_out=bool(t.time_out))
+    rew = _terms(ref.rewards, REWARD_ORDER, "reward", allow_custom=True)
+    for name, fn in zip(REWARD_ORDER, REWARD_FUNCS):
+        if name in rew:
+            if _func_name(rew[name].func) != fn:
+                raise ValueError(f"reward term '{name}' is a built-in name and must use '{fn}' (got '{_func_name(rew[name].func)}'); "
+                                 "give a user-written term another key")
+            out.rewards[name] = TermCfg(fn, weight=float(rew[name].weight), params=_plain_params(rew[name].params))
+        else:
+            out.rewards[name].weight = 0.0            # omitted by the user's table: the kernel term stays, switched off
+    for name, t in rew.items():
+        if name not in REWARD_ORDER:
+            if not callable(t.func):
+                raise ValueError(f"reward term '{name}': func is not callable")
+            out.rewards[name] = TermCfg(t.func, weight=float(t.weight), params=dict(t.params or {}))
+    ter = _terms(ref.terminations, TERMINATION_ORDER, "termination", allow_custom=True)
+    for name, fn in zip(TERMINATION_ORDER, TERMINATION_FUNCS):
+        if name in ter:
+            if _func_name(ter[name].func) != fn:
+                raise ValueError(f"termination term '{name}' is a built-in name and must use '{fn}' (got '{_func_name(ter[name].func)}')")
+            out.terminations[name] = TermCfg(fn, params=_plain_params(ter[name].params), time_out=bool(ter[name].time_out))
+        elif name == "is_success":
+            out.terminations[name].params["threshold"] = -1.0           # d < -1 never holds
+            out.rewards["reached_target"].params["threshold"] = -1.0
+        elif name == "far_from_target":
+            out.terminations[name].params["threshold"] = float("inf")   # d > inf never holds
+            out.rewards["far_from_target"].params["threshold"] = float("inf")
+        else:
+            raise ValueError(f"the built-in termination '{name}' cannot be omitted (the episode clock / the contact report end episodes in the kernel)")
+    for name, t in ter.items():
+        if name not in TERMINATION_ORDER:
+            if not callable(t.func):
+                raise ValueError(f"termination term '{name}': func is not callable")
+            out.terminations[name] = TermCfg(t.func, params=dict(t.params or {}), time_out=bool(getattr(t, "time_out", False)))
 
     cmd = ref.commands.target_pose
     out.commands.resampling_time_range = tuple(cmd.resampling_time_range)

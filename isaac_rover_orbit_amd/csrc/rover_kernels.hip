@@ -1422,11 +1422,18 @@ __device__ __forceinline__ float wave_sum(float x)
 }
 
 // ================================================================================================ K1: step kernel
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void rover_step_kernel(RvParams p, float *__restrict__ state,
-                                                        const float *__restrict__ action, float *__restrict__ obs,
-                                                        float *__restrict__ reward, uint8_t *__restrict__ terminated,
-                                                        uint8_t *__restrict__ truncated, float *__restrict__ force,
-                                                        float *__restrict__ log_partial)
+// PHASE 0: the whole env step.  PHASE 1 / 2: the step in two halves with the caller in between -- the SLOW PATH for user-written
+// reward / termination terms (rover_env_cfg.py:126-183 are tables of arbitrary `func=`; ORBIT's managers evaluate them on the
+// state the physics left, BEFORE _reset_idx).  1 = action, physics, counters, the built-in terms and their episodic sums: state,
+// reward, flags and forces are stored, nothing is reset.  2 = the rest of rover_env.py:89-99 for the reset mask the caller
+// hands back (built-in OR user terminations): log contributions, reset, command update, observation head.  The built-in terms
+// are re-evaluated in phase 2 for the log's termination counts -- a pure function of words phase 1 stored (stale command,
+// actions, episode counter) and of the force rows.
+template <int PHASE>
+__device__ __forceinline__ void step_lane_body(const RvParams &p, float *__restrict__ state, const float *__restrict__ action,
+                                               float *__restrict__ obs, float *__restrict__ reward, uint8_t *__restrict__ terminated,
+                                               uint8_t *__restrict__ truncated, float *__restrict__ force, float *__restrict__ log_partial,
+                                               const uint8_t *__restrict__ reset_mask)
 {
     const int e_raw = blockIdx.x * 64 + threadIdx.x;
     const bool active = e_raw < p.n;
@@ -1437,48 +1444,54 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     // physics words first (pose, velocities, joints, actions, contact cache); manager words after the physics so that
     // they do not occupy registers across the solver
     float S[ROVER_STATE_WORDS];
-#pragma unroll
-    for (int i = 0; i < ROVER_TARGET_W; ++i) S[i] = state[(size_t)i * N + e];
-#pragma unroll
-    for (int i = ROVER_ACTION; i < ROVER_ACTION + 2; ++i) S[i] = state[(size_t)i * N + e];
-#pragma unroll
-    for (int i = ROVER_LAMBDA_N; i < ROVER_LAMBDA_N + 6; ++i) S[i] = state[(size_t)i * N + e];
-
-    // rover_env.py:62 ActionManager.process_action
-    S[ROVER_PREV_ACTION] = S[ROVER_ACTION];
-    S[ROVER_PREV_ACTION + 1] = S[ROVER_ACTION + 1];
-    const float2 a = reinterpret_cast<const float2 *>(action)[e];
-    S[ROVER_ACTION] = a.x;
-    S[ROVER_ACTION + 1] = a.y;
-    float steer_m[4], wheel_m[6];
-    {
-        float processed[2], steer[4], wheel[6];
-        ackermann_one(c, S + ROVER_ACTION, processed, steer, wheel);
-        steer_m[0] = steer[0]; steer_m[1] = steer[3]; steer_m[2] = steer[1]; steer_m[3] = steer[2];  // FL, FR, RL, RR
-        wheel_m[0] = wheel[1]; wheel_m[1] = wheel[5]; wheel_m[2] = wheel[0];                            // FL, FR, CL,
-        wheel_m[3] = wheel[4]; wheel_m[4] = wheel[2]; wheel_m[5] = wheel[3];                            // CR, RL, RR
-    }
-
-    // rover_env.py:64-72 decimation loop; the contact report is the one of the last physics step
     float F[ROVER_NUM_BODIES * 3];
-    const StepConsts &K = p.K;
-    for (int s = 0; s < c.decimation - 1; ++s) physics_substep<false>(p, K, S, steer_m, wheel_m, nullptr);
-    if (c.decimation > 0) {
-        physics_substep<true>(p, K, S, steer_m, wheel_m, F);
+    if (PHASE == 2) {
+#pragma unroll
+        for (int i = 0; i < ROVER_STATE_WORDS; ++i) S[i] = state[(size_t)i * N + e];
+#pragma unroll
+        for (int i = 0; i < ROVER_NUM_BODIES * 3; ++i) F[i] = force[(size_t)i * N + e];
     } else {
 #pragma unroll
-        for (int i = 0; i < ROVER_NUM_BODIES * 3; ++i) F[i] = 0.0f;
+        for (int i = 0; i < ROVER_TARGET_W; ++i) S[i] = state[(size_t)i * N + e];
+#pragma unroll
+        for (int i = ROVER_ACTION; i < ROVER_ACTION + 2; ++i) S[i] = state[(size_t)i * N + e];
+#pragma unroll
+        for (int i = ROVER_LAMBDA_N; i < ROVER_LAMBDA_N + 6; ++i) S[i] = state[(size_t)i * N + e];
+
+        // rover_env.py:62 ActionManager.process_action
+        S[ROVER_PREV_ACTION] = S[ROVER_ACTION];
+        S[ROVER_PREV_ACTION + 1] = S[ROVER_ACTION + 1];
+        const float2 a = reinterpret_cast<const float2 *>(action)[e];
+        S[ROVER_ACTION] = a.x;
+        S[ROVER_ACTION + 1] = a.y;
+        float steer_m[4], wheel_m[6];
+        {
+            float processed[2], steer[4], wheel[6];
+            ackermann_one(c, S + ROVER_ACTION, processed, steer, wheel);
+            steer_m[0] = steer[0]; steer_m[1] = steer[3]; steer_m[2] = steer[1]; steer_m[3] = steer[2];  // FL, FR, RL, RR
+            wheel_m[0] = wheel[1]; wheel_m[1] = wheel[5]; wheel_m[2] = wheel[0];                            // FL, FR, CL,
+            wheel_m[3] = wheel[4]; wheel_m[4] = wheel[2]; wheel_m[5] = wheel[3];                            // CR, RL, RR
+        }
+
+        // rover_env.py:64-72 decimation loop; the contact report is the one of the last physics step
+        const StepConsts &K = p.K;
+        for (int s = 0; s < c.decimation - 1; ++s) physics_substep<false>(p, K, S, steer_m, wheel_m, nullptr);
+        if (c.decimation > 0) {
+            physics_substep<true>(p, K, S, steer_m, wheel_m, F);
+        } else {
+#pragma unroll
+            for (int i = 0; i < ROVER_NUM_BODIES * 3; ++i) F[i] = 0.0f;
+        }
+
+#pragma unroll
+        for (int i = ROVER_TARGET_W; i < ROVER_ACTION; ++i) S[i] = state[(size_t)i * N + e];
+#pragma unroll
+        for (int i = ROVER_TIME_LEFT; i < ROVER_LAMBDA_N; ++i) S[i] = state[(size_t)i * N + e];
+        S[ROVER_RESET_COUNT] = state[(size_t)ROVER_RESET_COUNT * N + e];
+        // :79
+        S[ROVER_EP_LEN] = __int_as_float(__float_as_int(S[ROVER_EP_LEN]) + 1);
     }
-
-#pragma unroll
-    for (int i = ROVER_TARGET_W; i < ROVER_ACTION; ++i) S[i] = state[(size_t)i * N + e];
-#pragma unroll
-    for (int i = ROVER_TIME_LEFT; i < ROVER_LAMBDA_N; ++i) S[i] = state[(size_t)i * N + e];
-    S[ROVER_RESET_COUNT] = state[(size_t)ROVER_RESET_COUNT * N + e];
-
-    // :79
-    const int ep_len = __float_as_int(S[ROVER_EP_LEN]) + 1;
-    S[ROVER_EP_LEN] = __int_as_float(ep_len);
+    const int ep_len = __float_as_int(S[ROVER_EP_LEN]);
     // :82-86 terminations + rewards on the command of the PREVIOUS step (B-13)
     float rew[ROVER_NUM_REW];
     bool term[ROVER_NUM_TERM];
@@ -1487,16 +1500,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const bool term_any = term[1] | term[2] | term[3];
     const float step_dt = c.sim_dt * (float)c.decimation;
     float total = 0.0f;
+    if (PHASE != 2) {
 #pragma unroll
-    for (int i = 0; i < ROVER_NUM_REW; ++i) {
-        if (c.rew_weight[i] != 0.0f) {
-            const float val = rew[i] * c.rew_weight[i] * step_dt;
-            total += val;
-            S[ROVER_EP_SUM + i] += val;
+        for (int i = 0; i < ROVER_NUM_REW; ++i) {
+            if (c.rew_weight[i] != 0.0f) {
+                const float val = rew[i] * c.rew_weight[i] * step_dt;
+                total += val;
+                S[ROVER_EP_SUM + i] += val;
+            }
         }
     }
+    if (PHASE == 1) {   // everything up to the reset decision is on record; the caller's terms come next
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < ROVER_STATE_WORDS; ++i) state[(size_t)i * N + e] = S[i];
+            reward[e] = total;
+            terminated[e] = term_any ? 1 : 0;
+            truncated[e] = time_out ? 1 : 0;
+#pragma unroll
+            for (int i = 0; i < ROVER_NUM_BODIES * 3; ++i) force[(size_t)i * N + e] = F[i];
+        }
+        return;
+    }
     // :89-91 reset, with the episodic log contributions captured first
-    const bool do_reset = term_any | time_out;
+    const bool do_reset = PHASE == 2 ? reset_mask[e] != 0 : (term_any | time_out);
     float lg[14];
 #pragma unroll
     for (int i = 0; i < 14; ++i) lg[i] = 0.0f;
@@ -1535,14 +1562,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         write_scan_desc(p, S + ROVER_POS, S + ROVER_QUAT, e);
 #pragma unroll
         for (int i = 0; i < ROVER_STATE_WORDS; ++i) state[(size_t)i * N + e] = S[i];
-        reward[e] = total;
-        terminated[e] = term_any ? 1 : 0;
-        truncated[e] = time_out ? 1 : 0;
-        if (force) {
+        if (PHASE == 0) {
+            reward[e] = total;
+            terminated[e] = term_any ? 1 : 0;
+            truncated[e] = time_out ? 1 : 0;
+            if (force) {
 #pragma unroll
-            for (int i = 0; i < ROVER_NUM_BODIES * 3; ++i) force[(size_t)i * N + e] = F[i];
+                for (int i = 0; i < ROVER_NUM_BODIES * 3; ++i) force[(size_t)i * N + e] = F[i];
+            }
         }
     }
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void rover_step_kernel(RvParams p, float *__restrict__ state,
+                                                        const float *__restrict__ action, float *__restrict__ obs,
+                                                        float *__restrict__ reward, uint8_t *__restrict__ terminated,
+                                                        uint8_t *__restrict__ truncated, float *__restrict__ force,
+                                                        float *__restrict__ log_partial)
+{
+    step_lane_body<0>(p, state, action, obs, reward, terminated, truncated, force, log_partial, nullptr);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void rover_step_begin_kernel(RvParams p, float *__restrict__ state,
+                                                        const float *__restrict__ action, float *__restrict__ reward,
+                                                        uint8_t *__restrict__ terminated, uint8_t *__restrict__ truncated,
+                                                        float *__restrict__ force)
+{
+    step_lane_body<1>(p, state, action, nullptr, reward, terminated, truncated, force, nullptr, nullptr);
+}
+__global__ __launch_bounds__(64) void rover_step_finish_kernel(RvParams p, float *__restrict__ state, float *__restrict__ obs,
+                                                               float *__restrict__ force, float *__restrict__ log_partial,
+                                                               const uint8_t *__restrict__ reset_mask)
+{
+    step_lane_body<2>(p, state, nullptr, obs, nullptr, nullptr, nullptr, force, log_partial, reset_mask);
 }
 
 // ---- per-slot constants of the "group" mapping: one 64-byte row per wheel slot, fetched with ONE level of loads
@@ -3313,6 +3363,7 @@ struct rover_sim {
                          // the four waves' eight tiles fit the LDS, one workgroup per CU holds the batch), 0 = off, 1 = on where possible
     bool single_tile_ok; // the single-tile one-launch form may be chosen automatically beyond one round of workgroups (measured: see fused_form)
     bool log_deferred;   // rover_set_log_deferred: rover_step leaves `log` alone, rover_flush_log reduces it on demand
+    bool phase_open;     // rover_step_begin has run, rover_step_finish has not
     int launch_error;    // set by launch_step_kernels when a launch could not be made (rover_step returns it)
     float2 *ray_xy;      // [1024] pattern offsets of ray i (rays past the pattern repeat ray 0): the wave-private scan's table (workspace)
 };
@@ -3842,6 +3893,41 @@ int rover_step(rover_sim *sim, const float *action, float *obs, float *reward, u
     sim->launch_error = ROVER_OK;
     launch_step_kernels(sim, st, action, obs, reward, terminated, truncated, force, log, nullptr);
     if (sim->launch_error != ROVER_OK) return sim->launch_error;
+    HIP_TRY(hipGetLastError());
+    return ROVER_OK;
+}
+
+// ---- the step in two halves (slow path for user-written terms; see step_lane_body)
+int rover_step_begin(rover_sim *sim, const float *action, float *reward, uint8_t *terminated, uint8_t *truncated, float *force,
+                     void *stream)
+{
+    if (int rc = ready(sim)) return rc;
+    if (!action || !reward || !terminated || !truncated || !force) return fail(ROVER_ERR_INVALID, "NULL buffer (the two-phase step needs the force rows)");
+    DeviceGuard guard(sim->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    next_batch(sim);
+    sim->phase_open = true;
+    MarkerRange whole(sim, "rover_step_begin");
+    hipLaunchKernelGGL(rover_step_begin_kernel, dim3((sim->p.n + 63) / 64), dim3(64), 0, st, sim->p, sim->state, action, reward, terminated,
+                       truncated, force);
+    HIP_TRY(hipGetLastError());
+    return ROVER_OK;
+}
+
+int rover_step_finish(rover_sim *sim, const uint8_t *reset_mask, float *obs, float *force, float *log, void *stream)
+{
+    if (int rc = ready(sim)) return rc;
+    if (!reset_mask || !obs || !force || !log) return fail(ROVER_ERR_INVALID, "NULL buffer");
+    if (!sim->phase_open) return fail(ROVER_ERR_STATE, "rover_step_finish without rover_step_begin");
+    DeviceGuard guard(sim->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    sim->phase_open = false;
+    MarkerRange whole(sim, "rover_step_finish");
+    const int blocks = (sim->p.n + 63) / 64;
+    hipLaunchKernelGGL(rover_step_finish_kernel, dim3(blocks), dim3(64), 0, st, sim->p, sim->state, obs, force, sim->log_partial, reset_mask);
+    // the scan kernel of the two-launch path: observation rows from the descriptors the finish kernel wrote; its first workgroup
+    // reduces extras["log"] (always eagerly here: this path is not the one-launch form, a deferred flush would find nothing)
+    launch_scan<2>(sim, sim->p.n + 1, st, obs, sim->p.obs_w, 4, sim->log_partial, blocks, log);
     HIP_TRY(hipGetLastError());
     return ROVER_OK;
 }

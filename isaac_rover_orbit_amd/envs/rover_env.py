@@ -8,8 +8,14 @@ Reproduces the object protocol the reference's consumers use (SURVEY.md section 
 * the mdp term signatures (``env.command_manager.get_command``, ``env.action_manager.action``,
   ``env.scene.sensors[...]``, ``env.episode_length_buf`` ...)
 
-``step()`` is two HIP kernel launches through the C ABI (``include/rover_hip.h``); nothing is computed in Python or
+``step()`` is one or two HIP kernel launches through the C ABI (``include/rover_hip.h``); nothing is computed in Python or
 torch on the hot path and there is no host synchronisation.  All tensors live on the env's GPU.
+
+User-written reward / termination terms (a cfg table entry whose ``func`` is a callable, ``cfg.py``) switch ``step()`` to the
+SLOW path: ``rover_step_begin`` (physics + built-in terms) -> the user's ``func(env, **params)`` evaluated in torch on the
+facades below, with ORBIT's manager semantics (reward += func * weight * dt with its own episodic sum and
+``Episode Reward/<name>`` key; terminations OR-ed into the reset mask BEFORE the reset) -> ``rover_step_finish`` (reset of the
+masked envs, command update, observation rows).  Still no host synchronisation.
 """
 from __future__ import annotations
 
@@ -144,8 +150,10 @@ class _RayCaster:
         d = _SensorData()
         pos = env.state[_lib.POS:_lib.POS + 3].t()
         d.pos_w = pos
-        obs = env.obs_buf["policy"]
-        hit_z = pos[:, 2:3] - obs[:, 4:] - env.cfg.height_scanner.height_offset
+        # between the two halves of a slow step the observation rows are still the previous step's: user terms get a scan of the
+        # CURRENT pose (the reference's RayCaster has updated by the time rewards are computed, rover_env_cfg.py:275-276)
+        scan = env._fresh_scan() if env._in_user_terms else env.obs_buf["policy"][:, 4:]
+        hit_z = pos[:, 2:3] - scan - env.cfg.height_scanner.height_offset
         q = env.state[_lib.QUAT:_lib.QUAT + 4].t()
         yaw = torch.atan2(2 * (q[:, 0] * q[:, 3] + q[:, 1] * q[:, 2]), 1 - 2 * (q[:, 2] ** 2 + q[:, 3] ** 2))
         nx, ny = env.cfg.height_scanner.grid
@@ -173,15 +181,41 @@ class _TerrainFacade:
         return self._env._spawns_dev
 
 
+class _Robot:
+    """``scene["robot"]`` (ORBIT Articulation): ``data.root_pos_w / root_quat_w / root_lin_vel_w / root_ang_vel_w / joint_pos /
+    joint_vel`` as zero-copy views of the SoA state (joint order: 3 bogies, 4 steer joints, 6 wheels)."""
+    joint_names = ["FL_Boogie_Revolute", "FR_Boogie_Revolute", "R_Boogie_Revolute", "FL_Steer_Revolute", "FR_Steer_Revolute",
+                   "RL_Steer_Revolute", "RR_Steer_Revolute", "FL_Drive_Continuous", "FR_Drive_Continuous", "CL_Drive_Continuous",
+                   "CR_Drive_Continuous", "RL_Drive_Continuous", "RR_Drive_Continuous"]
+
+    def __init__(self, env):
+        self._env = env
+
+    @property
+    def data(self):
+        st = self._env.state
+        d = _SensorData()
+        d.root_pos_w = st[_lib.POS:_lib.POS + 3].t()
+        d.root_quat_w = st[_lib.QUAT:_lib.QUAT + 4].t()
+        d.root_lin_vel_w = st[_lib.LINVEL:_lib.LINVEL + 3].t()
+        d.root_ang_vel_w = st[_lib.ANGVEL:_lib.ANGVEL + 3].t()
+        d.joint_pos = st[_lib.BOGIE_Q:_lib.BOGIE_Q + 13].t()
+        d.joint_vel = st[_lib.BOGIE_QD:_lib.BOGIE_QD + 13].t()
+        return d
+
+
 class _Scene:
     def __init__(self, env):
         self.terrain = _TerrainFacade(env)
         self.sensors = {"contact_sensor": _ContactSensor(env), "height_scanner": _RayCaster(env)}
+        self.articulations = {"robot": _Robot(env)}
         self.num_envs = env.num_envs
 
     def __getitem__(self, name):
         if name in self.sensors:
             return self.sensors[name]
+        if name in self.articulations:
+            return self.articulations[name]
         raise KeyError(name)
 
 
@@ -300,7 +334,25 @@ class RoverEnv(RLTaskEnv):
         if getattr(self.cfg, "log_reduction", "on_demand") not in ("on_demand", "every_step"):
             raise ValueError("log_reduction must be 'on_demand' or 'every_step'")
         _lib.check(self._lib.rover_set_log_deferred(self._h, int(self._log_deferred)), "rover_set_log_deferred")
-        self._log_dict = LogDict(self, {k: self._log[i] for i, k in enumerate(LOG_KEYS)})
+        log_items = {k: self._log[i] for i, k in enumerate(LOG_KEYS)}
+        # ---- user-written terms (cfg.py): evaluated in torch between the two halves of the step
+        self._user_rewards = list(self.cfg.custom_terms(self.cfg.rewards, REWARD_ORDER).items())
+        self._user_terminations = list(self.cfg.custom_terms(self.cfg.terminations, TERMINATION_ORDER).items())
+        self._slow_path = bool(self._user_rewards or self._user_terminations)
+        self._in_user_terms = False
+        self._scan_cache = None
+        if self._slow_path:
+            with torch.cuda.device(self.device):
+                if self._force is None:    # the second half's built-in collision term reads the force rows
+                    self._force = torch.zeros(_lib.NUM_BODIES * 3, n, dtype=torch.float32, device=dev)
+                self._user_sums = {name: torch.zeros(n, dtype=torch.float32, device=dev) for name, _ in self._user_rewards}
+                self._user_log = torch.zeros(len(self._user_rewards) + len(self._user_terminations), dtype=torch.float32, device=dev)
+                self._reset_mask = torch.zeros(n, dtype=torch.uint8, device=dev)
+            for i, (name, _) in enumerate(self._user_rewards):
+                log_items[f"Episode Reward/{name}"] = self._user_log[i]
+            for i, (name, _) in enumerate(self._user_terminations):
+                log_items[f"Episode Termination/{name}"] = self._user_log[len(self._user_rewards) + i]
+        self._log_dict = LogDict(self, log_items)
         self.extras = {"log": self._log_dict, "episode": self._log_dict}   # rover_env.py:39
 
         # ---- manager / scene facades + spaces
@@ -368,6 +420,9 @@ class RoverEnv(RLTaskEnv):
         if seed is not None:
             self.seed(seed)
         self.flush_log()     # a pending on-demand reduction belongs to the step before this reset (the reset advances the launch tag)
+        if self._slow_path:  # RewardManager.reset of every env: the user terms' episodic sums start over
+            for sums in self._user_sums.values():
+                sums.zero_()
         obs = self._obs[self._cur]
         _lib.check(self._lib.rover_reset(self._h, _ptr(obs), self._stream()), "rover_reset")
         self._bump_counter()
@@ -406,6 +461,8 @@ class RoverEnv(RLTaskEnv):
     def step(self, action: torch.Tensor):
         """``RoverEnv.step`` (rover_env.py:42-102): two asynchronous kernel launches, no host sync."""
         action = self._check_action(action)
+        if self._slow_path:
+            return self._step_with_user_terms(action)
         self._cur = (self._cur + 1) % self._nbuf
         k = self._cur
         rc = self._lib.rover_step(self._h, C.c_void_p(action.data_ptr()), self._obs_ptr[k], self._rew_ptr[k],
@@ -420,6 +477,65 @@ class RoverEnv(RLTaskEnv):
         self.reward_buf = self._rew[k]
         self.reset_terminated = self._term_b[k]
         self.reset_time_outs = self._trunc_b[k]
+        return self.obs_buf, self.reward_buf, self.reset_terminated, self.reset_time_outs, self.extras
+
+    def _fresh_scan(self) -> torch.Tensor:
+        """Height scan of the pose the physics left (slow path, once per step, only if a user term asks for the ray hits)."""
+        if self._scan_cache is None:
+            self._scan_cache = self.height_scan()
+        return self._scan_cache
+
+    def _step_with_user_terms(self, action: torch.Tensor):
+        """The slow path: ``RoverEnv.step`` of the reference (rover_env.py:62-99) with the user's terms in ORBIT's order.
+
+        rover_step_begin  :62-86   action, 6 physics steps, counters, built-in terminations + rewards (+ episodic sums)
+        torch             :82-86   user terminations (OR-ed into terminated / time-outs), user rewards (+= func * weight * dt, own
+                                   episodic sums); both see the state the physics left, the STALE command (B-13) and the incremented
+                                   episode counter (B-14) -- what ORBIT's managers hand to a term function at that point
+        torch             :27-39   the user terms' share of _reset_idx's log: mean episodic sum of the envs about to reset /
+                                   max_episode_length_s, termination counts; values persist while no env resets
+        rover_step_finish :89-99   built-in share of the log, reset of the masked envs, command update, observation rows"""
+        self._cur = (self._cur + 1) % self._nbuf
+        k = self._cur
+        st = self._stream()
+        _lib.check(self._lib.rover_step_begin(self._h, C.c_void_p(action.data_ptr()), self._rew_ptr[k], self._term_ptr[k],
+                                              self._trunc_ptr[k], self._force_ptr, st), "rover_step_begin")
+        self._bump_counter()
+        self.common_step_counter += 1
+        self.reward_buf = self._rew[k]
+        self.reset_terminated = self._term_b[k]
+        self.reset_time_outs = self._trunc_b[k]
+        self._in_user_terms, self._scan_cache = True, None
+        try:
+            dones = []
+            for name, t in self._user_terminations:
+                v = t.func(self, **t.params).to(torch.bool).reshape(self.num_envs)
+                dones.append(v)
+                (self.reset_time_outs if t.time_out else self.reset_terminated).logical_or_(v)
+            for name, t in self._user_rewards:
+                if t.weight == 0.0:      # ORBIT's RewardManager skips zero-weight terms
+                    continue
+                val = t.func(self, **t.params).to(torch.float32).reshape(self.num_envs) * (float(t.weight) * self.step_dt)
+                self.reward_buf += val
+                self._user_sums[name] += val
+        finally:
+            self._in_user_terms, self._scan_cache = False, None
+        mask_b = torch.logical_or(self.reset_terminated, self.reset_time_outs)
+        self._reset_mask.copy_(mask_b)
+        cnt = mask_b.sum()
+        any_reset = cnt > 0
+        nr = len(self._user_rewards)
+        for i, (name, _) in enumerate(self._user_rewards):
+            s = self._user_sums[name]
+            new = (s * mask_b).sum() / cnt.clamp(min=1) / self.max_episode_length_s
+            self._user_log[i] = torch.where(any_reset, new, self._user_log[i])
+            s.masked_fill_(mask_b, 0.0)
+        for i, v in enumerate(dones):
+            self._user_log[nr + i] = torch.where(any_reset, torch.logical_and(v, mask_b).sum().to(torch.float32), self._user_log[nr + i])
+        _lib.check(self._lib.rover_step_finish(self._h, _ptr(self._reset_mask), self._obs_ptr[k], self._force_ptr, self._log_ptr, st),
+                   "rover_step_finish")
+        self._log_pending = False        # the second half reduces the built-in log eagerly
+        self.obs_buf = self._obs_dicts[k]
         return self.obs_buf, self.reward_buf, self.reset_terminated, self.reset_time_outs, self.extras
 
     def flush_log(self):

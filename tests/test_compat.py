@@ -101,12 +101,29 @@ def test_reference_learning_glue_imports(ref_env):
     assert exp["agent"]["rollouts"] == 60
 
 
-def test_unknown_term_in_reference_cfg_is_rejected(ref_env):
-    from omni.isaac.orbit.managers import RewardTermCfg
+def test_user_written_term_in_reference_cfg_is_kept(ref_env):
+    """The reference's term tables hold arbitrary ``func=`` (rover_env_cfg.py:126-183): a callable under a new key is a user-written
+    term and survives the conversion (RoverEnv evaluates it on its slow path); what is NOT a callable, or a foreign function under a
+    built-in key, still raises."""
+    from omni.isaac.orbit.managers import RewardTermCfg, TerminationTermCfg
     from omni.isaac.orbit_tasks.utils import parse_env_cfg
+    from isaac_rover_orbit_amd.cfg import REWARD_ORDER, TERMINATION_ORDER
     from isaac_rover_orbit_amd.compat.convert import from_reference_cfg
     cfg = parse_env_cfg("AAURoverEnv-v0", num_envs=8)
-    cfg.rewards.my_bonus = RewardTermCfg(func=lambda env: 0, weight=1.0)
+    bonus = lambda env, scale: scale          # noqa: E731
+    cfg.rewards.my_bonus = RewardTermCfg(func=bonus, weight=1.5, params={"scale": 2.0})
+    cfg.terminations.my_stop = TerminationTermCfg(func=lambda env: None, time_out=True)
+    out = from_reference_cfg(cfg)
+    assert list(out.rewards) == REWARD_ORDER + ["my_bonus"] and out.rewards["my_bonus"].func is bonus
+    assert out.rewards["my_bonus"].weight == 1.5 and out.rewards["my_bonus"].params == {"scale": 2.0}
+    assert list(out.terminations) == TERMINATION_ORDER + ["my_stop"] and out.terminations["my_stop"].time_out and out.has_custom_terms
+    assert not from_reference_cfg(parse_env_cfg("AAURoverEnv-v0", num_envs=8)).has_custom_terms       # the stock table: fast path
+    cfg = parse_env_cfg("AAURoverEnv-v0", num_envs=8)
+    cfg.rewards.my_bonus = RewardTermCfg(func="not a callable", weight=1.0)
+    with pytest.raises(ValueError):
+        from_reference_cfg(cfg)
+    cfg = parse_env_cfg("AAURoverEnv-v0", num_envs=8)
+    cfg.rewards.oscillation = RewardTermCfg(func=bonus, weight=1.0)           # a built-in key with a foreign function
     with pytest.raises(ValueError):
         from_reference_cfg(cfg)
 

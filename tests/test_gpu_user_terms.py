@@ -1,0 +1,213 @@
+"""User-written reward / termination terms ("user-written terms still run (slow path)"; the reference's term tables,
+rover_env_cfg.py:126-183, hold arbitrary ``func=``): a cfg entry whose func is a callable switches ``RoverEnv.step`` to
+rover_step_begin -> torch evaluation on the env's facades -> rover_step_finish, with ORBIT's manager semantics (App. C).
+The stock table keeps the one-launch fast path."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(n, ter, rewards=None, terminations=None, seed=7):
+    from isaac_rover_orbit_amd.cfg import RoverEnvCfg, TermCfg
+    from isaac_rover_orbit_amd.envs import RoverEnv
+    cfg = RoverEnvCfg()
+    cfg.scene.num_envs = n
+    cfg.terrain.kind = "custom"
+    cfg.seed = seed
+    for k, v in (rewards or {}).items():
+        cfg.rewards[k] = TermCfg(*v) if isinstance(v, tuple) else v
+    for k, v in (terminations or {}).items():
+        cfg.terminations[k] = v
+    return RoverEnv(cfg, terrain=ter)
+
+
+@pytest.fixture(scope="module")
+def terrain():
+    from isaac_rover_orbit_amd import terrain as T
+    ter = T.make_procedural_terrain((1024, 1024), seed=5, n_rocks=120)
+    ter.make_spawns(2 * 2048, seed=41)
+    return ter
+
+
+class _AssetCfg:      # duck-typed SceneEntityCfg (omni.isaac.orbit.managers.SceneEntityCfg has a .name)
+    def __init__(self, name):
+        self.name = name
+
+
+def test_stock_table_keeps_the_one_launch_fast_path(terrain):
+    env = _make(2048, terrain)
+    assert not env._slow_path
+    env.reset()
+    env.step(torch.zeros(2048, 2, device=env.device))
+    assert env.kernel_names()[0].startswith("rover_step_scan"), env.kernel_names()      # ONE kernel per step
+    assert [k for k in env.extras["log"] if "Episode Reward" in k] == [f"Episode Reward/{k}" for k in
+           ["distance_to_target", "reached_target", "oscillation", "angle_to_target", "heading_soft_contraint", "collision", "far_from_target"]]
+    env.close()
+
+
+def test_inert_user_terms_reproduce_the_fast_path_bit_for_bit(terrain):
+    """The two halves of the step around user terms that contribute nothing == the one-launch step: observations, rewards,
+    flags, every state word and the log vector, resets included (some envs start one step from their time-out)."""
+    from isaac_rover_orbit_amd.cfg import TermCfg
+    n = 2048
+    fast = _make(n, terrain)
+    slow = _make(n, terrain,
+                 rewards={"nothing": TermCfg(lambda env: torch.zeros(env.num_envs, device=env.device), weight=1.0)},
+                 terminations={"never": TermCfg(lambda env: torch.zeros(env.num_envs, dtype=torch.bool, device=env.device))})
+    assert slow._slow_path and not fast._slow_path
+    fast.reset(); slow.reset()
+    S = fast.get_state()
+    S[::29, 51] = torch.tensor([745], dtype=torch.int32).view(torch.float32).item()    # time-outs a few steps from now
+    fast.set_state(S); slow.set_state(S)
+    g = torch.Generator(device=fast.device).manual_seed(3)
+    acts = torch.rand(40, n, 2, device=fast.device, generator=g) * 2 - 1
+    resets = 0
+    for k in range(40):
+        of, rf, tf, uf, _ = fast.step(acts[k])
+        os_, rs, ts, us, _ = slow.step(acts[k])
+        assert torch.equal(of["policy"].view(torch.int32), os_["policy"].view(torch.int32)), f"obs step {k}"
+        assert torch.equal(rf.view(torch.int32), rs.view(torch.int32)), f"reward step {k}"
+        assert torch.equal(tf, ts) and torch.equal(uf, us), f"flags step {k}"
+        # the log vector is a sum over the envs that reset: per-wave partials of 4 envs (fast path, sixteen lanes per env) against
+        # partials of 64 envs (the slow path runs one env per lane) -- the same terms in another order, equal to rounding
+        lf, ls = fast.episode_log_vector, slow.episode_log_vector
+        assert torch.allclose(lf, ls, rtol=2e-6, atol=1e-9) and torch.equal(lf[7:11], ls[7:11]) and lf[13] == ls[13], f"log step {k}"
+        resets += int((tf | uf).sum())
+    assert resets > 50
+    assert torch.equal(fast.get_state().view(torch.int32), slow.get_state().view(torch.int32))
+    assert float(slow.extras["log"]["Episode Reward/nothing"]) == 0.0 and float(slow.extras["log"]["Episode Termination/never"]) == 0.0
+    fast.close(); slow.close()
+
+
+def test_user_reward_and_terminations_follow_orbit_semantics(terrain):
+    """A duck-typed ``upright_penalty(env, asset_cfg, sensor_cfg)`` reading the height scanner's ``pos_w`` and the robot's
+    orientation, a user termination and a user time-out: what the functions SEE (stale command B-13, incremented counter B-14,
+    post-physics pose, contact forces, ray hits of that pose), and reward / flag / reset / log arithmetic, against a torch
+    evaluation and a fast-path twin (bit-exact wherever the twin still shares the env's history)."""
+    from isaac_rover_orbit_amd.cfg import TermCfg
+    n = 2048
+    seen = {}
+
+    def upright_penalty(env, asset_cfg, sensor_cfg):
+        q = env.scene[asset_cfg.name].data.root_quat_w
+        pos = env.scene.sensors[sensor_cfg.name].data.pos_w
+        seen["pos"], seen["quat"] = pos.clone(), q.clone()
+        seen["ep_len"] = env.episode_length_buf.clone()
+        seen["cmd"] = env.command_manager.get_command("target_pose").clone()
+        seen["action"], seen["prev_action"] = env.action_manager.action.clone(), env.action_manager.prev_action.clone()
+        seen["force"] = env.scene.sensors["contact_sensor"].data.force_matrix_w.clone()
+        seen["hits"] = env.scene.sensors[sensor_cfg.name].data.ray_hits_w.clone()
+        seen["origin"] = env.scene.terrain.env_origins.clone()
+        return (1.0 - (1.0 - 2.0 * (q[:, 1] ** 2 + q[:, 2] ** 2))) + 0.01 * pos[:, 2]
+
+    def wandered_off(env, radius):                                          # a time-out style term
+        d = env.scene.sensors["height_scanner"].data.pos_w[:, :2] - env.scene.terrain.env_origins[:, :2]
+        return torch.linalg.norm(d, dim=1) > radius
+
+    def reversing_hard(env, limit):                                         # a terminal term
+        return env.action_manager.action[:, 0] < limit
+
+    slow = _make(n, terrain,
+                 rewards={"upright": TermCfg(upright_penalty, weight=-0.3,
+                                             params={"asset_cfg": _AssetCfg("robot"), "sensor_cfg": _AssetCfg("height_scanner")})},
+                 terminations={"wandered_off": TermCfg(wandered_off, params={"radius": 0.9}, time_out=True),
+                               "reversing_hard": TermCfg(reversing_hard, params={"limit": -0.995})})
+    fast = _make(n, terrain)
+    slow.reset(); fast.reset()
+    assert "Episode Reward/upright" in slow.extras["log"] and "Episode Termination/wandered_off" in slow.extras["log"]
+    g = torch.Generator(device=fast.device).manual_seed(11)
+    acts = torch.rand(30, n, 2, device=fast.device, generator=g) * 2 - 1
+    clean = torch.ones(n, dtype=torch.bool, device=fast.device)             # envs no user termination has touched yet
+    sums = torch.zeros(n, device=fast.device)
+    dt, L_s = slow.step_dt, slow.max_episode_length_s
+    fired_to = fired_term = checked_logs = 0
+    for k in range(30):
+        prev_len = slow.episode_length_buf.clone()
+        prev_cmd = slow.command_manager.get_command("target_pose").clone()
+        prev_act = slow.action_manager.action.clone()
+        obs_s, rew_s, term_s, trunc_s, info = slow.step(acts[k])
+        obs_f, rew_f, term_f, trunc_f, _ = fast.step(acts[k])
+        term_s, trunc_s = term_s.clone(), trunc_s.clone()
+        # ---- what the user function saw
+        assert torch.equal(seen["ep_len"], prev_len + 1)                                    # B-14: incremented before the terms
+        assert torch.equal(seen["cmd"], prev_cmd)                                           # B-13: the previous step's command
+        assert torch.equal(seen["action"], acts[k]) and torch.equal(seen["prev_action"], prev_act)
+        alive = clean & ~(term_f | trunc_f)                                                 # twin env not reset by a built-in term
+        assert torch.equal(seen["pos"][alive], fast.scene.sensors["height_scanner"].data.pos_w[alive])   # the pose the physics left
+        assert torch.equal(seen["force"][clean], fast.scene.sensors["contact_sensor"].data.force_matrix_w[clean])
+        # the ray hits handed to a user term belong to THAT pose: z = pos.z - scan - offset of the twin's new observation row
+        hz = fast.scene.sensors["height_scanner"].data.pos_w[alive, 2:3] - obs_f["policy"][alive, 4:] - 0.26878
+        assert torch.allclose(seen["hits"][alive][..., 2], hz, atol=1e-6, equal_nan=True)
+        # ---- reward: built-in part (the twin's) + func * weight * dt, the same fp32 operations
+        q, pos = seen["quat"], seen["pos"]
+        val = ((1.0 - (1.0 - 2.0 * (q[:, 1] ** 2 + q[:, 2] ** 2))) + 0.01 * pos[:, 2]) * (-0.3 * dt)
+        assert torch.equal(rew_s[clean], (rew_f + val)[clean])
+        # ---- flags: built-in OR user terms; a time_out term lands in the time-outs
+        u_term = acts[k][:, 0] < -0.995
+        u_to = torch.linalg.norm(seen["pos"][:, :2] - seen["origin"][:, :2], dim=1) > 0.9
+        assert torch.equal(term_s[clean], (term_f | u_term)[clean])
+        assert torch.equal(trunc_s[clean], (trunc_f | u_to)[clean])
+        fired_term += int((u_term & clean).sum())
+        fired_to += int((u_to & clean).sum())
+        # ---- log: mean episodic sum of the envs reset in this step / max_episode_length_s, termination counts
+        sums += val
+        mask = term_s | trunc_s
+        if int(mask.sum()) > 0:
+            exp = (sums * mask).sum() / mask.sum() / L_s
+            assert math.isclose(float(info["log"]["Episode Reward/upright"]), float(exp), rel_tol=1e-5, abs_tol=1e-9)
+            assert float(info["log"]["Episode Termination/reversing_hard"]) == float((u_term & mask).sum())
+            assert float(info["log"]["Episode Termination/wandered_off"]) == float((u_to & mask).sum())
+            checked_logs += 1
+        sums[mask] = 0.0
+        # ---- every env that ended -- by a built-in or a user term -- was reset by the second half of the step
+        assert int(slow.episode_length_buf[mask].abs().sum()) == 0
+        assert bool((slow.episode_length_buf[~mask] == seen["ep_len"][~mask]).all())
+        clean &= ~((u_term & ~term_f) | (u_to & ~trunc_f))
+    assert fired_term > 0 and fired_to > 0 and checked_logs > 5, (fired_term, fired_to, checked_logs)
+    assert int(clean.sum()) > n // 4
+    slow.close(); fast.close()
+
+
+def test_reference_style_cfg_with_a_user_term_converts(terrain):
+    """compat.convert keeps a callable it does not know (rover_env_cfg.py:126-183 style table) instead of raising."""
+    from types import SimpleNamespace as NS
+    from isaac_rover_orbit_amd.cfg import REWARD_FUNCS, REWARD_ORDER, TERMINATION_FUNCS, TERMINATION_ORDER
+    from isaac_rover_orbit_amd.compat.convert import from_reference_cfg
+
+    def named(fn):
+        f = lambda env, **kw: None      # noqa: E731
+        f.__name__ = fn
+        return f
+
+    def my_bonus(env, scale):
+        return scale * torch.ones(env.num_envs, device=env.device)
+
+    rew = NS(**{k: NS(func=named(f), weight=1.0, params={"threshold": 0.18 if k == "reached_target" else 11.0}) for k, f in zip(REWARD_ORDER, REWARD_FUNCS)})
+    rew.my_bonus = NS(func=my_bonus, weight=2.0, params={"scale": 0.5})
+    ter = NS(**{k: NS(func=named(f), params={"threshold": 0.18 if k == "is_success" else 11.0}, time_out=(k == "time_limit"))
+                for k, f in zip(TERMINATION_ORDER, TERMINATION_FUNCS)})
+    obs = NS(actions=NS(func=named("last_action"), scale=None, params={}, noise=None, clip=None),
+             distance=NS(func=named("distance_to_target_euclidean"), scale=0.11, params={}, noise=None, clip=None),
+             heading=NS(func=named("angle_to_target_observation"), scale=1 / math.pi, params={}, noise=None, clip=None),
+             height_scan=NS(func=named("height_scan_rover"), scale=1, params={}, noise=None, clip=None))
+    ref = NS(scene=NS(num_envs=256, env_spacing=4.0,
+                      height_scanner=NS(pattern_cfg=NS(resolution=0.1, size=(3.0, 3.0)), offset=NS(pos=(0.0, 0.0, 10.0)), attach_yaw_only=True,
+                                        max_distance=100.0)),
+             sim=NS(dt=1 / 30.0, device="cuda:0"), decimation=6, episode_length_s=150.0,
+             actions=NS(actions=NS(scale=(1.0, 1.0), offset=-0.0135, wheelbase_length=0.849, middle_wheel_distance=0.894,
+                                   rear_and_front_wheel_distance=0.77, wheel_radius=0.1, min_steering_radius=0.8)),
+             observations=NS(policy=obs), rewards=rew, terminations=ter,
+             commands=NS(target_pose=NS(resampling_time_range=(150.0, 150.0), ranges=NS(heading=(-math.pi, math.pi)), simple_heading=False)))
+    cfg = from_reference_cfg(ref)
+    assert list(cfg.rewards) == REWARD_ORDER + ["my_bonus"] and cfg.rewards["my_bonus"].func is my_bonus and cfg.has_custom_terms
+    cfg.terrain.kind = "custom"
+    from isaac_rover_orbit_amd.envs import RoverEnv
+    env = RoverEnv(cfg, terrain=terrain)
+    env.reset()
+    _, r, _, _, info = env.step(torch.zeros(256, 2, device=env.device))
+    assert env._slow_path and "Episode Reward/my_bonus" in info["log"] and torch.isfinite(r).all()
+    env.close()
