@@ -652,9 +652,329 @@ __global__ __launch_bounds__(POL_THREADS) void rover_policy_ref_kernel(rover_pol
     extern __shared__ __align__(16) float lds[];
     ref_network<true>(d, L, packed, obs, n, out, lds);
 }
+// ---------------------------------------------------------------------------------------------------- actor + critic pair
 // Two networks of the reference architecture on the same observation rows in ONE launch (the policy mean and the value of a
-// rollout step): the 62 KB of rows per workgroup are fetched and staged once, the second network starts on a warm tile, and
-// one launch boundary disappears.  Same arithmetic per network as rover_policy_ref_kernel (the same device function).
+// rollout step), layer by layer TOGETHER -- not one network after the other (round 3: 34.8 us, 1.9 x one network):
+//   * layer 1 (961 -> 80, split-K): a wave carries the five column tiles of BOTH networks over its k range -- the A fragments
+//     (observation rows from the LDS tile) are read once for ten accumulator tiles, and the 2 x 307 KB of weights stream through
+//     a three-group register queue behind counted waits;
+//   * layers 2 .. 5: the column tiles of both networks are dealt to the eight waves as ONE list (tile tt = wave, wave + 8, ...;
+//     tt < T: actor, else critic), so a layer costs one barrier, one LDS round trip and one epilogue for the pair -- layer 2's
+//     eight tiles fill the eight waves (four of them idled with one network), layer 4's twenty are 3 + 2 per SIMD;
+//   * layer 6 (128 -> out, split-K over the waves): two MFMA chains per wave, the two combines side by side.
+// LDS: the carve of one network (tile | part | two activation buffers) -- the critic's layer-1 partials and its two activation
+// buffers live in the observation tile, which is dead once every wave has read its layer-1 A fragments (the four proprioceptive
+// columns are saved in registers first).
+// Per output element the arithmetic is the single network's: the same k-ordered chain per (network, tile), the same split-K
+// ranges and combine order -- bit-identical to two rover_policy_ref_kernel launches and to oracle/policy_oracle.c.
+// (Wt[i]: the WAVE-UNIFORM start of tile i's fragments -- the loads take it as a scalar base plus the lane's offset, one VGPR for
+// all tiles, instead of a 64-bit address pair per tile)
+template <int NT, int QD>
+__device__ __forceinline__ void pq_preload(v4f (&q)[QD][NT], const v4f *const (&Wt)[NT], int lane)
+{
+#pragma unroll
+    for (int u = 0; u < QD; ++u)
+#pragma unroll
+        for (int i = 0; i < NT; ++i) q[u][i] = Wt[i][u * 64 + lane];
+}
+// acc[i] += A_i[16 x 16 GC] x B_i for NT tiles, k groups 0 .. GC - 1 in order; the queue holds groups g .. g + QD - 1
+template <int NT, int GC, int QD>
+__device__ __forceinline__ void pq_run(v4f (&acc)[NT], const float *const (&ap)[NT], v4f (&q)[QD][NT], const v4f *const (&Wt)[NT], int lane)
+{
+    static_assert(QD <= GC, "queue deeper than the layer");
+#pragma unroll
+    for (int g = 0; g < GC; ++g) {
+        const int slot = g % QD;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[i][16 * g + 4 * j], q[slot][i][j], acc[i], 0, 0, 0);
+        if (g + QD < GC) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i) q[slot][i] = Wt[i][(g + QD) * 64 + lane];
+        }
+    }
+}
+// epilogue of one column tile of a full-K layer: bias, LeakyReLU, into an LDS activation buffer
+__device__ __forceinline__ void pq_store(const v4f &acc, float bv, float *dst, int pitch, int tile, int N, int rows, int arow, int akq,
+                                         float slope)
+{
+    float *pd = dst + 4 * akq * pitch + 16 * tile + arow;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (4 * akq + j < rows && 16 * tile + arow < N) pd[j * pitch] = activate(acc[j] + bv, ROVER_ACT_LEAKY_RELU, slope);
+}
+__device__ __forceinline__ void ref_pair_network(const rover_policy_desc &da, const rover_policy_desc &db, const PolLaunch &L,
+                                                 const float *__restrict__ packed_a, const float *__restrict__ packed_b,
+                                                 const float *__restrict__ obs, int n, float *__restrict__ out_a,
+                                                 float *__restrict__ out_b, float *lds)
+{
+    packed_a += (size_t)(blockIdx.x % (unsigned)L.n_copies) * L.copy_floats;
+    packed_b += (size_t)(blockIdx.x % (unsigned)L.n_copies) * L.copy_floats;
+    PSTAMP(0);
+    constexpr int OBS = 965, PROP = 4, ENC_OFF = 3;
+    constexpr int G1 = 61, GW1 = 8, T1 = 5, G2 = 5, G3 = 4, G4 = 16, G5 = 10;
+    constexpr int PP1 = 16 * T1 + 4;                         // row pitch of the layer-1 partials (five tiles)
+    constexpr int PP6 = 20;                                  // ... of the layer-6 partials (one tile)
+    const int pitch = L.act_pitch;
+    float *tile = lds;
+    float *partA = tile + L.tile_floats;
+    float *bufA0 = partA + L.part_floats, *bufA1 = bufA0 + POL_ROWS * pitch;
+    float *partB = tile;                                     // the critic's share of the tile region (see above)
+    float *bufB0 = tile + POL_WAVES * POL_ROWS * PP1, *bufB1 = tile;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = blockIdx.x * POL_ROWS;
+    const int rows = min(POL_ROWS, n - row0);
+    const float slope = da.leaky_slope;
+    const int arow = lane & 15, akq = lane >> 4;
+    auto Wof = [&](int net, int li) { return reinterpret_cast<const v4f *>((net ? packed_b : packed_a) + (net ? db : da).layers[li].w_off); };   // wave-uniform
+    auto Bof = [&](int net, int li) { return (net ? packed_b : packed_a) + (net ? db : da).layers[li].b_off; };
+
+    // ---- observation rows -> LDS by LDS-DMA, layer 1's first k group of both networks queued right behind the copy.  A group is 40
+    // MFMAs per wave (1.3 k cycles of the SIMD's MFMA unit, twice that with the second wave of the SIMD): one group of lead covers
+    // the L2 round trip of the next.  Measured (tools/policy_stamps.py pair, cycles: tile / layer 1 / whole kernel) for queue depths
+    // 1 / 2 / 3: 3.9 k / 27.9 k / 67.4 k, 5.4 k / 27.3 k / 68.5 k, 6.4 k / 26.3 k / 68.8 k -- layer 1 is bound by the MFMA unit (20.5 k
+    // of its 27 k), and fragments queued behind the copy only slow the copy down.
+#ifndef POL_QD1
+#define POL_QD1 1
+#endif
+#ifndef POL_QD4
+#define POL_QD4 4
+#endif
+#ifndef POL_QD5
+#define POL_QD5 3
+#endif
+    constexpr int QD1 = POL_QD1;
+    const bool full1 = wave < 7;
+    v4f q1[QD1][2 * T1];
+    const v4f *W1[2 * T1];
+#pragma unroll
+    for (int i = 0; i < 2 * T1; ++i) W1[i] = Wof(i >= T1, 0) + ((size_t)(i % T1) * G1 + (size_t)wave * GW1) * 64;
+    {
+        const float *src = obs + (size_t)row0 * OBS;
+        const int total = rows * OBS, total_pad = POL_ROWS * OBS;
+        const bool dma = rows == POL_ROWS && (total & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+        if (dma) {
+            const v4f *s4 = reinterpret_cast<const v4f *>(src);
+            v4f *t4 = reinterpret_cast<v4f *>(tile);
+            constexpr int n4 = POL_ROWS * OBS / 4;
+            const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
+#pragma unroll
+            for (int i0 = 0; i0 < n4; i0 += POL_THREADS)
+                if (i0 + tid < n4)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(s4 + i0 + tid),
+                                                     (__attribute__((address_space(3))) void *)(t4 + i0 + wave_base), 16, 0, 0);
+        } else {
+            for (int i = tid; i < total_pad; i += POL_THREADS) tile[i] = i < total ? src[i] : 0.0f;
+        }
+        asm volatile("" ::: "memory");   // the weight loads below stay BEHIND the copy in issue order (the counted wait relies on it)
+        if (full1) {
+            pq_preload<2 * T1, QD1>(q1, W1, lane);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QD1 * 2 * T1) : "memory");     // the copy, not the fragments queued behind it
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();   // the tile is complete
+    PSTAMP(1);
+    const float prop = tid < POL_ROWS * PROP ? tile[(tid >> 2) * OBS + (tid & 3)] : 0.0f;   // models.py:93-96, saved before the tile is reused
+
+    // ---- layer 1 of both networks: 961 -> 80, split-K over the waves
+    v4f acc1[2 * T1];
+#pragma unroll
+    for (int i = 0; i < 2 * T1; ++i) acc1[i] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+    {
+        const float *a1 = tile + ENC_OFF + arow * OBS;
+        if (full1) {
+            const float *ap[2 * T1];
+#pragma unroll
+            for (int i = 0; i < 2 * T1; ++i) ap[i] = a1 + 16 * (wave * GW1) + akq;
+            pq_run<2 * T1, GW1, QD1>(acc1, ap, q1, W1, lane);
+        } else {   // the ragged end (k groups 56 .. 60, the last one a single input): the generic queue, one network after the other
+            v4f accA[T1], accB[T1];
+#pragma unroll
+            for (int i = 0; i < T1; ++i) { accA[i] = (v4f){0.0f, 0.0f, 0.0f, 0.0f}; accB[i] = (v4f){0.0f, 0.0f, 0.0f, 0.0f}; }
+            mfma_groups<T1, POL_PF>(accA, a1, akq, da.layers[0].K, Wof(0, 0) + lane, (size_t)G1 * 64, 7 * GW1, G1, G1);
+            mfma_groups<T1, POL_PF>(accB, a1, akq, db.layers[0].K, Wof(1, 0) + lane, (size_t)G1 * 64, 7 * GW1, G1, G1);
+#pragma unroll
+            for (int i = 0; i < T1; ++i) { acc1[i] = accA[i]; acc1[T1 + i] = accB[i]; }
+        }
+    }
+    // layer 2's fragments (eight column tiles for eight waves: waves 0 .. 3 the actor's, 4 .. 7 the critic's) travel under the combine
+    const int net2 = wave >> 2, t2 = wave & 3;
+    v4f q2[G2][1];
+    const v4f *W2[1] = {Wof(net2, 1) + (size_t)t2 * G2 * 64};
+    pq_preload<1, G2>(q2, W2, lane);
+    const float bv2 = Bof(net2, 1)[min(16 * t2 + arow, da.layers[1].N - 1)];
+    __syncthreads();   // every wave has read its layer-1 A fragments: the tile region is free
+    {
+        float *pa = partA + (wave * POL_ROWS + 4 * akq) * PP1 + arow, *pb = partB + (wave * POL_ROWS + 4 * akq) * PP1 + arow;
+#pragma unroll
+        for (int i = 0; i < T1; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { pa[j * PP1 + 16 * i] = acc1[i][j]; pb[j * PP1 + 16 * i] = acc1[T1 + i][j]; }
+    }
+    __syncthreads();
+    {   // combine: ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)), bias, LeakyReLU; 16 x 80 outputs per network
+        const int N1 = da.layers[0].N;
+        const float *b1a = Bof(0, 0), *b1b = Bof(1, 0);
+        for (int e = tid; e < 2 * POL_ROWS * 16 * T1; e += POL_THREADS) {
+            const int net = e >= POL_ROWS * 16 * T1, ee = e - net * POL_ROWS * 16 * T1;
+            const int r = (int)(((float)ee + 0.5f) * (1.0f / (float)(16 * T1))), c = ee - r * 16 * T1;
+            const float *pp = (net ? partB : partA) + r * PP1 + c;
+            float qq[POL_WAVES];
+#pragma unroll
+            for (int w = 0; w < POL_WAVES; ++w) qq[w] = pp[w * POL_ROWS * PP1];
+            const float sum = ((qq[0] + qq[1]) + (qq[2] + qq[3])) + ((qq[4] + qq[5]) + (qq[6] + qq[7]));
+            if (r < rows && c < N1) (net ? bufB0 : bufA0)[r * pitch + c] = activate(sum + (net ? b1b : b1a)[c], ROVER_ACT_LEAKY_RELU, slope);
+        }
+    }
+    PSTAMP(2);
+    // layer 3's fragments: tiles tt = wave + 8 i of 32 (tt < 16: actor tile tt, else critic tile tt - 16)
+    v4f q3[G3][4];
+    const v4f *W3[4];
+    float bv3[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int tt = wave + POL_WAVES * i, net = tt >> 4, t = tt & 15;
+        W3[i] = Wof(net, 2) + (size_t)t * G3 * 64;
+        bv3[i] = Bof(net, 2)[16 * t + arow];
+    }
+    pq_preload<4, G3>(q3, W3, lane);
+    __syncthreads();   // bufA0 / bufB0 = layer 1's activations; partB is dead (bufB1 overlays it)
+
+    // ---- layer 2: 80 -> 60 into buf?1[:, 4 ..], the proprioceptive columns in front
+    {
+        v4f acc[1] = {(v4f){0.0f, 0.0f, 0.0f, 0.0f}};
+        const float *ap[1] = {(net2 ? bufB0 : bufA0) + arow * pitch + akq};
+        pq_run<1, G2, G2>(acc, ap, q2, W2, lane);
+        pq_store(acc[0], bv2, (net2 ? bufB1 : bufA1) + PROP, pitch, t2, da.layers[1].N, rows, arow, akq, slope);
+    }
+    if (tid < POL_ROWS * PROP) {
+        bufA1[(tid >> 2) * pitch + (tid & 3)] = prop;
+        bufB1[(tid >> 2) * pitch + (tid & 3)] = prop;
+    }
+    PSTAMP(3);
+    // layer 4's fragments: twenty tiles, tt = wave + 8 i: three for waves 0 .. 3, two for waves 4 .. 7; the first six k groups
+    constexpr int QD4 = POL_QD4;
+    const bool three4 = wave < 4;
+    v4f q4[QD4][3];
+    const v4f *W4[3];
+    float bv4[3];
+    int net4[3], t4[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int tt = min(wave + POL_WAVES * i, 19);
+        net4[i] = tt >= 10; t4[i] = tt - 10 * net4[i];
+        W4[i] = Wof(net4[i], 3) + (size_t)t4[i] * G4 * 64;
+        bv4[i] = Bof(net4[i], 3)[16 * t4[i] + arow];
+    }
+    if (three4) {
+        pq_preload<3, QD4>(q4, W4, lane);
+    } else {
+        v4f q42[QD4][2];
+        const v4f *W42[2] = {W4[0], W4[1]};
+        pq_preload<2, QD4>(q42, W42, lane);
+#pragma unroll
+        for (int u = 0; u < QD4; ++u) { q4[u][0] = q42[u][0]; q4[u][1] = q42[u][1]; }
+    }
+    __syncthreads();   // buf?1 = the MLP inputs
+
+    // ---- layer 3: 64 -> 256 into buf?0
+    {
+        v4f acc[4];
+        const float *ap[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[i] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+            ap[i] = (i >= 2 ? bufB1 : bufA1) + arow * pitch + akq;      // tt = wave + 8 i: i < 2 actor, else critic
+        }
+        pq_run<4, G3, G3>(acc, ap, q3, W3, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            pq_store(acc[i], bv3[i], i >= 2 ? bufB0 : bufA0, pitch, (wave + POL_WAVES * i) & 15, da.layers[2].N, rows, arow, akq, slope);
+    }
+    PSTAMP(4);
+    // layer 5's fragments: actor tile `wave`, critic tile `wave`; the first five of ten k groups
+    constexpr int QD5 = POL_QD5;
+    v4f q5[QD5][2];
+    const v4f *W5[2] = {Wof(0, 4) + (size_t)wave * G5 * 64, Wof(1, 4) + (size_t)wave * G5 * 64};
+    const float bv5[2] = {Bof(0, 4)[16 * wave + arow], Bof(1, 4)[16 * wave + arow]};
+    pq_preload<2, QD5>(q5, W5, lane);
+    __syncthreads();   // buf?0 = layer 3's activations
+
+    // ---- layer 4: 256 -> 160 into buf?1
+    if (three4) {
+        v4f acc[3];
+        const float *ap[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            acc[i] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+            ap[i] = (net4[i] ? bufB0 : bufA0) + arow * pitch + akq;
+        }
+        pq_run<3, G4, QD4>(acc, ap, q4, W4, lane);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pq_store(acc[i], bv4[i], net4[i] ? bufB1 : bufA1, pitch, t4[i], da.layers[3].N, rows, arow, akq, slope);
+    } else {
+        v4f acc[2];
+        const float *ap[2];
+        v4f q42[QD4][2];
+        const v4f *W42[2] = {W4[0], W4[1]};
+#pragma unroll
+        for (int u = 0; u < QD4; ++u) { q42[u][0] = q4[u][0]; q42[u][1] = q4[u][1]; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            acc[i] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+            ap[i] = (net4[i] ? bufB0 : bufA0) + arow * pitch + akq;
+        }
+        pq_run<2, G4, QD4>(acc, ap, q42, W42, lane);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) pq_store(acc[i], bv4[i], net4[i] ? bufB1 : bufA1, pitch, t4[i], da.layers[3].N, rows, arow, akq, slope);
+    }
+    PSTAMP(5);
+    // layer 6's fragments (split-K: k group `wave` of 8, the one column tile of each network) travel under layer 5
+    const v4f f6a = Wof(0, 5)[wave * 64 + lane], f6b = Wof(1, 5)[wave * 64 + lane];
+    __syncthreads();   // buf?1 = layer 4's activations
+
+    // ---- layer 5: 160 -> 128 into buf?0
+    {
+        v4f acc[2] = {(v4f){0.0f, 0.0f, 0.0f, 0.0f}, (v4f){0.0f, 0.0f, 0.0f, 0.0f}};
+        const float *ap[2] = {bufA1 + arow * pitch + akq, bufB1 + arow * pitch + akq};
+        pq_run<2, G5, QD5>(acc, ap, q5, W5, lane);
+        pq_store(acc[0], bv5[0], bufA0, pitch, wave, da.layers[4].N, rows, arow, akq, slope);
+        pq_store(acc[1], bv5[1], bufB0, pitch, wave, db.layers[4].N, rows, arow, akq, slope);
+    }
+    PSTAMP(6);
+    __syncthreads();   // buf?0 = layer 5's activations
+
+    // ---- layer 6: 128 -> out, split-K with one k group per wave, both networks; partials through partA ([0, 2560) actor, then critic)
+    {
+        v4f acA = (v4f){0.0f, 0.0f, 0.0f, 0.0f}, acB = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+        const float *apA = bufA0 + arow * pitch + 16 * wave + akq, *apB = bufB0 + arow * pitch + 16 * wave + akq;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acA = __builtin_amdgcn_mfma_f32_16x16x4f32(apA[4 * j], f6a[j], acA, 0, 0, 0);
+            acB = __builtin_amdgcn_mfma_f32_16x16x4f32(apB[4 * j], f6b[j], acB, 0, 0, 0);
+        }
+        float *pw = partA + (wave * POL_ROWS + 4 * akq) * PP6 + arow;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pw[j * PP6] = acA[j]; pw[POL_WAVES * POL_ROWS * PP6 + j * PP6] = acB[j]; }
+        __syncthreads();
+        const int net = tid >> 8, e = tid & 255, r = e >> 4, c = e & 15;
+        const rover_policy_desc &d = net ? db : da;
+        const int N = d.layers[5].N, act = d.layers[5].act;
+        const float *pp = partA + net * POL_WAVES * POL_ROWS * PP6 + r * PP6 + c;
+        float qq[POL_WAVES];
+#pragma unroll
+        for (int w = 0; w < POL_WAVES; ++w) qq[w] = pp[w * POL_ROWS * PP6];
+        const float sum = ((qq[0] + qq[1]) + (qq[2] + qq[3])) + ((qq[4] + qq[5]) + (qq[6] + qq[7]));
+        float *dst = (net ? out_b : out_a) + (size_t)row0 * N;
+        if (r < rows && c < N) dst[r * N + c] = activate(sum + Bof(net, 5)[c], act, d.leaky_slope);
+    }
+    PSTAMP(7);
+}
 __global__ __launch_bounds__(POL_THREADS) void rover_policy_ref_pair_kernel(rover_policy_desc da, rover_policy_desc db, PolLaunch La,
                                                                             PolLaunch Lb, const float *__restrict__ packed_a,
                                                                             const float *__restrict__ packed_b,
@@ -662,8 +982,13 @@ __global__ __launch_bounds__(POL_THREADS) void rover_policy_ref_pair_kernel(rove
                                                                             float *__restrict__ out_a, float *__restrict__ out_b)
 {
     extern __shared__ __align__(16) float lds[];
+#ifdef POL_PAIR_SEQUENTIAL   // round 3's form: one network after the other on the staged tile
     ref_network<true>(da, La, packed_a, obs, n, out_a, lds);
     ref_network<false>(db, Lb, packed_b, obs, n, out_b, lds);
+#else
+    (void)Lb;                // same carve for both networks (identical shapes up to the last layer's width)
+    ref_pair_network(da, db, La, packed_a, packed_b, obs, n, out_a, out_b, lds);
+#endif
 }
 
 // the shapes rover_policy_ref_kernel is written for

@@ -52,6 +52,8 @@ VARIANTS = {"STAMP": ("rover_kernels.hip", "-DRV_K2_STAMP"), "K1STAMP": ("rover_
             "Q_S4_12": ("rover_kernels.hip", "-DRV_SHARE_FREE=4 -DRV_SHARE_COPY=12"), "Q_S8_12": ("rover_kernels.hip", "-DRV_SHARE_FREE=8 -DRV_SHARE_COPY=12"),
             "Q_S4_16": ("rover_kernels.hip", "-DRV_SHARE_FREE=4 -DRV_SHARE_COPY=16"), "Q_S8_16": ("rover_kernels.hip", "-DRV_SHARE_FREE=8 -DRV_SHARE_COPY=16"),
             "Q_S0_12": ("rover_kernels.hip", "-DRV_SHARE_FREE=0 -DRV_SHARE_COPY=12"), "Q_S4_8": ("rover_kernels.hip", "-DRV_SHARE_FREE=4 -DRV_SHARE_COPY=8"),
+            "P_QD1_3": ("policy_kernels.hip", "-DPOL_STAMP -DPOL_QD1=3"), "P_QD4_8": ("policy_kernels.hip", "-DPOL_STAMP -DPOL_QD4=8 -DPOL_QD5=10"),
+            "P_QD4_4": ("policy_kernels.hip", "-DPOL_STAMP -DPOL_QD4=4 -DPOL_QD5=3"), "P_QD1_1": ("policy_kernels.hip", "-DPOL_STAMP -DPOL_QD1=1"),
             "Q_NOLINK": ("rover_kernels.hip", "-DRV_X_NOLINK"), "Q_NODRAW": ("rover_kernels.hip", "-DRV_X_NODRAW"),
             "Q_NOSTORE": ("rover_kernels.hip", "-DRV_X_NOSTORE"), "Q_NOLDS": ("rover_kernels.hip", "-DRV_X_NOLDS"),
             "Q_NOBOTH": ("rover_kernels.hip", "-DRV_X_NOLDS -DRV_X_NOSTORE"), "Q_BASE": ("rover_kernels.hip", "-DRV_Q_BASE"),
