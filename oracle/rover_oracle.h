@@ -132,6 +132,10 @@ void rvo_step(const rvo_config *cfg, const rvo_terrain *t, int n, int env_id_off
               uint8_t *truncated, float *force /* n x 13 x 3 */, float *log_out /* RVO_LOG_WORDS */);
 int rvo_num_threads(void);
 void rvo_set_num_threads(int n); /* 0 = OpenMP default */
+/* study variants of the dynamics model (rover_oracle.c: bit 0 triangle-surface wheel contact, bit 1 coupled 9 x 9 mass matrix + PGS);
+ * 0 = the model the HIP path implements -- tests, smoke and bench never set anything else */
+void rvo_set_model_variant(int v);
+int rvo_get_model_variant(void);
 
 #ifdef __cplusplus
 }

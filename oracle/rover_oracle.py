@@ -74,6 +74,8 @@ def lib():
         _lib.rvo_num_threads.restype = C.c_int
         _lib.rvo_model_constants.restype = C.c_int
         assert _lib.rvo_state_words() == STATE_WORDS
+        if os.environ.get("RVO_MODEL_VARIANT"):   # dynamics study only (tools/dynamics_study.py): the physics checks under a variant
+            _lib.rvo_set_model_variant(int(os.environ["RVO_MODEL_VARIANT"]))
     return _lib
 
 
@@ -254,6 +256,12 @@ def step(cfg: Config, t: TerrainData, state, action, env_id_offset=0, log=None):
 def set_num_threads(n: int):
     """Threads of the OpenMP loops (0 = the OpenMP default = all host cores)."""
     lib().rvo_set_num_threads(int(n))
+
+
+def set_model_variant(v: int):
+    """Study variants of the dynamics model (rover_oracle.c): bit 0 = wheel contact on the triangle surface,
+    bit 1 = coupled 9 x 9 mass matrix + sequential PGS.  0 = the model the HIP path implements (the only value tests use)."""
+    lib().rvo_set_model_variant(int(v))
 
 
 def max_threads() -> int:
