@@ -572,15 +572,22 @@ __device__ __forceinline__ LinkSample link_point_fetch(const RvParams &p, const 
     s.o00 = o[0]; s.o01 = o[1]; s.o10 = o[p.W]; s.o11 = o[p.W + 1];
     return s;
 }
-__device__ __forceinline__ float link_point_eval(const LinkSample &s)
+// force[3]: along the obstacle surface's un-normalised normal (-gx, -gy, 1): vertical component k x penetration (the value
+// round 3 reported alone), horizontal components from the slope of the surface patch under the point
+__device__ __forceinline__ void link_point_eval(const LinkSample &s, float inv_res, float *force)
 {
-    const float dx0 = s.h01 - s.h00, dx1 = s.h11 - s.h10;
+    const float dx0 = s.h01 - s.h00, dx1 = s.h11 - s.h10, dy0 = s.h10 - s.h00, dy1 = s.h11 - s.h01;
     const float hx0 = s.h00 + s.fx * dx0, hx1 = s.h10 + s.fx * dx1;
     const float hgt = hx0 + s.fy * (hx1 - hx0);
+    const float gx = (dx0 + s.fy * (dx1 - dx0)) * inv_res;
+    const float gy = (dy0 + s.fx * (dy1 - dy0)) * inv_res;
     const float o0 = s.o00 + s.fx * (s.o01 - s.o00), o1 = s.o10 + s.fx * (s.o11 - s.o10);
     const float obst = o0 + s.fy * (o1 - o0);
     const float pen = hgt - s.z;
-    return (obst > RV_OBSTACLE_EPS && pen > 0.0f) ? RV_LINK_STIFFNESS * pen : 0.0f;
+    const float fz = (obst > RV_OBSTACLE_EPS && pen > 0.0f) ? RV_LINK_STIFFNESS * pen : 0.0f;
+    force[0] = -gx * fz;
+    force[1] = -gy * fz;
+    force[2] = fz;
 }
 // the obstacle-layer height of a sample (terrain_sample<true>'s `obst`: same cell, same weights, same operations)
 __device__ __forceinline__ float link_sample_obstacle(const LinkSample &s)
@@ -588,18 +595,18 @@ __device__ __forceinline__ float link_sample_obstacle(const LinkSample &s)
     const float o0 = s.o00 + s.fx * (s.o01 - s.o00), o1 = s.o10 + s.fx * (s.o11 - s.o10);
     return o0 + s.fy * (o1 - o0);
 }
-__device__ __forceinline__ float link_point_force(const RvParams &p, const float R[3][3], const float *pos, const float *P,
-                                                  const float *ax, float bq, const float *p0)
+__device__ __forceinline__ void link_point_force(const RvParams &p, const float R[3][3], const float *pos, const float *P,
+                                                 const float *ax, float bq, const float *p0, float *force)
 {
-    return link_point_eval(link_point_fetch(p, R, pos, P, ax, bq, p0));
+    link_point_eval(link_point_fetch(p, R, pos, P, ax, bq, p0), p.inv_res, force);
 }
-// z rows of the seven link bodies from the twelve point forces lf[slot][role]: fixed summation order
-__device__ __forceinline__ void link_body_forces(const float lf[6][2], float *Fz /* 7 */)
+// one component of the rows of the seven link bodies from the twelve point forces lf[slot][role]: fixed summation order
+__device__ __forceinline__ void link_body_forces(const float lf[6][2], float *Fb /* 7 */)
 {
-    Fz[0] = (lf[0][1] + lf[1][0]) + lf[1][1];   // FL_Boogie
-    Fz[1] = (lf[2][1] + lf[3][0]) + lf[3][1];   // FR_Boogie
-    Fz[2] = lf[4][1] + lf[5][1];                // R_Boogie
-    Fz[3] = lf[0][0]; Fz[4] = lf[2][0]; Fz[5] = lf[4][0]; Fz[6] = lf[5][0];   // FL, FR, RL, RR steer
+    Fb[0] = (lf[0][1] + lf[1][0]) + lf[1][1];   // FL_Boogie
+    Fb[1] = (lf[2][1] + lf[3][0]) + lf[3][1];   // FR_Boogie
+    Fb[2] = lf[4][1] + lf[5][1];                // R_Boogie
+    Fb[3] = lf[0][0]; Fb[4] = lf[2][0]; Fb[5] = lf[4][0]; Fb[6] = lf[5][0];   // FL, FR, RL, RR steer
 }
 // contact geometry, Jacobians, split effective masses and bias of ONE wheel.  GROUP_ROLE: the 16-lanes-per-env mapping, where
 // the two role lanes of a wheel slot share the row work: role A derives the normal row, role B the longitudinal one, both
@@ -930,7 +937,7 @@ __device__ __forceinline__ void physics_substep(const RvParams &p, const StepCon
     }
     if (RECORD_FORCE) {   // link bodies (bogies, steer links): pose of the substep's start, like the wheel rows
         constexpr float LINK_POINT[6][2][3] = RV_LINK_POINT_INIT;
-        float lf[6][2], Fz[7];
+        float lf3[3][6][2], Fb[7];
 #pragma unroll
         for (int s = 0; s < 6; ++s) {
             const int j = s >> 1;
@@ -939,12 +946,17 @@ __device__ __forceinline__ void physics_substep(const RvParams &p, const StepCon
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const float p0[3] = {LINK_POINT[s][r][0], LINK_POINT[s][r][1], LINK_POINT[s][r][2]};
-                lf[s][r] = link_point_force(p, R, S + ROVER_POS, P, ax, bq[j], p0);
+                float f3[3];
+                link_point_force(p, R, S + ROVER_POS, P, ax, bq[j], p0, f3);
+                lf3[0][s][r] = f3[0]; lf3[1][s][r] = f3[1]; lf3[2][s][r] = f3[2];
             }
         }
-        link_body_forces(lf, Fz);
 #pragma unroll
-        for (int b = 0; b < 7; ++b) F[b * 3 + 2] = Fz[b];
+        for (int i = 0; i < 3; ++i) {
+            link_body_forces(lf3[i], Fb);
+#pragma unroll
+            for (int b = 0; b < 7; ++b) F[b * 3 + i] = Fb[b];
+        }
     }
     // ---- 7. integrate
     chassis_integrate(h, R, v, w, com_w, S + ROVER_POS, S + ROVER_QUAT, S + ROVER_LINVEL, S + ROVER_ANGVEL);
@@ -1146,7 +1158,7 @@ __device__ __forceinline__ void solver_iterations_group(const StepConsts &K, Con
 // is left alone here.
 template <bool RECORD_FORCE, bool LINK_ELSEWHERE = false>
 __device__ __forceinline__ void physics_substep_group(const RvParams &p, const StepConsts &K, GroupLane &g,
-                                                      float *Fw /* 3: this wheel's force, [3]: this lane's link-point force */,
+                                                      float *Fw /* [0..2]: this wheel's force, [3..5]: this lane's link-point force */,
                                                       int sidx = 0)
 {
     K1_STAMP(2 + 3 * sidx);
@@ -1171,7 +1183,7 @@ __device__ __forceinline__ void physics_substep_group(const RvParams &p, const S
     LinkSample ls;
     if (RECORD_FORCE && !LINK_ELSEWHERE) ls = link_point_fetch(p, R, g.pos, g.P, g.ax, bq, g.lp);      // pose of the substep's start, like the wheel rows
     wheel_geometry<RECORD_FORCE && !LINK_ELSEWHERE, true>(p, K, R, g.pos, com_w, g.arm, g.P, g.ax, g.b_winv, bq, at_hi, at_lo, g.steerable, g.sq, ct, g.role_b);
-    if (RECORD_FORCE && !LINK_ELSEWHERE) Fw[3] = link_point_eval(ls);
+    if (RECORD_FORCE && !LINK_ELSEWHERE) link_point_eval(ls, p.inv_res, Fw + 3);
     K1_STAMP(3 + 3 * sidx);
     ct.ln = RV_WARM_START * g.lam;
     ct.lt = 0.0f;
@@ -2189,10 +2201,10 @@ __device__ __forceinline__ void windows_from_lds(const float *win, PrivateWindow
 }
 // LDS of the copy-wave form behind the eight tiles: windows [4 waves][2 sets][4 envs][8] floats (1 KB), then per step wave
 // RV_HAND floats of hand-over: [0, 48) rotation matrix + position of its four envs at the START of the last substep,
-// [64, 128) the bogie angle of every lane, [128, 192) the lane's link-point force and [192, 256) the obstacle-layer height under
-// the lane's wheel, both written by its twin in the copy wave, [256, 304) the reset outcomes of the four envs (12 floats each:
-// reset_draw evaluated by the copy wave during the physics).
-constexpr int RV_HAND = 320;
+// [64, 128) the bogie angle of every lane, [128, 192) the lane's link-point force (z; x and y: [320, 384), [384, 448)) and
+// [192, 256) the obstacle-layer height under the lane's wheel, written by its twin in the copy wave, [256, 304) the reset outcomes
+// of the four envs (12 floats each: reset_draw evaluated by the copy wave during the physics).
+constexpr int RV_HAND = 448;
 __device__ __forceinline__ float *fused_win(float *lds, const RvParams &p, int wv)
 {
     return reinterpret_cast<float *>(reinterpret_cast<int16_t *>(lds) + (size_t)8 * p.tile_dim * p.tile_pitch) + wv * 64;
@@ -2253,12 +2265,18 @@ __device__ __forceinline__ void scan_copy_wave(const RvParams &p, const float *_
         const float bq = lk[64 + lane];
 #ifdef RV_X_NOLINK   // timing experiment (wrong contact report): what do the link points and the wheel obstacle look-ups cost the step?
         const_cast<float *>(lk)[128 + lane] = 0.0f;
+        const_cast<float *>(lk)[320 + lane] = 0.0f;
+        const_cast<float *>(lk)[384 + lane] = 0.0f;
         const_cast<float *>(lk)[192 + lane] = bq * 0.0f;
 #else
         const LinkSample ls = link_point_fetch(p, R, pos, P, ax, bq, lp);
         const float wbp[3] = {sc.wb[0], sc.wb[1], sc.wb[2]};
         const LinkSample ws = link_point_fetch(p, R, pos, P, ax, bq, wbp);   // the wheel centre rides on the bogie like a link point
-        const_cast<float *>(lk)[128 + lane] = link_point_eval(ls);
+        float f3[3];
+        link_point_eval(ls, p.inv_res, f3);
+        const_cast<float *>(lk)[320 + lane] = f3[0];
+        const_cast<float *>(lk)[384 + lane] = f3[1];
+        const_cast<float *>(lk)[128 + lane] = f3[2];
         const_cast<float *>(lk)[192 + lane] = link_sample_obstacle(ws);
 #endif
     }
@@ -2359,7 +2377,7 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
         g.wheel_t = rv / c.wheel_radius;   // one division per lane instead of six (same quotient)
     }
     // rover_env.py:64-72 decimation loop
-    float Fw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float Fw[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};   // [0..2] this wheel's force, [3..5] this lane's link-point force
     f2 oxy[PRIVATE_ROUNDS];   // the scan phase's ray table (one-launch forms)
     K1_STAMP(1);
     for (int s = 0; s < c.decimation - 1; ++s) physics_substep_group<false>(p, K, g, nullptr, s);
@@ -2387,7 +2405,7 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
         __syncthreads();                                                // A
         if (c.decimation > 0) {
             const float *lk = fused_link(lds, p, wv);
-            Fw[3] = lk[128 + lane];
+            Fw[3] = lk[320 + lane]; Fw[4] = lk[384 + lane]; Fw[5] = lk[128 + lane];
             if (!(lk[192 + lane] > RV_OBSTACLE_EPS)) { Fw[0] = 0.0f; Fw[1] = 0.0f; Fw[2] = 0.0f; }   // the wheel is not on the obstacle layer
         }
         // the ray table of the scan phase: requested now, so that it arrives under the manager tail
@@ -2400,14 +2418,15 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
             }
         }
     }
-    if (!id.wheel_active) { Fw[0] = 0.0f; Fw[1] = 0.0f; Fw[2] = 0.0f; Fw[3] = 0.0f; }
+    if (!id.wheel_active) { Fw[0] = 0.0f; Fw[1] = 0.0f; Fw[2] = 0.0f; Fw[3] = 0.0f; Fw[4] = 0.0f; Fw[5] = 0.0f; }
     if (active) group_store(state, N, e, id, g);
     // contact report: gather the six Drive-body forces and the twelve link-point forces of the env (sensor body order) into
     // every lane -- only in waves where some body touches the obstacle layer (otherwise every force is the +0 the array holds)
     float F[ROVER_NUM_BODIES * 3];
 #pragma unroll
     for (int i = 0; i < ROVER_NUM_BODIES * 3; ++i) F[i] = 0.0f;
-    const bool any_force = __ballot(Fw[0] != 0.0f || Fw[1] != 0.0f || Fw[2] != 0.0f || Fw[3] != 0.0f) != 0ull;
+    // (the link points' z component only: penetration is what makes any component of a point force non-zero)
+    const bool any_force = __ballot(Fw[0] != 0.0f || Fw[1] != 0.0f || Fw[2] != 0.0f || Fw[5] != 0.0f) != 0ull;
     if (any_force) {
         constexpr int BODY_SLOT[6] = {1, 3, 0, 2, 4, 5};  // bodies 7..12 = CL, CR, FL, FR, RL, RR -> solver slot
         const int base = lane & ~15;
@@ -2415,25 +2434,31 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
         for (int b = 0; b < 6; ++b)
 #pragma unroll
             for (int i = 0; i < 3; ++i) F[(7 + b) * 3 + i] = __shfl(Fw[i], base + BODY_SLOT[b], 64);
-        float lf[6][2], Fz[7];
 #pragma unroll
-        for (int sl = 0; sl < 6; ++sl) {
-            lf[sl][0] = __shfl(Fw[3], base + sl, 64);
-            lf[sl][1] = __shfl(Fw[3], base + 8 + sl, 64);
+        for (int i = 0; i < 3; ++i) {
+            float lf[6][2], Fb[7];
+#pragma unroll
+            for (int sl = 0; sl < 6; ++sl) {
+                lf[sl][0] = __shfl(Fw[3 + i], base + sl, 64);
+                lf[sl][1] = __shfl(Fw[3 + i], base + 8 + sl, 64);
+            }
+            link_body_forces(lf, Fb);
+#pragma unroll
+            for (int b = 0; b < 7; ++b) F[b * 3 + i] = Fb[b];
         }
-        link_body_forces(lf, Fz);
-#pragma unroll
-        for (int b = 0; b < 7; ++b) F[b * 3 + 2] = Fz[b];
     }
     if (force && active && id.owner) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) force[(size_t)(id.body * 3 + i) * N + e] = Fw[i];
     }
-    if (force && active && (lane & 15) < 7) {   // z rows of the seven link bodies (x, y rows stay the caller's zeros)
-        float fz = F[2];
+    if (force && active && (lane & 15) < 7) {   // the three rows of the seven link bodies
 #pragma unroll
-        for (int b = 1; b < 7; ++b) fz = ((lane & 15) == b) ? F[b * 3 + 2] : fz;
-        force[(size_t)((lane & 15) * 3 + 2) * N + e] = fz;
+        for (int i = 0; i < 3; ++i) {
+            float fb = F[i];
+#pragma unroll
+            for (int b = 1; b < 7; ++b) fb = ((lane & 15) == b) ? F[b * 3 + i] : fb;
+            force[(size_t)((lane & 15) * 3 + i) * N + e] = fb;
+        }
     }
     K1_STAMP(23);
 
@@ -2654,10 +2679,10 @@ __global__ __launch_bounds__(RV_K1G_THREADS) void rover_physics_kernel_group(RvP
     group_load(state, N, e, id, sc, K, g);
     g.steer_t = steer_t[4 * e + (id.si >= 0 ? id.si : 0)];
     g.wheel_t = wheel_t[6 * e + id.k];
-    float Fw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float Fw[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     for (int s = 0; s < substeps - 1; ++s) physics_substep_group<false>(p, K, g, nullptr);
     if (substeps > 0) physics_substep_group<true>(p, K, g, Fw);
-    if (!id.wheel_active) Fw[3] = 0.0f;
+    if (!id.wheel_active) { Fw[3] = 0.0f; Fw[4] = 0.0f; Fw[5] = 0.0f; }
     if (active) group_store(state, N, e, id, g);
     if (force && active && id.owner) {
 #pragma unroll
@@ -2665,18 +2690,21 @@ __global__ __launch_bounds__(RV_K1G_THREADS) void rover_physics_kernel_group(RvP
     }
     if (force) {
         const int base = lane & ~15;
-        float lf[6][2], Fz[7];
 #pragma unroll
-        for (int sl = 0; sl < 6; ++sl) {
-            lf[sl][0] = __shfl(Fw[3], base + sl, 64);
-            lf[sl][1] = __shfl(Fw[3], base + 8 + sl, 64);
-        }
-        link_body_forces(lf, Fz);
-        if (active && (lane & 15) < 7) {
-            float fz = Fz[0];
+        for (int i = 0; i < 3; ++i) {
+            float lf[6][2], Fb[7];
 #pragma unroll
-            for (int b = 1; b < 7; ++b) fz = ((lane & 15) == b) ? Fz[b] : fz;
-            force[(size_t)((lane & 15) * 3 + 2) * N + e] = fz;
+            for (int sl = 0; sl < 6; ++sl) {
+                lf[sl][0] = __shfl(Fw[3 + i], base + sl, 64);
+                lf[sl][1] = __shfl(Fw[3 + i], base + 8 + sl, 64);
+            }
+            link_body_forces(lf, Fb);
+            if (active && (lane & 15) < 7) {
+                float fb = Fb[0];
+#pragma unroll
+                for (int b = 1; b < 7; ++b) fb = ((lane & 15) == b) ? Fb[b] : fb;
+                force[(size_t)((lane & 15) * 3 + i) * N + e] = fb;
+            }
         }
     }
 }

@@ -228,7 +228,7 @@ def test_link_bodies_report_contact_with_a_rock_between_the_wheels(oracle):
         S = fresh(ro, 1, (15.0, 15.0), 0.26878)
         f = ro.physics_step(cfg, t, S, np.zeros((1, 4), np.float32), np.zeros((1, 6), np.float32), 1)
         assert np.abs(f[0, 7:]).max() == 0.0                              # no wheel stands on the obstacle layer
-        assert np.abs(f[0, :, :2]).max() == 0.0                           # link forces are vertical
+        assert np.abs(f[0, :, :2]).max() == 0.0                           # the rock's top is flat: the link forces are vertical here
         rows = np.nonzero(f[0, :, 2] > 0)[0]
         od, oa, rew, term = ro.mdp_terms(cfg, np.zeros((1, 3), np.float32) + 5, np.zeros((1, 2), np.float32),
                                          np.zeros((1, 2), np.float32), np.zeros(1, np.int32), f)
@@ -254,6 +254,21 @@ def test_link_bodies_report_contact_with_a_rock_between_the_wheels(oracle):
     S = fresh(ro, 1, (15.0, 15.0), 0.26878)
     f = ro.physics_step(cfg, t, S, np.zeros((1, 4), np.float32), np.zeros((1, 6), np.float32), 1)
     assert f[0, 3, 2] > 1.0 and np.abs(f[0, 7:]).max() == 0.0             # FL_Steer touches, the wheel beside it does not
+    assert f[0, 3, 0] == 0.0 and f[0, 3, 1] > 0.0                         # ... on the post's edge in y (rows 306 / 307): the force leans away from it, +y
+    # a FRONTAL hit: the fork meets the rising face of a 2 m post (one column at x = 15.40, the fork at x = 15.44 on the slope
+    # down to the next column) -- the force points along the surface's normal, away from the face: x row > 0, and much larger
+    # than the z row on a face that steep (rewards.py:119-124 norms per xyz component: a graze and a frontal hit now differ)
+    ob = ter.obstacle.copy()
+    ob[305:307, 308:309] = 2.0
+    ter3 = T.Terrain(ground=ter.ground, obstacle=ob, rock_mask=ter.rock_mask, safe_rock_mask=ter.safe_rock_mask)
+    ter3.spawn_locations = ter.spawn_locations
+    cfg, t = ro.default_config(), oracle_terrain(ro, ter3)
+    S = fresh(ro, 1, (15.0, 15.0), 0.26878)
+    f = ro.physics_step(cfg, t, S, np.zeros((1, 4), np.float32), np.zeros((1, 6), np.float32), 1)
+    assert f[0, 3, 2] > 1.0 and f[0, 3, 0] > 5.0 * f[0, 3, 2]
+    od, oa, rew, term = ro.mdp_terms(cfg, np.zeros((1, 3), np.float32) + 5, np.zeros((1, 2), np.float32), np.zeros((1, 2), np.float32),
+                                     np.zeros(1, np.int32), f)
+    assert term[0, 3] == 1
 
 
 def test_oracle_is_deterministic_and_shard_invariant(oracle):
