@@ -179,8 +179,9 @@ int rover_step(rover_sim *sim, const float *action, float *obs, float *reward, u
  *   ... the caller evaluates its terms on `state` / `force` (device tensors), adds to `reward`, ORs into the flags ...
  *   rover_step_finish  rover_env.py:89-99 for `reset_mask` (u8 per env: built-in OR user terminations): episodic log of the
  *                      masked envs, reset, command update, observation rows; `log` is reduced eagerly.
- * Same arithmetic as rover_step (one env per lane): with a reset mask equal to the built-in flags the two halves produce the bits
- * rover_step produces.  `force` is required (the built-in collision term of the second half reads it). */
+ * Same arithmetic as rover_step (first half: sixteen lanes per env, second half: one env per lane -- the mappings agree bit for
+ * bit): with a reset mask equal to the built-in flags the two halves produce the bits rover_step produces (the log vector up to
+ * the order of its sums).  `force` is required (the built-in collision term of the second half reads it). */
 int rover_step_begin(rover_sim *sim, const float *action, float *reward, uint8_t *terminated, uint8_t *truncated, float *force,
                      void *stream);
 int rover_step_finish(rover_sim *sim, const uint8_t *reset_mask, float *obs, float *force, float *log, void *stream);

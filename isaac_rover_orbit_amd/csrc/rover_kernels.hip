@@ -96,7 +96,6 @@ struct RvParams {
     int cpr_log;  // log2 of the chunk slots per staged row (smallest power of two >= tile_pitch / chunk_cells)
     int wq, pq;   // 16-byte chunks per heightfield row / per LDS tile row
     int tile_bufs; // LDS tile buffers of the scan kernel (2 when they fit beside full occupancy, else 1)
-    int ray_blocks; // step-form scan kernel: 1 = wave w casts the 8 x 8 block (w & 3, w >> 2) of the ray grid (grids up to 32 x 32)
     // extras["log"]: a wave of the step kernel writes its partial row only when one of its envs reset, tagged (word 15) with
     // this launch's step_tag, and counts itself in *log_counter; the scan kernel reduces the rows carrying the tag -- or, in
     // the common case of a step without resets, reads the counter and does nothing
@@ -296,11 +295,7 @@ __device__ __forceinline__ void terrain_sample(const RvParams &p, float x, float
     const float fx = u - (float)j0, fy = v - (float)i0;
     const size_t base = (size_t)i0 * p.W + j0;
     const float *q = p.height + base;
-#ifdef RV_K1_NOTERRAIN   // diagnostic build: no terrain gathers (how much memory latency do the wheels expose?)
-    const float h00 = fx * 0.01f, h01 = fy * 0.01f, h10 = 0.0f, h11 = 0.0f;
-#else
     const float h00 = q[0], h01 = q[1], h10 = q[p.W], h11 = q[p.W + 1];
-#endif
     const float dx0 = h01 - h00, dx1 = h11 - h10, dy0 = h10 - h00, dy1 = h11 - h01;
     const float hx0 = h00 + fx * dx0;
     const float hx1 = h10 + fx * dx1;
@@ -1123,7 +1118,6 @@ __device__ __forceinline__ void solver_iteration_generic(const StepConsts &K, Co
 __device__ __forceinline__ void solver_iterations_group(const StepConsts &K, Contact &ct, const RoleRows &rr, f2 *V, float cw,
                                                         float mu, int iterations)
 {
-#ifndef RV_SOLVER_GENERIC
     int pairs = iterations >> 1;
     if (pairs > 0) {
         f2 v0 = V[0], v1 = V[1];
@@ -1147,9 +1141,6 @@ __device__ __forceinline__ void solver_iterations_group(const StepConsts &K, Con
         ct.ls = ls;
     }
     if (iterations & 1) solver_iteration_generic(K, ct, rr, V, cw, mu);
-#else
-    for (int it = 0; it < iterations; ++it) solver_iteration_generic(K, ct, rr, V, cw, mu);
-#endif
 }
 
 // LINK_ELSEWHERE: the lane's link-body sample point AND the obstacle-layer height under its wheel are evaluated by the lane's twin
@@ -1434,7 +1425,8 @@ __device__ __forceinline__ float wave_sum(float x)
 }
 
 // ================================================================================================ K1: step kernel
-// PHASE 0: the whole env step.  PHASE 1 / 2: the step in two halves with the caller in between -- the SLOW PATH for user-written
+// PHASE 0: the whole env step.  PHASE 1 / 2: the step in two halves with the caller in between (the product runs phase 1 in the
+// sixteen-lanes-per-env mapping, step_group_body<0, true>: no scratch; phase 1 here is its one-env-per-lane twin) -- the SLOW PATH for user-written
 // reward / termination terms (rover_env_cfg.py:126-183 are tables of arbitrary `func=`; ORBIT's managers evaluate them on the
 // state the physics left, BEFORE _reset_idx).  1 = action, physics, counters, the built-in terms and their episodic sums: state,
 // reward, flags and forces are stored, nothing is reset.  2 = the rest of rover_env.py:89-99 for the reset mask the caller
@@ -1592,13 +1584,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                                                         float *__restrict__ log_partial)
 {
     step_lane_body<0>(p, state, action, obs, reward, terminated, truncated, force, log_partial, nullptr);
-}
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void rover_step_begin_kernel(RvParams p, float *__restrict__ state,
-                                                        const float *__restrict__ action, float *__restrict__ reward,
-                                                        uint8_t *__restrict__ terminated, uint8_t *__restrict__ truncated,
-                                                        float *__restrict__ force)
-{
-    step_lane_body<1>(p, state, action, nullptr, reward, terminated, truncated, force, nullptr, nullptr);
 }
 __global__ __launch_bounds__(64) void rover_step_finish_kernel(RvParams p, float *__restrict__ state, float *__restrict__ obs,
                                                                float *__restrict__ force, float *__restrict__ log_partial,
@@ -1873,11 +1858,7 @@ __device__ __forceinline__ void private_windows(const ScanWindow &sw, PrivateWin
         w.pk[j] = __builtin_amdgcn_readlane(pk, 16 * j);
     }
 }
-#ifdef RV_FUSED_UNALIGNED   // experiment: let hipcc merge the two cells of a row into one (2-byte-aligned) ds_read_b32
-#define RV_FUSED_ATTR
-#else
 #define RV_FUSED_ATTR __attribute__((target("no-unaligned-access-mode")))
-#endif
 constexpr int PRIVATE_ROUNDS = 16, PRIVATE_GROUP = 4;   // a pipeline group is a quad of rounds (one 16-byte store per lane)
 // Ray -> (round m, lane): ray = 256 (m >> 2) + 4 lane + (m & 3).  A lane's four rays of a QUAD of rounds are neighbours in the
 // observation row, so a quad ends in ONE 16-byte store per lane (row pointer in SGPRs, the lane's byte offset in one VGPR shared
@@ -1917,10 +1898,6 @@ typedef float v4f_u4 __attribute__((ext_vector_type(4), aligned(4)));   // a row
 template <int Q>
 __device__ __forceinline__ void private_store4(float *row /* wave-uniform */, unsigned lane_bytes16, v4f_t v)
 {
-#ifdef RV_X_NOSTORE   // timing experiment (wrong values): no observation stores, the values kept alive
-    asm volatile("" : : "v"(v));
-    return;
-#endif
     // (address space 1: `row` was rebuilt from two readfirstlanes, and a generic pointer would make this a FLAT store, which
     // also counts in lgkmcnt -- the counter the pipeline's LDS reads are waited on)
     typedef __attribute__((address_space(1))) v4f_u4 *global_v4;
@@ -1941,12 +1918,10 @@ __device__ __forceinline__ void private_store_quad(float *row, int lane, int ray
         if (lane < (n3 >> 2)) {
             private_store4<3>(row, lane_bytes16, o4);
         } else if (lane == (n3 >> 2)) {
-#ifndef RV_X_NOSTORE
             __attribute__((address_space(1))) float *tail = (__attribute__((address_space(1))) float *)row + 256 * 3 + 4 * lane;
             if ((n3 & 3) > 0) tail[0] = o4.x;
             if ((n3 & 3) > 1) tail[1] = o4.y;
             if ((n3 & 3) > 2) tail[2] = o4.z;
-#endif
         }
         break;
     }
@@ -2028,11 +2003,7 @@ __device__ __forceinline__ void private_cast(const RvParams &p, const PrivateWin
                 for (int q = 0; q < G; ++q) {
                     const int m = M0 + g * G + q;
                     if (m < M1) {
-#ifdef RV_X_NOLDS   // timing experiment (wrong values): no LDS reads
-                        h00[b][q] = a0[q]; h01[b][q] = a0[q] + 1; h10[b][q] = a0[q] + 2; h11[b][q] = a0[q] + 3;
-#else
                         lds_cell4_issue(a0[q], a0[q] + 2u * (unsigned)pitch, h00[b][q], h01[b][q], h10[b][q], h11[b][q]);
-#endif
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -2040,12 +2011,10 @@ __device__ __forceinline__ void private_cast(const RvParams &p, const PrivateWin
             if (g > 0) {
                 const int pb = b ^ 1;
                 float ov[G];
-#ifndef RV_X_NOLDS
                 // the previous group's sixteen reads have returned when at most the fifteen youngest LDS operations are outstanding
                 // (LDS returns in order; the group issued just above is sixteen operations); after the last group: all of them
                 if (g < NG) lds_cell_wait<15>(h00[pb], h01[pb], h10[pb], h11[pb]);
                 else lds_cell_wait<0>(h00[pb], h01[pb], h10[pb], h11[pb]);
-#endif
 #pragma unroll
                 for (int q = 0; q < G; ++q) {
                     const int m = M0 + (g - 1) * G + q;
@@ -2236,11 +2205,7 @@ __device__ __forceinline__ void scan_copy_wave(const RvParams &p, const float *_
         const int e = min(e_base + (lane >> 4), p.n - 1);
         const uint32_t count = __float_as_uint(state[(size_t)ROVER_RESET_COUNT * p.n + e]);
         ResetOutcome ro;
-#ifdef RV_X_NODRAW   // timing experiment (wrong resets): what do the copy wave's reset draws cost the step?
-        ro.px = ro.py = ro.pz = ro.qz = ro.tx = ro.ty = ro.tz = ro.heading_cmd = (float)count; ro.qw = 1.0f;
-#else
         reset_draw(p, (uint32_t)(p.env_id_offset + e), count, nullptr, ro);
-#endif
         if ((lane & 15) == 0) {
             float4 *d = reinterpret_cast<float4 *>(fused_link(lds, p, partner) + 256 + (lane >> 4) * 12);
             d[0] = make_float4(ro.px, ro.py, ro.pz, ro.qw);
@@ -2263,12 +2228,6 @@ __device__ __forceinline__ void scan_copy_wave(const RvParams &p, const float *_
 #pragma unroll
         for (int i = 0; i < 3; ++i) lp[i] = role_b ? sc.lp[1][i] : sc.lp[0][i];
         const float bq = lk[64 + lane];
-#ifdef RV_X_NOLINK   // timing experiment (wrong contact report): what do the link points and the wheel obstacle look-ups cost the step?
-        const_cast<float *>(lk)[128 + lane] = 0.0f;
-        const_cast<float *>(lk)[320 + lane] = 0.0f;
-        const_cast<float *>(lk)[384 + lane] = 0.0f;
-        const_cast<float *>(lk)[192 + lane] = bq * 0.0f;
-#else
         const LinkSample ls = link_point_fetch(p, R, pos, P, ax, bq, lp);
         const float wbp[3] = {sc.wb[0], sc.wb[1], sc.wb[2]};
         const LinkSample ws = link_point_fetch(p, R, pos, P, ax, bq, wbp);   // the wheel centre rides on the bogie like a link point
@@ -2278,7 +2237,6 @@ __device__ __forceinline__ void scan_copy_wave(const RvParams &p, const float *_
         const_cast<float *>(lk)[384 + lane] = f3[1];
         const_cast<float *>(lk)[128 + lane] = f3[2];
         const_cast<float *>(lk)[192 + lane] = link_sample_obstacle(ws);
-#endif
     }
     __syncthreads();                                                    // A
     windows_from_lds(win, w);
@@ -2324,7 +2282,9 @@ __device__ __forceinline__ void scan_copy_wave(const RvParams &p, const float *_
 // FUSE: 0 = the step alone (the scan kernel follows as a second launch and reads the 32-byte descriptors); 1 / 2 = the height
 // scan of the wave's four envs (bilinear patch / triangle mesh, int16 terrain copy) is the LAST PHASE of the same wave, from two
 // wave-private LDS tiles (scan_private_wave): one launch per env step, no descriptor round trip, no second dispatch.
-template <int FUSE>
+// BEGIN_ONLY: the first half of the two-phase step (rover_step_begin; see step_lane_body): everything up to the reset decision
+// is stored -- physical state, manager words, reward, flags, force rows -- and nothing is reset.
+template <int FUSE, bool BEGIN_ONLY = false>
 __device__ __forceinline__ void step_group_body(const RvParams &p, float *__restrict__ state, const float *__restrict__ action,
                                                 float *__restrict__ obs, float *__restrict__ reward, uint8_t *__restrict__ terminated,
                                                 uint8_t *__restrict__ truncated, float *__restrict__ force,
@@ -2341,12 +2301,7 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
     const GroupIds id = group_ids(lane, sc);
     K1_STAMP(0);
 
-#ifdef RV_K1_CONSTS_IN_KERNEL
-    StepConsts K;
-    make_step_consts(c.sim_dt, K);
-#else
     const StepConsts &K = p.K;
-#endif
     GroupLane g;
     group_load(state, N, e, id, sc, K, g);
     // rover_env.py:62 ActionManager.process_action
@@ -2495,6 +2450,16 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
     }
     const bool do_reset = term_any | time_out;
     const bool writer = active && (lane & 15) == 0;
+    if constexpr (BEGIN_ONLY) {
+        if (writer) {
+#pragma unroll
+            for (int i = ROVER_TARGET_W; i < ROVER_LAMBDA_N; ++i) state[(size_t)i * N + e] = S[i];
+            reward[e] = total;
+            terminated[e] = term_any ? 1 : 0;
+            truncated[e] = time_out ? 1 : 0;
+        }
+        return;
+    }
     // episodic log contributions: only waves in which some env resets pay for the 14 wave reductions
     const bool any_reset = __ballot(do_reset && writer) != 0ull;
     float lg[14];
@@ -2637,6 +2602,15 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
         K1_STAMP(26);
     }
 }
+// first half of the two-phase step, sixteen lanes per env (spill-free; the one-env-per-lane form of the same phase would carry
+// 740 bytes of scratch per lane)
+__global__ __launch_bounds__(RV_K1G_THREADS) void rover_step_begin_kernel(RvParams p, float *__restrict__ state,
+                                                                          const float *__restrict__ action, float *__restrict__ reward,
+                                                                          uint8_t *__restrict__ terminated, uint8_t *__restrict__ truncated,
+                                                                          float *__restrict__ force)
+{
+    step_group_body<0, true>(p, state, action, nullptr, reward, terminated, truncated, force, nullptr, nullptr, nullptr);
+}
 __global__ __launch_bounds__(RV_K1G_THREADS) void rover_step_kernel_group(RvParams p, float *__restrict__ state,
                                                               const float *__restrict__ action, float *__restrict__ obs,
                                                               float *__restrict__ reward, uint8_t *__restrict__ terminated,
@@ -2755,9 +2729,6 @@ __device__ __forceinline__ void reduce_log_partials(const RvParams &p, float *ld
                                                     int n_waves, float *__restrict__ log_out)
 {
     const rover_config &c = p.cfg;
-#ifdef RV_K2_NOREDUCE   // diagnostic build (wrong extras["log"]): what does the reduction cost the scan kernel?
-    if (n_waves >= 0) return;
-#endif
     // Rows carry the tag of the launch that wrote them; the reduction sums the rows of the LATEST launch in which an env reset
     // (log_counter[1]).  Run behind every step that is this step's tag whenever the counter is non-zero; run on demand
     // (rover_flush_log) it reproduces what the per-step reduction would hold: entries 0..12 from the latest step with resets,
@@ -2820,14 +2791,7 @@ __global__ __launch_bounds__(RV_K2_THREADS) __attribute__((amdgpu_waves_per_eu(8
     // persistent workgroups: the grid is sized to what the chip holds at once (launching one 8-wave workgroup per env
     // costs ~10 us of dispatch alone at N = 4096); each workgroup walks envs blockIdx.x, blockIdx.x + n_wg, ...
     const int n_wg = (int)gridDim.x;
-#ifdef RV_K2_EMPTY
-    if (N > 0) return;  // diagnostic build: launch cost of the grid alone
-#endif
-#ifdef RV_K2_STAMP
-#define RV_STAMP(k) do { if (MODE == 0 && tid == 0) { reinterpret_cast<unsigned long long *>(const_cast<float *>(log_partial))[(size_t)e * 8 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
-#else
 #define RV_STAMP(k) do { } while (0)
-#endif
     // LDS carve: [0, 64) ray x offsets, [64, 128) ray y offsets, [128, 192) reciprocals 1/t, [192, ...) tile_bufs terrain
     // tiles (16-B aligned) of fp32 heights or, when the terrain has an exact 16-bit copy, of int16 heights (half the bytes)
     using cell_t = typename std::conditional<Q16, int16_t, float>::type;
@@ -3041,9 +3005,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8), 
     const rover_config &c = p.cfg;
     const int N = p.n;
     const int n_wg = (int)gridDim.x;
-#ifdef RV_K2_EMPTY   // timing experiment: dispatch + drain of the grid alone
-    if (N > 0) return;
-#endif
     using cell_t = typename std::conditional<Q16, int16_t, float>::type;
     constexpr int CC = Q16 ? 8 : 4;  // cells per 16-byte chunk
     typedef float v4f __attribute__((ext_vector_type(4)));
@@ -3065,13 +3026,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8), 
 #pragma unroll
     for (int m = 0; m < RPT; ++m) {
         int r = tid + m * THREADS;
-        if (THREADS == 1024 && p.ray_blocks) {
-            // compact footprint per wave: an 8 x 8 block of neighbouring rays (16 x 16 cells of the tile at 2 cells per ray)
-            // instead of two 31-ray lines -- whatever the yaw, a wave's 256 corner reads stay inside ~16 tile rows x 40 bytes
-            const int wv = tid >> 6, ln = tid & 63;
-            const int rx = (wv & 3) * 8 + (ln & 7), ry = (wv >> 2) * 8 + (ln >> 3);
-            r = (rx < c.scan_nx && ry < c.scan_ny) ? ry * c.scan_nx + rx : p.rays;
-        }
         ray[m] = r < p.rays ? r : (m == 0 ? 0 : ray[0]);
         ox[m] = pattern_x(ray[m] % c.scan_nx);
         oy[m] = pattern_y(ray[m] / c.scan_nx);
@@ -3090,9 +3044,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8), 
     if (gidx >= n_groups) return;
     int e0 = group_of(gidx) * EPI;
     __syncthreads();  // table
-#ifdef RV_K2_PROLOGUE_ONLY   // timing experiment: dispatch + per-thread ray set-up, no env loop
-    if (N > 0) { if (ox[0] + oy[0] == 12345.678f) out[tid] = ox[0]; return; }
-#endif
 
     // asynchronous dense copy of a th x tw4 chunk window into LDS (see rover_scan_obs_kernel)
     auto issue_tile = [&](const float4 &d1, cell_t *tile) {
@@ -3104,11 +3055,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8), 
         const float inv_tw4 = inv_tab[tw4];
         for (int k0 = 0; k0 < nchunk; k0 += THREADS) {
             const int k = k0 + tid;
-#if defined(RV_K2_NO_COPY)   // timing experiments only (wrong results; tools/build_diag.py NOCOPY / NORAYS / NOCOPYRAYS)
-            if (k < 0) {
-#else
             if (k < nchunk) {
-#endif
                 const int r = (int)(((float)k + 0.5f) * inv_tw4);  // k / tw4, exact for k < 2^20
                 const int cq = k - (int)__umul24(r, tw4);
                 __builtin_amdgcn_global_load_lds(
@@ -3192,29 +3139,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8), 
             auto all_rays = [&](auto fast_tag) {
                 float o[RPT];
 #pragma unroll
-#ifdef RV_K2_NO_RAYS
-                for (int m = 0; m < RPT; ++m) o[m] = px[j] + ox[m];
-#else
                 for (int m = 0; m < RPT; ++m) o[m] = ray_obs(ox[m], oy[m], fast_tag);
-#endif
-#if defined(RV_K2_STORE4)   // timing experiment (wrong values): the same bytes as 16-byte stores from every fourth lane
-                if ((tid & 3) == 0) {
-                    if (tid + 3 < p.rays) {
-                        typedef float v4u __attribute__((ext_vector_type(4), aligned(4)));
-                        *reinterpret_cast<v4u *>(row + tid) = (v4u){o[0], o[0], o[0], o[0]};
-                    } else {
-                        for (int q = tid; q < p.rays; ++q) row[q] = o[0];
-                    }
-                }
-#elif defined(RV_K2_NOSTORE)   // timing experiment: no observation stores at all (only thread 0 keeps the values alive)
-                if (tid == 0 && o[0] == 12345.678f) row[0] = o[0];
-#elif defined(RV_K2_NT_STORE)   // timing experiment: streaming stores (the rows do not stay dirty in L2 until the kernel boundary)
-#pragma unroll
-                for (int m = 0; m < RPT; ++m) __builtin_nontemporal_store(o[m], &row[ray[m]]);
-#else
 #pragma unroll
                 for (int m = 0; m < RPT; ++m) row[ray[m]] = o[m];
-#endif
             };
             if ((pk[j] >> 15) & 1) all_rays(std::true_type{});
             else all_rays(std::false_type{});
@@ -3455,7 +3382,7 @@ static int fused_form(const rover_sim *sim)
 {
     if (sim->fused == 0 || !sim->group_mapping || sim->scan_form != 0) return 0;
     const ScanForm f = scan_form_of(sim, 2);
-    if (!f.simple || !f.q16 || sim->p.rays > 1024 || sim->p.ray_blocks) return 0;
+    if (!f.simple || !f.q16 || sim->p.rays > 1024) return 0;
     if (sim->p.tile_pitch / 8 > 64) return 0;   // private_issue stages whole rows per instruction: a row must fit a wave's 64 lanes
     // (the device's own limit: 160 KiB per workgroup on gfx950)
     const bool fits1 = fused_lds_bytes(sim) <= sim->max_lds, fits2 = 2 * single_tile_lds_bytes(sim) <= sim->max_lds;
@@ -3936,8 +3863,8 @@ int rover_step_begin(rover_sim *sim, const float *action, float *reward, uint8_t
     next_batch(sim);
     sim->phase_open = true;
     MarkerRange whole(sim, "rover_step_begin");
-    hipLaunchKernelGGL(rover_step_begin_kernel, dim3((sim->p.n + 63) / 64), dim3(64), 0, st, sim->p, sim->state, action, reward, terminated,
-                       truncated, force);
+    hipLaunchKernelGGL(rover_step_begin_kernel, dim3((sim->p.n + RV_K1G_ENVS - 1) / RV_K1G_ENVS), dim3(RV_K1G_THREADS), 0, st, sim->p, sim->state,
+                       action, reward, terminated, truncated, force);
     HIP_TRY(hipGetLastError());
     return ROVER_OK;
 }
@@ -4000,7 +3927,9 @@ int rover_kernel_names(const rover_sim *sim, char *step_kernel, char *scan_kerne
     }
     snprintf(step_kernel, cap, "%s", sim->group_mapping ? "rover_step_kernel_group" : "rover_step_kernel");
     const ScanForm f = scan_form_of(sim, 2);
-    if (f.simple)
+    if (sim->scan_form == 7 && f.simple && f.q16)   // measurement hook: the wave-private scan as a kernel of its own
+        snprintf(scan_kernel, cap, "rover_scan_private_kernel<%s>", f.tri ? "true" : "false");
+    else if (f.simple)
         snprintf(scan_kernel, cap, "rover_scan_step_kernel<%s, %s, 1024, %d>", f.q16 ? "true" : "false", f.tri ? "true" : "false", f.epi);
     else
         snprintf(scan_kernel, cap, "rover_scan_obs_kernel<2, %s, %s>", f.q16 ? "true" : "false", f.tri ? "true" : "false");
@@ -4097,18 +4026,12 @@ int rover_height_scan(rover_sim *sim, float *scan, void *stream)
 }
 
 // measurement hook (tools/n_sweep.py): 0 = automatic choice, 1 = the generic scan kernel on the step path as well, 2 = the
-// step form with one env per iteration
+// step form with one env per iteration, 7 = the wave-private scan (the scan phase of the one-launch kernels) as a kernel of its
+// own behind the group-mapped step kernel.  (Forms 3 .. 6 -- 8 x 8 ray blocks per wave, XCD-aware pair dealing off / on -- were
+// round-3 experiments; their outcome is in DESIGN.md section 10, their code is gone.)
 int rover_debug_set_scan_form(rover_sim *sim, int form)
 {
-    if (!sim || form < 0 || form > 7) return ROVER_ERR_INVALID;   // 7: the wave-private scan as a kernel of its own
-    if (form == 5 || form == 6) {   // 5 / 6: XCD-aware dealing of the env pairs off / on (measurement hook; default on)
-        sim->p.xcd_rows = form == 6;
-        return ROVER_OK;
-    }
-    if (form >= 3) {   // 3 / 4: ray -> thread mapping of the step form: 8 x 8 blocks per wave / lines (measurement hook)
-        sim->p.ray_blocks = (form == 3 && sim->p.cfg.scan_nx <= 32 && sim->p.cfg.scan_ny <= 32) ? 1 : 0;
-        return ROVER_OK;
-    }
+    if (!sim || !(form == 0 || form == 1 || form == 2 || form == 7)) return ROVER_ERR_INVALID;
     sim->scan_form = form;
     return ROVER_OK;
 }
@@ -4123,14 +4046,6 @@ int rover_debug_set_fused(rover_sim *sim, int fused)
 int rover_debug_set_k1_stamps(void *buf)
 {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_k1_stamps), &buf, sizeof(buf)) == hipSuccess ? ROVER_OK : ROVER_ERR_HIP;
-}
-#endif
-#ifdef RV_K2_STAMP
-int rover_debug_scan(rover_sim *sim, float *scan, void *stamps, void *stream)
-{
-    const RvParams &p = sim->p;
-    launch_scan<0>(sim, p.n, static_cast<hipStream_t>(stream), scan, p.rays, 0, (const float *)stamps, 0, nullptr);
-    return ROVER_OK;
 }
 #endif
 

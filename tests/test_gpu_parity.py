@@ -448,6 +448,7 @@ def test_private_scan_kernel_measurement_form(oracle):
     fn = C.CDLL(env._lib._name).rover_debug_set_scan_form
     fn.argtypes = [C.c_void_p, C.c_int]
     assert fn(env._h, 7) == 0
+    assert env.kernel_names()[1].startswith("rover_scan_private_kernel"), env.kernel_names()   # the form IS selected (it silently was not, round 3)
     rng = np.random.RandomState(4)
     actions = rng.uniform(-1, 1, (10, n, 2)).astype(np.float32)
     assert rollout_compare(oracle, env, 10, actions, 0.0, 0.0, resync=False) == 0
