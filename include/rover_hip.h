@@ -196,6 +196,10 @@ int rover_step_finish(rover_sim *sim, const uint8_t *reset_mask, float *obs, flo
  * terrain copy, a batch of at least eight envs per compute unit): without it a second launch would follow for the log alone.
  * Default: not deferred (two launches; the scan kernel's first workgroup reduces the log). */
 int rover_set_log_deferred(rover_sim *sim, int32_t deferred);
+/* Observation rows with streaming (non-temporal) stores in the one-launch kernels: 1 = on.  Worth ~2 % of the step when nothing on
+ * the device reads the rows next (a host-side consumer, a random-action rollout); leave it off (default) when a policy kernel
+ * follows -- its read of the rows then hits L2.  No reference counterpart (the reference's observation tensor is a torch.cat). */
+int rover_set_obs_streaming(rover_sim *sim, int32_t streaming);
 int rover_flush_log(rover_sim *sim, float *log, void *stream);
 
 /* Profiling twin of rover_step: identical launches, bracketed by HIP events recorded on `stream`; returns the device

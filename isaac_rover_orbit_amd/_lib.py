@@ -23,7 +23,7 @@ EXPORTS = [
     "rover_reset", "rover_reset_with_draws", "rover_set_seed", "rover_get_counter", "rover_set_counter", "rover_step", "rover_profile_step",
     "rover_profile_event_overhead", "rover_mdp_terms", "rover_ackermann", "rover_height_scan", "rover_physics", "rover_model_constants",
     "rover_state_words", "rover_config_bytes", "rover_last_error", "rover_version", "rover_set_markers", "rover_kernel_names",
-    "rover_set_log_deferred", "rover_flush_log", "rover_step_begin", "rover_step_finish",
+    "rover_set_log_deferred", "rover_flush_log", "rover_step_begin", "rover_step_finish", "rover_set_obs_streaming",
     "rover_terrain_rasterize", "rover_terrain_surface", "rover_terrain_rock_mask", "rover_terrain_scratch_bytes",   # rover_terrain.h
     "rover_set_terrain_lookup",
     "rover_policy_default_desc", "rover_policy_packed_floats", "rover_policy_pack", "rover_policy_forward",  # rover_policy.h
@@ -145,6 +145,7 @@ def load():
     lib.rover_set_markers.argtypes = [vp, i32]
     lib.rover_set_log_deferred.argtypes = [vp, i32]
     lib.rover_flush_log.argtypes = [vp, vp, vp]
+    lib.rover_set_obs_streaming.argtypes = [vp, i32]
     lib.rover_step_begin.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.rover_step_finish.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.rover_kernel_names.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_size_t]

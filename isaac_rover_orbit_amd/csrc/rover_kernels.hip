@@ -105,6 +105,7 @@ struct RvParams {
     // observations (rows 16 b .. 16 b + 15) are produced on ONE XCD, the XCD (b mod 8) on which workgroup b of a kernel with
     // one workgroup per 16 rows -- the policy / value forward pass -- will run: its read then hits that XCD's L2
     int xcd_rows;
+    int nt_obs;   // 1 = the one-launch kernels store the observation rows with streaming (non-temporal) stores (rover_set_obs_streaming)
 };
 
 // ------------------------------------------------------------------------------------------------ small helpers
@@ -1876,6 +1877,8 @@ __device__ __forceinline__ f2 pk_mul_hi(f2 a, f2 b)
 // lds_cell_wait that lists them (its "+v" ties make every later use depend on the wait).
 __device__ __forceinline__ void lds_cell4_issue(unsigned row0, unsigned row1, int &h00, int &h01, int &h10, int &h11)
 {
+    // (Measured, round 4: the two cells of a row as ONE 2-byte-aligned ds_read_b32, split in the epilogue: 45.1 us per step against
+    // 35.6 -- a misaligned 32-bit LDS read costs far more than the two 16-bit reads it replaces, as in round 2's scan kernel.)
     asm volatile("ds_read_i16 %0, %4\n\t"
                  "ds_read_i16 %1, %4 offset:2\n\t"
                  "ds_read_i16 %2, %5\n\t"
@@ -1896,27 +1899,32 @@ typedef float v4f_u4 __attribute__((ext_vector_type(4), aligned(4)));   // a row
 // store reads its data registers for several cycles after issue -- the next group's first packed multiply overwrote the second
 // dword of lanes 12 .. 15 of every row.)
 template <int Q>
-__device__ __forceinline__ void private_store4(float *row /* wave-uniform */, unsigned lane_bytes16, v4f_t v)
+__device__ __forceinline__ void private_store4(float *row /* wave-uniform */, unsigned lane_bytes16, v4f_t v, bool nt)
 {
     // (address space 1: `row` was rebuilt from two readfirstlanes, and a generic pointer would make this a FLAT store, which
     // also counts in lgkmcnt -- the counter the pipeline's LDS reads are waited on)
     typedef __attribute__((address_space(1))) v4f_u4 *global_v4;
     typedef __attribute__((address_space(1))) char *global_bytes;
-    *(global_v4)((global_bytes)row + 1024 * Q + lane_bytes16) = v;
+    // streaming (non-temporal) stores on request (rover_set_obs_streaming): the 15.8 MB of observation rows leave every CU within
+    // the same few microseconds and nothing of this kernel reads them back -- 34.9 us per step against 35.6 with plain stores
+    // (tools/quick_bench.py, round 4).  Not the default: the next reader of the rows is usually the policy kernel, whose tile copy
+    // finds plainly stored rows in L2 (pair kernel 31.0 us behind plain stores, 33.7 us behind streamed ones).
+    if (nt) __builtin_nontemporal_store(v, (global_v4)((global_bytes)row + 1024 * Q + lane_bytes16));
+    else *(global_v4)((global_bytes)row + 1024 * Q + lane_bytes16) = v;
 }
 // quad `quad` of a row: quads 0 .. 2 of a dense pattern are full; in the last one lanes below n3 / 4 hold four rays, lane n3 / 4
 // the n3 % 4 that remain (n3 = rays - 768: 193 .. 256)
-__device__ __forceinline__ void private_store_quad(float *row, int lane, int rays, int quad, v4f_t o4)
+__device__ __forceinline__ void private_store_quad(float *row, int lane, int rays, int quad, v4f_t o4, bool nt)
 {
     const unsigned lane_bytes16 = (unsigned)lane * 16u;
     switch (quad) {   // the quad is the store's immediate offset
-    case 0: private_store4<0>(row, lane_bytes16, o4); break;
-    case 1: private_store4<1>(row, lane_bytes16, o4); break;
-    case 2: private_store4<2>(row, lane_bytes16, o4); break;
+    case 0: private_store4<0>(row, lane_bytes16, o4, nt); break;
+    case 1: private_store4<1>(row, lane_bytes16, o4, nt); break;
+    case 2: private_store4<2>(row, lane_bytes16, o4, nt); break;
     default: {
         const int n3 = rays - 64 * (PRIVATE_ROUNDS - 4);
         if (lane < (n3 >> 2)) {
-            private_store4<3>(row, lane_bytes16, o4);
+            private_store4<3>(row, lane_bytes16, o4, nt);
         } else if (lane == (n3 >> 2)) {
             __attribute__((address_space(1))) float *tail = (__attribute__((address_space(1))) float *)row + 256 * 3 + 4 * lane;
             if ((n3 & 3) > 0) tail[0] = o4.x;
@@ -2039,7 +2047,7 @@ __device__ __forceinline__ void private_cast(const RvParams &p, const PrivateWin
                 }
                 {
                     const v4f_t o4 = {ov[0], ov[1], ov[2], ov[3]};
-                    private_store_quad(row, lane, p.rays, (M0 >> 2) + g - 1, o4);
+                    private_store_quad(row, lane, p.rays, (M0 >> 2) + g - 1, o4, p.nt_obs != 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -3884,6 +3892,13 @@ int rover_step_finish(rover_sim *sim, const uint8_t *reset_mask, float *obs, flo
     // reduces extras["log"] (always eagerly here: this path is not the one-launch form, a deferred flush would find nothing)
     launch_scan<2>(sim, sim->p.n + 1, st, obs, sim->p.obs_w, 4, sim->log_partial, blocks, log);
     HIP_TRY(hipGetLastError());
+    return ROVER_OK;
+}
+
+int rover_set_obs_streaming(rover_sim *sim, int32_t streaming)
+{
+    if (!sim) return fail(ROVER_ERR_INVALID, "sim is NULL");
+    sim->p.nt_obs = streaming != 0;
     return ROVER_OK;
 }
 

@@ -334,6 +334,7 @@ class RoverEnv(RLTaskEnv):
         if getattr(self.cfg, "log_reduction", "on_demand") not in ("on_demand", "every_step"):
             raise ValueError("log_reduction must be 'on_demand' or 'every_step'")
         _lib.check(self._lib.rover_set_log_deferred(self._h, int(self._log_deferred)), "rover_set_log_deferred")
+        _lib.check(self._lib.rover_set_obs_streaming(self._h, int(bool(getattr(self.cfg, "stream_observations", False)))), "rover_set_obs_streaming")
         log_items = {k: self._log[i] for i, k in enumerate(LOG_KEYS)}
         # ---- user-written terms (cfg.py): evaluated in torch between the two halves of the step
         self._user_rewards = list(self.cfg.custom_terms(self.cfg.rewards, REWARD_ORDER).items())
