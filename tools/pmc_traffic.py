@@ -52,7 +52,7 @@ res = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT
                "tile staging is 16 B/lane global_load_lds); the step kernels' 4-byte gathers are an uncalibrated width -> raw "
                "value.  Keys = kernel names exactly as rocprofv3 prints them (minus qualifiers / parameter list) = "
                "rover_kernel_names().",
-       "round": 3, "_build": sys.argv[5] if len(sys.argv) > 5 else ""}
+       "round": 4, "_build": sys.argv[5] if len(sys.argv) > 5 else ""}
 # The one-launch kernel (rover_step_scan_kernel) contains both read streams: the step phase's 4-byte terrain gathers (raw value)
 # and the scan phase's 16-byte window staging (x 2).  Its corrected fetch = 2 x raw - the step phase's share, taken from the
 # two-launch step kernel measured in the same passes (tools/pmc_run.py with ROVER_FUSED=0 runs behind the product run).
