@@ -134,7 +134,8 @@ class _ContactSensor:
             raise RuntimeError("contact forces are not recorded (cfg.record_contact_forces=False)")
         d = _SensorData()
         n = env.num_envs
-        d.force_matrix_w = env._force.view(_lib.NUM_BODIES, 3, n).permute(2, 0, 1).unsqueeze(2)
+        d.net_forces_w = env._force.view(_lib.NUM_BODIES, 3, n).permute(2, 0, 1)
+        d.force_matrix_w = d.net_forces_w.unsqueeze(2)
         return d
 
 
@@ -181,9 +182,34 @@ class _TerrainFacade:
         return self._env._spawns_dev
 
 
+class _RobotData:
+    """Zero-copy views of the SoA state; the body-frame velocities are rotated on access (ORBIT's ``quat_rotate_inverse``)."""
+
+    def __init__(self, st):
+        self.root_pos_w = st[_lib.POS:_lib.POS + 3].t()
+        self.root_quat_w = st[_lib.QUAT:_lib.QUAT + 4].t()
+        self.root_lin_vel_w = st[_lib.LINVEL:_lib.LINVEL + 3].t()
+        self.root_ang_vel_w = st[_lib.ANGVEL:_lib.ANGVEL + 3].t()
+        self.joint_pos = st[_lib.BOGIE_Q:_lib.BOGIE_Q + 13].t()
+        self.joint_vel = st[_lib.BOGIE_QD:_lib.BOGIE_QD + 13].t()
+
+    def _to_body(self, v):
+        q = self.root_quat_w
+        w, u = q[:, 0:1], q[:, 1:4]
+        return v * (2.0 * w * w - 1.0) - 2.0 * w * torch.cross(u, v, dim=-1) + 2.0 * u * (u * v).sum(-1, keepdim=True)
+
+    @property
+    def root_lin_vel_b(self):
+        return self._to_body(self.root_lin_vel_w)
+
+    @property
+    def root_ang_vel_b(self):
+        return self._to_body(self.root_ang_vel_w)
+
+
 class _Robot:
-    """``scene["robot"]`` (ORBIT Articulation): ``data.root_pos_w / root_quat_w / root_lin_vel_w / root_ang_vel_w / joint_pos /
-    joint_vel`` as zero-copy views of the SoA state (joint order: 3 bogies, 4 steer joints, 6 wheels)."""
+    """``scene["robot"]`` (ORBIT Articulation): ``data.root_pos_w / root_quat_w / root_lin_vel_w / root_ang_vel_w / root_lin_vel_b /
+    root_ang_vel_b / joint_pos / joint_vel`` (joint order: 3 bogies, 4 steer joints, 6 wheels)."""
     joint_names = ["FL_Boogie_Revolute", "FR_Boogie_Revolute", "R_Boogie_Revolute", "FL_Steer_Revolute", "FR_Steer_Revolute",
                    "RL_Steer_Revolute", "RR_Steer_Revolute", "FL_Drive_Continuous", "FR_Drive_Continuous", "CL_Drive_Continuous",
                    "CR_Drive_Continuous", "RL_Drive_Continuous", "RR_Drive_Continuous"]
@@ -193,15 +219,7 @@ class _Robot:
 
     @property
     def data(self):
-        st = self._env.state
-        d = _SensorData()
-        d.root_pos_w = st[_lib.POS:_lib.POS + 3].t()
-        d.root_quat_w = st[_lib.QUAT:_lib.QUAT + 4].t()
-        d.root_lin_vel_w = st[_lib.LINVEL:_lib.LINVEL + 3].t()
-        d.root_ang_vel_w = st[_lib.ANGVEL:_lib.ANGVEL + 3].t()
-        d.joint_pos = st[_lib.BOGIE_Q:_lib.BOGIE_Q + 13].t()
-        d.joint_vel = st[_lib.BOGIE_QD:_lib.BOGIE_QD + 13].t()
-        return d
+        return _RobotData(self._env.state)
 
 
 class _Scene:

@@ -211,3 +211,26 @@ def test_reference_style_cfg_with_a_user_term_converts(terrain):
     _, r, _, _, info = env.step(torch.zeros(256, 2, device=env.device))
     assert env._slow_path and "Episode Reward/my_bonus" in info["log"] and torch.isfinite(r).all()
     env.close()
+
+
+def test_robot_facade_body_frame_velocities_and_net_forces(terrain):
+    """``root_lin_vel_b`` / ``root_ang_vel_b`` = ORBIT's ``quat_rotate_inverse(root_quat_w, v_w)`` (utils/math, not in
+    /root/reference: the published formula, checked here against a float64 rotation matrix), ``net_forces_w`` = the 13 x 3 report."""
+    env = _make(2048, terrain)
+    env.reset()
+    g = torch.Generator(device=env.device).manual_seed(5)
+    for _ in range(12):
+        env.step(torch.rand(2048, 2, device=env.device, generator=g) * 2 - 1)
+    d = env.scene["robot"].data
+    q = d.root_quat_w.double()
+    w, x, y, z = q.unbind(1)
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                     2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                     2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], dim=1).view(-1, 3, 3)
+    for vb, vw in ((d.root_lin_vel_b, d.root_lin_vel_w), (d.root_ang_vel_b, d.root_ang_vel_w)):
+        want = torch.einsum("nji,nj->ni", R, vw.double())            # R^T v
+        assert vb.shape == (2048, 3) and torch.allclose(vb.double(), want, atol=1e-5)
+        assert float(vw.abs().max()) > 0.05
+    s = env.scene.sensors["contact_sensor"].data
+    assert s.net_forces_w.shape == (2048, 13, 3) and torch.equal(s.net_forces_w, s.force_matrix_w[:, :, 0])
+    env.close()
