@@ -367,9 +367,20 @@ __device__ __forceinline__ float collision_measure(const float *F /* 13 x 3 */)
 
 // rewards.py:14-137, terminations.py:14-64, ORBIT mdp.time_out; rew = unweighted term values
 // no_force: the caller knows that every entry of F is +0 (wave-uniform), so the collision measure is exactly 0
+// terminations.py:14-64 + ORBIT mdp.time_out alone (the same expressions as in mdp_terms_one below): the one-launch kernel
+// decides the reset BEFORE the rest of the manager tail, so that the copy wave can stage the windows of the final pose
+__device__ __forceinline__ void mdp_terminations(const rover_config &c, const float *cmd_b, int ep_len, bool coll, bool *term)
+{
+    const float d = sqrtf(cmd_b[0] * cmd_b[0] + cmd_b[1] * cmd_b[1]);
+    term[0] = ep_len >= c.max_episode_length;
+    term[1] = d < c.success_threshold;
+    term[2] = d > c.far_threshold;
+    term[3] = coll;
+}
+// coll_known: < 0 = evaluate the collision measure from F; 0 / 1 = the caller has (same function, same F)
 __device__ __forceinline__ void mdp_terms_one(const rover_config &c, const float *cmd_b, const float *action,
                                               const float *prev_action, int ep_len, const float *F, float *rew,
-                                              bool *term, bool no_force = false)
+                                              bool *term, bool no_force = false, int coll_known = -1)
 {
     const float L = (float)c.max_episode_length;
     const float d = sqrtf(cmd_b[0] * cmd_b[0] + cmd_b[1] * cmd_b[1]);
@@ -387,7 +398,7 @@ __device__ __forceinline__ void mdp_terms_one(const rover_config &c, const float
     }
     rew[3] = (fabsf(angle) > 2.0f) ? fabsf(angle) / L : 0.0f;
     rew[4] = (action[0] < 0.0f) ? (float)(1.0 / (double)c.max_episode_length) : 0.0f;
-    const bool coll = no_force ? false : collision_measure(F) > 1.0f;  // hard-coded 1, `threshold` ignored (B-8)
+    const bool coll = coll_known >= 0 ? coll_known != 0 : (no_force ? false : collision_measure(F) > 1.0f);  // hard-coded 1, `threshold` ignored (B-8)
     rew[5] = coll ? 1.0f : 0.0f;
     rew[6] = (d > c.far_threshold) ? 1.0f : 0.0f;
     term[0] = ep_len >= c.max_episode_length;
@@ -1014,8 +1025,30 @@ __device__ __forceinline__ void slot_sum4(float &a0, float &a1, float &a2, float
         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
 }
 
-#ifdef RV_K1_STAMP
+#if defined(RV_K1_STAMP) || defined(RV_K1_LITE)
 __device__ unsigned long long *g_k1_stamps;
+#endif
+// RV_K1_LITE: a timeline of the one-launch kernel's two waves on SIMD 0 (step wave 0: slots 0.., copy wave 4: slots 16..) from
+// stamps that do not wait for anything -- the waiting stamps below serialise the very overlap this timeline is about
+#ifdef RV_K1_LITE
+__device__ __forceinline__ void k1_lite(int slot)
+{
+    if ((threadIdx.x & 255) == 0) {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        g_k1_stamps[(size_t)blockIdx.x * 64 + (threadIdx.x >> 8) * 32 + slot] = t;
+    }
+}
+#define K1_LITE(k) k1_lite(k)
+#else
+#define K1_LITE(k) do { } while (0)
+#endif
+#ifdef RV_K1_LITE_FINE   // more stamps inside the manager tail / the first staging (each costs the wave several hundred cycles)
+#define K1_LITE_F(k) k1_lite(k)
+#else
+#define K1_LITE_F(k) do { } while (0)
+#endif
+#ifdef RV_K1_STAMP
 __device__ __forceinline__ void k1_stamp(int slot)
 {
     if (threadIdx.x == 0) {
@@ -1701,17 +1734,32 @@ __device__ __forceinline__ void group_load(const float *__restrict__ state, int 
     }
 }
 // physical state back to HBM: chassis by slot 0 / role A, bogie j by slot 2j, steer / wheel words by their wheel's role-A lane
-__device__ __forceinline__ void group_store(float *__restrict__ state, int N, int e, const GroupIds &id, const GroupLane &g)
+// Words that every lane of an env's sixteen holds (the replicated chassis, the manager words): lane r of the group stores word
+// W0 + r -- ONE store instruction for up to sixteen SoA rows instead of one per row from a single lane.  A store instruction
+// costs the CU's address path ~50 cycles however few lanes it has (measured in the one-launch kernel: 53 of them removed =
+// -1.3 us, the copy waves' window requests queue behind them), a 16-way select ~15 VALU instructions.
+// (The select chain is a template recursion: written as a loop, hipcc recognises `x = v[r]` in it, turns it into a run-time index
+// and sends the whole array to scratch -- or, promoted, to LDS.)
+template <int I, int CNT, int OFF, int LEN>
+__device__ __forceinline__ float pick_by_lane(int r, const float (&v)[LEN], float x)
 {
-    if (id.slot == 0 && !id.role_b) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) state[(size_t)(ROVER_POS + i) * N + e] = g.pos[i];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) state[(size_t)(ROVER_QUAT + i) * N + e] = g.quat[i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) state[(size_t)(ROVER_LINVEL + i) * N + e] = g.linvel[i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) state[(size_t)(ROVER_ANGVEL + i) * N + e] = g.angvel[i];
+    if constexpr (I < CNT) return pick_by_lane<I + 1, CNT, OFF, LEN>(r, v, (r == I) ? v[OFF + I] : x);
+    else return x;
+}
+template <int W0, int CNT, int OFF, int LEN>
+__device__ __forceinline__ void store_rows_by_lane(float *__restrict__ state, int N, int e, int r, const float (&v)[LEN])
+{
+    static_assert(CNT >= 1 && CNT <= 16 && OFF + CNT <= LEN, "one row per lane of the group");
+    const float x = pick_by_lane<1, CNT, OFF, LEN>(r, v, v[OFF]);
+    if (r < CNT) state[(size_t)(W0 + r) * N + e] = x;
+}
+__device__ __forceinline__ void group_store(float *__restrict__ state, int N, int e, const GroupIds &id, const GroupLane &g, int lane)
+{
+    {
+        const float ch[13] = {g.pos[0], g.pos[1], g.pos[2], g.quat[0], g.quat[1], g.quat[2], g.quat[3],
+                              g.linvel[0], g.linvel[1], g.linvel[2], g.angvel[0], g.angvel[1], g.angvel[2]};
+        static_assert(ROVER_POS == 0 && ROVER_QUAT == 3 && ROVER_LINVEL == 7 && ROVER_ANGVEL == 10, "chassis words 0..12");
+        store_rows_by_lane<ROVER_POS, 13, 0>(state, N, e, lane & 15, ch);
     }
     if (id.owner) {
         if ((id.slot & 1) == 0) {
@@ -2143,20 +2191,23 @@ __device__ __forceinline__ void scan_single_tile_wave(const RvParams &p, int16_t
     }
 }
 
-// ---- the fused step kernel's scan phase with COPY WAVES.  One wave issues a global_load_lds_dwordx4 every ~145 cycles and
-// nothing else meanwhile (2.5 k cycles per window, measured with a stamp that does not wait), so the four step waves of a
-// workgroup are paired with four copy waves (waves 4..7, one per SIMD, asleep at a barrier during the physics): copy wave k + 4
-// stages the windows of step wave k -- the first two under k's manager tail, the third and fourth under k's rays.
-// The copy wave also casts (rounds 10..15 of envs 0 and 3: nothing to stage beside them) and, during the LAST substep, evaluates
-// the link-body sample points of the contact report for its twin lanes.
-// Windows travel through LDS (win[wave][set][env][8 words]: set 0 = after the physics, set 1 = final); SEVEN workgroup barriers,
-// executed by all eight waves on every path (B2 right after B: the step wave has restaged windows 0, 1 if one of its envs reset):
-//   L  pose + bogie angles of the last substep's start written | copy: link-point forces | step: the last substep
-//   A  set 0 written, link forces written | copy: stage windows 0, 1 (set 0), wait | step: manager tail, set 1, ray table
-//   B  windows 0, 1 landed, set 1 written                                        | step: (reset in the wave: restage 0, 1 itself) rays of env 0
-//   C  tile 0 free              | copy: stage window 2 (set 1) into tile 0, wait | step: rays of env 1
-//   D  window 2 landed, tile 1 free | copy: stage window 3 into tile 1, wait     | step: rays of env 2
-//   E  window 3 landed                                                           | step: rays of env 3
+// ---- the fused step kernel's scan phase with COPY WAVES.  One wave issues a global_load_lds_dwordx4 every ~120 cycles and
+// nothing else meanwhile (2.3 k cycles per window: the CU's L2 port delivers ~33 B/clk to its four requesting waves), so the four
+// step waves of a workgroup are paired with four copy waves (waves 4..7, one per SIMD, asleep at a barrier during the physics):
+// copy wave k + 4 stages the windows of step wave k.  During the physics it draws what a reset of each env WOULD draw (reset_draw)
+// and, during the LAST substep, evaluates the link-body sample points and the wheels' obstacle look-ups of the contact report.
+// The reset is decided by the step wave right after the physics (mdp_terminations: the other termination terms are functions of
+// words loaded before the physics), so the windows handed over are those of the FINAL pose; the copy wave stages the first two and
+// casts env 0 under the step wave's manager tail.  Windows travel through LDS (win[wave][env][8 words]); SIX workgroup barriers,
+// executed by all eight waves on every path (no path depends on whether an env reset):
+//   L   pose + bogie angles of the last substep's start written | copy: link-point forces, obstacle heights | step: the last substep
+//   A   link forces written                                     | step: contact report, collision flag, reset decision, final windows
+//   A2  final windows written | copy: stage windows 0, 1, wait, rays of env 0, wait       | step: manager tail, ray table
+//   B   env 0 cast, window 1 landed | copy: stage window 2 into tile 0, wait              | step: rays of env 1
+//   C   window 2 landed, tile 1 free | copy: stage window 3 into tile 1, wait             | step: rays of env 2
+//   D   window 3 landed                                         | both: rays of env 3 (rounds [0, SHARE_3) / [SHARE_3, 16))
+// A cast is bound by the SIMD's instruction issue, not by latency: two waves casting the same env together take as long as one
+// (16 rounds: 2.9 k cycles against 3.0 k; tools/k1_lite.py), so sharing an env pays only where the other wave would idle anyway.
 __device__ __forceinline__ void windows_to_lds(float *win, const ScanWindow &sw, int lane)
 {
     if ((lane & 15) == 0) {
@@ -2176,7 +2227,7 @@ __device__ __forceinline__ void windows_from_lds(const float *win, PrivateWindow
         w.pk[j] = __builtin_amdgcn_readfirstlane(__float_as_int(d1.w));
     }
 }
-// LDS of the copy-wave form behind the eight tiles: windows [4 waves][2 sets][4 envs][8] floats (1 KB), then per step wave
+// LDS of the copy-wave form behind the eight tiles: windows [4 waves][64] floats (1 KB; [4 envs][8] used), then per step wave
 // RV_HAND floats of hand-over: [0, 48) rotation matrix + position of its four envs at the START of the last substep,
 // [64, 128) the bogie angle of every lane, [128, 192) the lane's link-point force (z; x and y: [320, 384), [384, 448)) and
 // [192, 256) the obstacle-layer height under the lane's wheel, written by its twin in the copy wave, [256, 304) the reset outcomes
@@ -2187,16 +2238,19 @@ __device__ __forceinline__ float *fused_win(float *lds, const RvParams &p, int w
     return reinterpret_cast<float *>(reinterpret_cast<int16_t *>(lds) + (size_t)8 * p.tile_dim * p.tile_pitch) + wv * 64;
 }
 __device__ __forceinline__ float *fused_link(float *lds, const RvParams &p, int wv) { return fused_win(lds, p, 0) + 256 + wv * RV_HAND; }
-// rounds (whole quads) of an env's sixteen cast by the step wave; the copy wave takes the rest -- of envs 0 and 3 only: beside
-// envs 1 and 2 it has a window to stage.  Round 4 (tools/quick_bench.py, us per step at 4096 envs, step wave's rounds of envs
-// 0, 3 / of envs 1, 2): 4 / 16 35.06, 8 / 16 35.3, 8 / 12 36.0, 4 / 12 36.0, 0 / 12 36.4, 4 / 8 36.4.
-#ifndef RV_SHARE_FREE
-#define RV_SHARE_FREE 4
+// Rounds (whole quads) of an env's sixteen cast by the STEP wave; the copy wave takes the rest.  Env 0 is the copy wave's alone
+// (cast under the manager tail, so that tile 0 is free for window 2 before barrier B); beside env 2 it stages window 3.
+#ifndef RV_SHARE_1
+#define RV_SHARE_1 16
 #endif
-#ifndef RV_SHARE_COPY
-#define RV_SHARE_COPY 16
+#ifndef RV_SHARE_2
+#define RV_SHARE_2 16
 #endif
-constexpr int SHARE_FREE = RV_SHARE_FREE, SHARE_COPY = RV_SHARE_COPY;
+#ifndef RV_SHARE_3
+#define RV_SHARE_3 8
+#endif
+constexpr int SHARE_1 = RV_SHARE_1, SHARE_2 = RV_SHARE_2, SHARE_3 = RV_SHARE_3;
+constexpr int SHARE_MAX = SHARE_1 > SHARE_2 ? (SHARE_1 > SHARE_3 ? SHARE_1 : SHARE_3) : (SHARE_2 > SHARE_3 ? SHARE_2 : SHARE_3);
 template <bool TRI>
 __device__ __forceinline__ void scan_copy_wave(const RvParams &p, const float *__restrict__ state, float *lds, int partner, int lane,
                                                float *__restrict__ obs, const float2 *__restrict__ ray_xy)
@@ -2246,38 +2300,48 @@ __device__ __forceinline__ void scan_copy_wave(const RvParams &p, const float *_
         const_cast<float *>(lk)[128 + lane] = f3[2];
         const_cast<float *>(lk)[192 + lane] = link_sample_obstacle(ws);
     }
+    K1_LITE(0);
     __syncthreads();                                                    // A
+    K1_LITE(1);
+    __syncthreads();                                                    // A2: the windows of the FINAL poses (resets decided)
+    K1_LITE(2);
     windows_from_lds(win, w);
     if (n_env > 0) private_issue(p, w, 0, tile0, lane);
     if (n_env > 1) private_issue(p, w, 1, tile1, lane);
     f2 oxy[PRIVATE_ROUNDS];
 #pragma unroll
     for (int m = 0; m < PRIVATE_ROUNDS; ++m) {
-        oxy[m] = (f2){0.0f, 0.0f};
-        if (m >= (SHARE_FREE < SHARE_COPY ? SHARE_FREE : SHARE_COPY)) {
-            const float2 v = ray_xy[m * 64 + lane];
-            oxy[m] = (f2){v.x, v.y};
-        }
+        const float2 v = ray_xy[m * 64 + lane];
+        oxy[m] = (f2){v.x, v.y};
     }
+    K1_LITE(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                                    // B
-    windows_from_lds(win + 32, w);
-    __syncthreads();                                                    // B2 (a reset in the step wave: it has restaged windows 0, 1)
-    // (Measured, round 4: a share for this wave beside envs 1 / 2 as well -- with its stores deferred to the next phase so that the
-    // s_waitcnt vmcnt(0) for the window copy does not wait for their acknowledgement -- is slower, 36.3 vs 35.1 us per step: next to
-    // a window copy in flight the second casting wave gains nothing.  It casts beside envs 0 and 3 only.)
-    if (n_env > 0) private_cast<TRI, SHARE_FREE, PRIVATE_ROUNDS>(p, w, 0, tile0, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __syncthreads();                                                    // C
+    K1_LITE(4);
+    // env 0 under the step wave's manager tail.  (Measured, us per step at 4096 envs: this order 33.8; window 2 requested before
+    // barrier B as well 34.35 -- the step wave waits for the request's issue; window 1 requested only after env 0's cast 34.35.)
+    if (n_env > 0) private_cast<TRI, 0, PRIVATE_ROUNDS>(p, w, 0, tile0, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
+    K1_LITE(5);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    K1_LITE(6);
+    __syncthreads();                                                    // B: env 0 is cast, tile 0 is free
+    K1_LITE(7);
     if (n_env > 2) private_issue(p, w, 2, tile0, lane);
-    if (n_env > 1) private_cast<TRI, SHARE_COPY, PRIVATE_ROUNDS>(p, w, 1, tile1, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
+    if (n_env > 1) private_cast<TRI, SHARE_1, PRIVATE_ROUNDS>(p, w, 1, tile1, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
+    K1_LITE(8);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();                                                    // D
+    K1_LITE(9);
+    __syncthreads();                                                    // C: window 2 has landed, tile 1 is free
+    K1_LITE(10);
     if (n_env > 3) private_issue(p, w, 3, tile1, lane);
-    if (n_env > 2) private_cast<TRI, SHARE_COPY, PRIVATE_ROUNDS>(p, w, 2, tile0, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
+    K1_LITE(11);
+    if (n_env > 2) private_cast<TRI, SHARE_2, PRIVATE_ROUNDS>(p, w, 2, tile0, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
+    K1_LITE(12);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();                                                    // E
-    if (n_env > 3) private_cast<TRI, SHARE_FREE, PRIVATE_ROUNDS>(p, w, 3, tile1, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
+    K1_LITE(13);
+    __syncthreads();                                                    // D: window 3 has landed
+    K1_LITE(14);
+    if (n_env > 3) private_cast<TRI, SHARE_3, PRIVATE_ROUNDS>(p, w, 3, tile1, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
+    K1_LITE(15);
 }
 
 // ================================================================================================ K1g: step, group mapping
@@ -2308,6 +2372,7 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
     const SlotConst sc = d_SLOT[lane & 7];
     const GroupIds id = group_ids(lane, sc);
     K1_STAMP(0);
+    K1_LITE(0);
 
     const StepConsts &K = p.K;
     GroupLane g;
@@ -2362,27 +2427,17 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
         if (c.decimation > 0) physics_substep_group<true>(p, K, g, Fw, c.decimation - 1);
     }
     K1_STAMP(20);
-    if constexpr (FUSE == 1 || FUSE == 2) {   // the physics has fixed the pose (unless the env resets below): its windows go to the copy wave
-        const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-        windows_to_lds(fused_win(lds, p, wv), scan_window(p, g.pos, g.quat), lane);
+    K1_LITE(1);
+    if constexpr (FUSE == 1 || FUSE == 2) {
         __syncthreads();                                                // A
         if (c.decimation > 0) {
+            const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
             const float *lk = fused_link(lds, p, wv);
             Fw[3] = lk[320 + lane]; Fw[4] = lk[384 + lane]; Fw[5] = lk[128 + lane];
             if (!(lk[192 + lane] > RV_OBSTACLE_EPS)) { Fw[0] = 0.0f; Fw[1] = 0.0f; Fw[2] = 0.0f; }   // the wheel is not on the obstacle layer
         }
-        // the ray table of the scan phase: requested now, so that it arrives under the manager tail
-#pragma unroll
-        for (int m = 0; m < PRIVATE_ROUNDS; ++m) {
-            oxy[m] = (f2){0.0f, 0.0f};
-            if (m < (SHARE_FREE > SHARE_COPY ? SHARE_FREE : SHARE_COPY)) {
-                const float2 v = ray_xy[m * 64 + lane];
-                oxy[m] = (f2){v.x, v.y};
-            }
-        }
     }
     if (!id.wheel_active) { Fw[0] = 0.0f; Fw[1] = 0.0f; Fw[2] = 0.0f; Fw[3] = 0.0f; Fw[4] = 0.0f; Fw[5] = 0.0f; }
-    if (active) group_store(state, N, e, id, g);
     // contact report: gather the six Drive-body forces and the twelve link-point forces of the env (sensor body order) into
     // every lane -- only in waves where some body touches the obstacle layer (otherwise every force is the +0 the array holds)
     float F[ROVER_NUM_BODIES * 3];
@@ -2410,6 +2465,40 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
             for (int b = 0; b < 7; ++b) F[b * 3 + i] = Fb[b];
         }
     }
+    int coll_known = -1;   // one-launch forms: the collision flag, evaluated ahead of the other terms
+    if constexpr (FUSE == 1 || FUSE == 2) {
+        // The reset is decided NOW -- time-out / success / far are functions of words loaded before the physics (B-13: the terms
+        // see the previous step's command), the collision flag of the report just gathered -- so the FINAL pose is known here: the
+        // pose the physics left, or the spawn pose the copy wave drew.  Its windows go to the copy wave, which stages them and
+        // casts the first env under the rest of the manager tail.
+        const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const bool coll = any_force ? collision_measure(F) > 1.0f : false;
+        coll_known = coll ? 1 : 0;
+        bool term_e[ROVER_NUM_TERM];
+        mdp_terminations(c, S + ROVER_CMD_B, __float_as_int(S[ROVER_EP_LEN]) + 1, coll, term_e);
+        float pf[3] = {g.pos[0], g.pos[1], g.pos[2]}, qf[4] = {g.quat[0], g.quat[1], g.quat[2], g.quat[3]};
+        if (term_e[0] | term_e[1] | term_e[2] | term_e[3]) {
+            const float4 *d = reinterpret_cast<const float4 *>(fused_link(lds, p, wv) + 256 + (lane >> 4) * 12);
+            const float4 d0 = d[0], d1 = d[1];
+            pf[0] = d0.x; pf[1] = d0.y; pf[2] = d0.z;
+            qf[0] = d0.w; qf[1] = 0.0f; qf[2] = 0.0f; qf[3] = d1.x;
+        }
+        windows_to_lds(fused_win(lds, p, wv), scan_window(p, pf, qf), lane);
+        __syncthreads();                                                // A2
+        K1_LITE(2);
+        // the ray table of the scan phase: requested now, so that it arrives under the manager tail
+#pragma unroll
+        for (int m = 0; m < PRIVATE_ROUNDS; ++m) {
+            oxy[m] = (f2){0.0f, 0.0f};
+            if (m < SHARE_MAX) {
+                const float2 v = ray_xy[m * 64 + lane];
+                oxy[m] = (f2){v.x, v.y};
+            }
+        }
+    }
+    K1_LITE_F(11);
+    if (active) group_store(state, N, e, id, g, lane);
+    K1_LITE_F(12);
     if (force && active && id.owner) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) force[(size_t)(id.body * 3 + i) * N + e] = Fw[i];
@@ -2424,6 +2513,7 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
         }
     }
     K1_STAMP(23);
+    K1_LITE_F(13);
 
     // ---- MDP tail on the manager words (replicated in the group; loaded before the physics, see above)
 #pragma unroll
@@ -2442,8 +2532,9 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
     S[ROVER_EP_LEN] = __int_as_float(ep_len);
     float rew[ROVER_NUM_REW];
     bool term[ROVER_NUM_TERM];
-    mdp_terms_one(c, S + ROVER_CMD_B, S + ROVER_ACTION, S + ROVER_PREV_ACTION, ep_len, F, rew, term, !any_force);
+    mdp_terms_one(c, S + ROVER_CMD_B, S + ROVER_ACTION, S + ROVER_PREV_ACTION, ep_len, F, rew, term, !any_force, coll_known);
     K1_STAMP(24);
+    K1_LITE_F(14);
     const bool time_out = term[0];
     const bool term_any = term[1] | term[2] | term[3];
     const float step_dt = c.sim_dt * (float)c.decimation;
@@ -2459,9 +2550,11 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
     const bool do_reset = term_any | time_out;
     const bool writer = active && (lane & 15) == 0;
     if constexpr (BEGIN_ONLY) {
+        if (active) {
+            store_rows_by_lane<ROVER_TARGET_W, 16, ROVER_TARGET_W>(state, N, e, lane & 15, S);
+            store_rows_by_lane<ROVER_TARGET_W + 16, 10, ROVER_TARGET_W + 16>(state, N, e, lane & 15, S);
+        }
         if (writer) {
-#pragma unroll
-            for (int i = ROVER_TARGET_W; i < ROVER_LAMBDA_N; ++i) state[(size_t)i * N + e] = S[i];
             reward[e] = total;
             terminated[e] = term_any ? 1 : 0;
             truncated[e] = time_out ? 1 : 0;
@@ -2518,8 +2611,10 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
         }
     }
     K1_STAMP(21);
+    K1_LITE_F(15);
     command_compute(p, S, gid, step_dt);
     K1_STAMP(22);
+    K1_LITE_F(16);
 
     if (any_reset) {   // this wave's row of the log partials, tagged with the step; counted for the scan kernel's reduction
 #pragma unroll
@@ -2535,21 +2630,27 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
             p.log_counter[1] = p.step_tag;   // the latest launch with resets (every wave of a launch stores the same value)
         }
     }
-    if (writer) {
-        write_obs_head(p, S, obs, e);
-        if (FUSE == 0) write_scan_desc(p, S + ROVER_POS, S + ROVER_QUAT, e);
-        if (do_reset) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) state[(size_t)(ROVER_POS + i) * N + e] = S[ROVER_POS + i];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) state[(size_t)(ROVER_QUAT + i) * N + e] = S[ROVER_QUAT + i];
+    if (active) {   // the manager words are replicated in the env's sixteen lanes: lane r stores row W0 + r (store_rows_by_lane)
+        const int r = lane & 15;
+        {
+            float *o = obs + (size_t)e * p.obs_w;   // write_obs_head, one element per lane
+            const float cbx = S[ROVER_CMD_B], cby = S[ROVER_CMD_B + 1];
+            const float head[4] = {S[ROVER_ACTION], S[ROVER_ACTION + 1], sqrtf(cbx * cbx + cby * cby) * p.cfg.obs_scale_distance,
+                                   rv_atan2f(cby, cbx) * p.cfg.obs_scale_heading};
+            const float x = pick_by_lane<1, 4, 0, 4>(r, head, head[0]);
+            if (r < 4) o[r] = x;
         }
-#pragma unroll
-        for (int i = ROVER_TARGET_W; i < ROVER_LAMBDA_N; ++i) state[(size_t)i * N + e] = S[i];
-        state[(size_t)ROVER_RESET_COUNT * N + e] = S[ROVER_RESET_COUNT];
-        reward[e] = total;
-        terminated[e] = term_any ? 1 : 0;
-        truncated[e] = time_out ? 1 : 0;
+        if (FUSE == 0 && r == 0) write_scan_desc(p, S + ROVER_POS, S + ROVER_QUAT, e);
+        if (do_reset) store_rows_by_lane<ROVER_POS, 7, ROVER_POS>(state, N, e, r, S);
+        static_assert(ROVER_LAMBDA_N - ROVER_TARGET_W == 26, "manager words 39..64");
+        store_rows_by_lane<ROVER_TARGET_W, 16, ROVER_TARGET_W>(state, N, e, r, S);
+        store_rows_by_lane<ROVER_TARGET_W + 16, 10, ROVER_TARGET_W + 16>(state, N, e, r, S);
+        if (r == 0) {
+            state[(size_t)ROVER_RESET_COUNT * N + e] = S[ROVER_RESET_COUNT];
+            reward[e] = total;
+            terminated[e] = term_any ? 1 : 0;
+            truncated[e] = time_out ? 1 : 0;
+        }
     }
     K1_STAMP(25);
     if constexpr (FUSE == 3 || FUSE == 4) {   // no copy waves, one tile per wave (more than one round of workgroups)
@@ -2562,52 +2663,37 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
         K1_STAMP(26);
     }
     if constexpr (FUSE == 1 || FUSE == 2) {
-        // ---- height scan of the wave's four envs (see scan_copy_wave for the protocol).  Every lane of an env's row holds the
-        // env's final pose: the window is formed in all lanes, lane 16 j's copy goes to LDS (set 1) and becomes wave-uniform.
+        // ---- height scan of the wave's envs 1, 2, 3 (env 0: the copy wave's, under the tail above; see scan_copy_wave for the protocol)
         const int tile_cells = p.tile_dim * p.tile_pitch;
         const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         int16_t *tile0 = reinterpret_cast<int16_t *>(lds) + (size_t)(2 * wv) * tile_cells, *tile1 = tile0 + tile_cells;
         float *win = fused_win(lds, p, wv);
         const int n_scan = max(0, min(4, p.n - wave * 4));
         const int e_base = wave * 4;
-        const bool restage = __ballot(do_reset) != 0ull;   // a reset moved a rover of this wave: windows 0 / 1 were staged for the old pose
+        // the windows of the final poses: written by this wave before barrier A2 (the reset was decided there)
         PrivateWindows pw;
-        if (restage) {
-            const ScanWindow sw = scan_window(p, S + ROVER_POS, S + ROVER_QUAT);
-            windows_to_lds(win + 32, sw, lane);
-            private_windows(sw, pw);
-        } else {   // the pose the physics left is final: set 1 = set 0, and the windows come back from there (same bits)
-            if ((lane & 15) == 0) {
-                const float4 *s0 = reinterpret_cast<const float4 *>(win + (lane >> 4) * 8);
-                float4 *s1 = reinterpret_cast<float4 *>(win + 32 + (lane >> 4) * 8);
-                const float4 a0 = s0[0], a1 = s0[1];
-                s1[0] = a0;
-                s1[1] = a1;
-            }
-            windows_from_lds(win, pw);
-        }
-        __syncthreads();                                                // B
-        if (restage) {
-            if (n_scan > 0) private_issue(p, pw, 0, tile0, lane);
-            if (n_scan > 1) private_issue(p, pw, 1, tile1, lane);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the ray table (and a restaged window)
-        __syncthreads();                                                // B2
+        windows_from_lds(win, pw);
+        K1_LITE(3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the ray table
+        K1_LITE(4);
+        __syncthreads();                                                // B: the copy wave has cast env 0 and requested window 2
+        K1_LITE(5);
         K1_STAMP(27);
-        if (n_scan > 0) private_cast<FUSE == 2, 0, SHARE_FREE>(p, pw, 0, tile0, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
+        if (n_scan > 1) private_cast<FUSE == 2, 0, SHARE_1>(p, pw, 1, tile1, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         K1_STAMP(28);
-        __syncthreads();                                                // C
-        if (n_scan > 1) private_cast<FUSE == 2, 0, SHARE_COPY>(p, pw, 1, tile1, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
+        K1_LITE(6);
+        __syncthreads();                                                // C: window 2 has landed, tile 1 is free
+        K1_LITE(7);
+        if (n_scan > 2) private_cast<FUSE == 2, 0, SHARE_2>(p, pw, 2, tile0, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         K1_STAMP(29);
-        __syncthreads();                                                // D
-        if (n_scan > 2) private_cast<FUSE == 2, 0, SHARE_COPY>(p, pw, 2, tile0, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        K1_STAMP(31);
-        __syncthreads();                                                // E
-        if (n_scan > 3) private_cast<FUSE == 2, 0, SHARE_FREE>(p, pw, 3, tile1, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
+        K1_LITE(8);
+        __syncthreads();                                                // D: window 3 has landed
+        K1_LITE(9);
+        if (n_scan > 3) private_cast<FUSE == 2, 0, SHARE_3>(p, pw, 3, tile1, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
         K1_STAMP(26);
+        K1_LITE(10);
     }
 }
 // first half of the two-phase step, sixteen lanes per env (spill-free; the one-env-per-lane form of the same phase would carry
@@ -2665,7 +2751,7 @@ __global__ __launch_bounds__(RV_K1G_THREADS) void rover_physics_kernel_group(RvP
     for (int s = 0; s < substeps - 1; ++s) physics_substep_group<false>(p, K, g, nullptr);
     if (substeps > 0) physics_substep_group<true>(p, K, g, Fw);
     if (!id.wheel_active) { Fw[3] = 0.0f; Fw[4] = 0.0f; Fw[5] = 0.0f; }
-    if (active) group_store(state, N, e, id, g);
+    if (active) group_store(state, N, e, id, g, lane);
     if (force && active && id.owner) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) force[(size_t)(id.body * 3 + i) * N + e] = Fw[i];
@@ -4057,7 +4143,7 @@ int rover_debug_set_fused(rover_sim *sim, int fused)
     sim->fused = fused;
     return ROVER_OK;
 }
-#ifdef RV_K1_STAMP
+#if defined(RV_K1_STAMP) || defined(RV_K1_LITE)
 int rover_debug_set_k1_stamps(void *buf)
 {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_k1_stamps), &buf, sizeof(buf)) == hipSuccess ? ROVER_OK : ROVER_ERR_HIP;

@@ -17,12 +17,14 @@ sys.path.insert(0, ROOT)
 from isaac_rover_orbit_amd import build as b  # noqa: E402
 
 VARIANTS = {"K1STAMP": ("rover_kernels.hip", "-DRV_K1_STAMP"),            # s_memtime phase stamps in the step kernels (tools/k1_stamps.py)
+            "K1LITE": ("rover_kernels.hip", "-DRV_K1_LITE"),              # no-wait timeline of a step wave and its copy wave (tools/k1_lite.py)
+            "K1LITEF": ("rover_kernels.hip", "-DRV_K1_LITE -DRV_K1_LITE_FINE"),
             "LIFTSTAMP": ("lift_kernels.hip", "-DLF_STAMP"),               # ... in the lift step kernel (tools/lift_stamps.py)
             "POLSTAMP": ("policy_kernels.hip", "-DPOL_STAMP"),             # ... in the policy kernels (tools/policy_stamps.py [pair])
             "NOSLP": ("rover_kernels.hip", "-fno-slp-vectorize"),
-            # split of an env's sixteen ray rounds between a step wave and its copy wave (whole quads; tools/quick_bench.py)
-            "Q_S4_16": ("rover_kernels.hip", "-DRV_SHARE_FREE=4 -DRV_SHARE_COPY=16"), "Q_S8_16": ("rover_kernels.hip", "-DRV_SHARE_FREE=8 -DRV_SHARE_COPY=16"),
-            "Q_S4_12": ("rover_kernels.hip", "-DRV_SHARE_FREE=4 -DRV_SHARE_COPY=12"), "Q_S8_12": ("rover_kernels.hip", "-DRV_SHARE_FREE=8 -DRV_SHARE_COPY=12"),
+            # rounds (whole quads) of envs 1 / 2 / 3 cast by the step wave, the rest by its copy wave (tools/quick_bench.py)
+            **{f"SH_{a}_{b_}_{c}": ("rover_kernels.hip", f"-DRV_SHARE_1={a} -DRV_SHARE_2={b_} -DRV_SHARE_3={c}")
+               for (a, b_, c) in ((16, 16, 8), (16, 16, 12), (16, 16, 4), (16, 16, 16), (12, 16, 8), (16, 12, 8))},
             # policy pair kernel: round 3's sequential form; queue depths of the weight fragments
             "P_SEQ": ("policy_kernels.hip", "-DPOL_PAIR_SEQUENTIAL"), "P_QD1_3": ("policy_kernels.hip", "-DPOL_STAMP -DPOL_QD1=3"),
             "P_QD4_8": ("policy_kernels.hip", "-DPOL_STAMP -DPOL_QD4=8 -DPOL_QD5=10")}
