@@ -75,8 +75,10 @@ typedef struct rover_config {
     float friction_mu;
     int32_t solver_iterations;
     int32_t max_target_tries;
-    int32_t step_mapping;    /* mapping of the step kernel: 0 = auto (by num_envs), 1 = one env per lane,
-                                2 = sixteen lanes per env (wave-cooperative); results are bit-identical */
+    int32_t step_mapping;    /* mapping of the step kernel: 0 = auto = sixteen lanes per env (wave-cooperative, spill-free; ONE
+                                launch per step wherever the terrain / ray pattern allow it), 2 = the same, stated; 1 = one env
+                                per lane: faster than the two-launch form of the group mapping from ~65536 envs per GPU on, but
+                                its kernels carry 728 - 984 B of scratch per lane -- only on request.  Bit-identical results */
     int32_t spawn_draw;      /* how a reset picks its spawn table row (randomizations.py:22 `randperm(len(table))[:k]`):
                                 1 = DISTINCT rows inside one reset batch, like the reference's randperm prefix: row =
                                 (a * global_env_id + b) mod n_spawns, (a, b) redrawn for every reset()/step() call from

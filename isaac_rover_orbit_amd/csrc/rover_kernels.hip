@@ -425,9 +425,6 @@ struct Contact {
     float obst;
 };
 
-#ifndef RV_GROUP_MAPPING_BELOW
-#define RV_GROUP_MAPPING_BELOW 32768   // num_envs below which the auto mapping picks 16 lanes per env (tools/n_sweep.py)
-#endif
 #define RV_SPLIT_C 6.0f  // contacts sharing the chassis (mass splitting)
 #define RV_SPLIT_B 2.0f  // contacts sharing one bogie
 #define RV_TREE8(a) ((((a)[0] + (a)[1]) + ((a)[2] + (a)[3])) + (((a)[4] + (a)[5]) + ((a)[6] + (a)[7])))
@@ -3482,8 +3479,8 @@ static int fused_form(const rover_sim *sim)
     const bool fits1 = fused_lds_bytes(sim) <= sim->max_lds, fits2 = 2 * single_tile_lds_bytes(sim) <= sim->max_lds;
     if (sim->fused == 1) return fits1 ? 1 : 0;        // measurement hooks: force a form wherever its tiles fit
     if (sim->fused == 2) return fits2 ? 2 : 0;
-    // without the on-demand log reduction the one launch would need a second one after all (4 us behind the boundary)
-    if (!sim->log_deferred) return 0;
+    // (without the on-demand log reduction rover_log_kernel follows the one launch: still shorter than step + scan kernel with
+    // the reduction in its last workgroup -- 4096 envs: 33.9 + ~5 us against 45.3 us)
     // The copy-wave form holds ONE workgroup per CU: it is the one to use while one round of workgroups holds the batch -- and
     // not far below that either: the scan phase of a wave is four envs long whatever the batch, while the scan KERNEL shrinks
     // with it (N sweep: 1024 envs 36.7 vs 34.6 us, 4096 envs 42.0 vs 47.1 us per step; break-even near 2048 envs on 256 CUs).
@@ -3493,21 +3490,12 @@ static int fused_form(const rover_sim *sim)
     return (sim->single_tile_ok && fits2) ? 2 : 0;
 }
 static bool fused_step(const rover_sim *sim) { return fused_form(sim) != 0; }
-// The automatic mapping (cfg.step_mapping = 0) from RV_GROUP_MAPPING_BELOW envs on: sixteen lanes per env if that runs as one
-// launch (single-tile form: 178 / 185 M env-steps/s at 65536 / 131072 envs), else one env per lane (165 / 168 M; the TWO-launch
-// group mapping is the slowest of the three there: 151 / 153 M).  Re-evaluated before a launch: the int16 terrain copy and the
-// on-demand log may be set after rover_create.  Both mappings produce the same bits from the same state layout.
-static void refresh_mapping(rover_sim *sim)
-{
-    if (sim->p.cfg.step_mapping != 0 || sim->p.n < RV_GROUP_MAPPING_BELOW) return;
-    auto set = [&](bool group) {
-        sim->group_mapping = group;
-        sim->step_blocks = group ? (sim->p.n + RV_K1G_ENVS - 1) / RV_K1G_ENVS : (sim->p.n + 63) / 64;
-        sim->n_waves = group ? sim->step_blocks * (RV_K1G_THREADS / 64) : sim->step_blocks;
-    };
-    set(true);
-    if (fused_form(sim) == 0) set(false);
-}
+// The automatic mapping (cfg.step_mapping = 0) is sixteen lanes per env at every batch size: as one launch wherever the terrain /
+// pattern allow it (fused_form), else as the two launches of the group mapping.  One env per lane (cfg.step_mapping = 1) is faster
+// than those two launches from ~65536 envs on (tools/n_sweep.py: 164 against 131 M env-steps/s at 65536 envs; slower at 32768:
+// 116 against 142 M) but its kernels carry 728 - 984 bytes of scratch per lane: an explicit choice, never the automatic one.
+// Both mappings produce the same bits from the same state layout.
+static void refresh_mapping(rover_sim *) {}
 // the kernel launches of one env step (rover_step / rover_profile_step); ev: optional event recorded between the two launches
 static void launch_step_kernels(rover_sim *sim, hipStream_t st, const float *action, float *obs, float *reward, uint8_t *terminated,
                                 uint8_t *truncated, float *force, float *log, hipEvent_t mid);
@@ -3736,7 +3724,7 @@ int rover_create(const rover_config *cfg, int32_t num_envs, int32_t env_id_offse
     }
     if (cfg->step_mapping < 0 || cfg->step_mapping > 2) { delete s; return fail(ROVER_ERR_INVALID, "step_mapping must be 0, 1 or 2"); }
     // latency mapping (16 lanes per env) while one-env-per-lane would leave most SIMDs without a wave
-    s->group_mapping = cfg->step_mapping == 2 || (cfg->step_mapping == 0 && num_envs < RV_GROUP_MAPPING_BELOW);
+    s->group_mapping = cfg->step_mapping != 1;   // one env per lane only on request (its kernels spill: see refresh_mapping)
     // log-partial rows = waves launched (the group mapping launches whole 256-thread workgroups)
     s->step_blocks = s->group_mapping ? (num_envs + RV_K1G_ENVS - 1) / RV_K1G_ENVS : (num_envs + 63) / 64;
     s->n_waves = s->group_mapping ? s->step_blocks * (RV_K1G_THREADS / 64) : s->step_blocks;

@@ -23,7 +23,8 @@ def make_env(n, ter, **over):
     cfg = RoverEnvCfg()
     cfg.scene.num_envs = n
     cfg.terrain.kind = "custom"
-    if over.get("step_mapping") == "group2":     # the group mapping as TWO launches (log reduced behind every step by the scan kernel)
+    two_launches = over.get("step_mapping") == "group2"
+    if two_launches:     # the group mapping as TWO launches (log reduced behind every step by the scan kernel)
         over = dict(over, step_mapping="group", log_reduction="every_step")
     fused_form = 2 if over.get("step_mapping") == "group1" else 1   # "group1": one launch, single-tile form (no copy waves)
     if over.get("step_mapping") == "group1":
@@ -39,7 +40,17 @@ def make_env(n, ter, **over):
         fn = C.CDLL(env._lib._name).rover_debug_set_fused
         fn.argtypes = [C.c_void_p, C.c_int]
         assert fn(env._h, fused_form) == 0
+    if two_launches:
+        _set_fused(env, 0)
     return env
+
+
+def _set_fused(env, form):
+    """Measurement / test hook of the library: 0 = two launches per step, 1 = one launch with copy waves, 2 = one launch, single tile."""
+    import ctypes as C
+    fn = C.CDLL(env._lib._name).rover_debug_set_fused
+    fn.argtypes = [C.c_void_p, C.c_int]
+    assert fn(env._h, form) == 0
 
 
 def oracle_side(ro, env, counter=None):
@@ -673,15 +684,18 @@ def test_kernel_names_markers_and_spawn_table_check():
         env = make_env(n_envs, ter)
         assert env.kernel_names()[0] == name, (n_envs, env.kernel_names())
         env.close()
-    # the automatic mapping at 32768 envs and more: sixteen lanes per env when that is one launch, else one env per lane
+    # the automatic mapping is sixteen lanes per env at every size (the one-env-per-lane kernels spill: only on request)
     env = make_env(32768, ter)
     assert env.kernel_names() == ("rover_step_scan1_kernel<true>", "")
     env.close()
-    env = make_env(32768, ter, log_reduction="every_step")
-    assert env.kernel_names()[0] == "rover_step_kernel"
+    env = make_env(32768, ter, log_reduction="every_step")                   # eager log: the same launch + the log reduction
+    assert env.kernel_names() == ("rover_step_scan1_kernel<true>", "rover_log_kernel")
     env.close()
-    env = make_env(16 * cus, ter, log_reduction="every_step")                # ... and only with the log reduced on demand
+    env = make_env(32768, ter, use_int16_terrain=False)                      # no one-launch form: two launches, still spill-free
     assert env.kernel_names()[0] == "rover_step_kernel_group"
+    env.close()
+    env = make_env(16 * cus, ter, log_reduction="every_step")
+    assert env.kernel_names() == ("rover_step_scan_kernel<true>", "rover_log_kernel")
     env.set_markers(True)
     env.reset()
     o1 = env.step(torch.zeros(env.num_envs, 2, device="cuda"))[0]["policy"].clone()
@@ -769,11 +783,8 @@ def test_random_configurations_match_oracle(oracle, seed):
     cfg.spawn_draw = str(rng.choice(["distinct", "independent"]))
     cfg.log_reduction = str(rng.choice(["on_demand", "every_step"]))      # with "group" + int16 terrain: one launch per step / two
     env = RoverEnv(cfg, terrain=ter)
-    if cfg.step_mapping == "group" and cfg.log_reduction == "on_demand":       # one launch per step wherever that kernel can run
-        import ctypes as C
-        fn = C.CDLL(env._lib._name).rover_debug_set_fused
-        fn.argtypes = [C.c_void_p, C.c_int]
-        assert fn(env._h, 1) == 0
+    if cfg.step_mapping == "group":       # on demand: one launch per step wherever that kernel can run; every step: two launches
+        _set_fused(env, 1 if cfg.log_reduction == "on_demand" else 0)
     assert env.num_rays == nx * ny, (env.num_rays, nx, ny, res)
     actions = rng.uniform(-1, 1, (12, n, 2)).astype(np.float32)
     flips = rollout_compare(oracle, env, 12, actions, 0.0, 0.0, resync=False)

@@ -15,6 +15,8 @@ def make(mode):
     cfg = RoverEnvCfg(); cfg.scene.num_envs = n; cfg.terrain.kind = "custom"; cfg.step_mapping = "group"; cfg.log_reduction = mode
     env = RoverEnv(cfg, terrain=ter); env.reset(); return env
 a, b = make("every_step"), make("on_demand")
+ff0 = C.CDLL(a._lib._name).rover_debug_set_fused; ff0.argtypes = [C.c_void_p, C.c_int]
+assert ff0(a._h, 0) == 0              # a: two launches per step
 if os.environ.get("FUSED_FORM"):      # 1 = copy-wave form, 2 = single-tile form, whatever the batch size
     ff = C.CDLL(b._lib._name).rover_debug_set_fused; ff.argtypes = [C.c_void_p, C.c_int]
     assert ff(b._h, int(os.environ["FUSED_FORM"])) == 0

@@ -30,9 +30,9 @@ for case in CASES:
     if mapping == "group2":
         cfg.log_reduction = "every_step"
     env = RoverEnv(cfg, terrain=ter)
-    if mapping in ("groupf", "group1"):      # one launch forced: copy-wave form / single-tile form
+    if mapping in ("groupf", "group1", "group2"):      # forced: one launch, copy-wave form / single-tile form; two launches
         ff = C.CDLL(env._lib._name).rover_debug_set_fused; ff.argtypes = [C.c_void_p, C.c_int]
-        assert ff(env._h, 1 if mapping == "groupf" else 2) == 0
+        assert ff(env._h, {"groupf": 1, "group1": 2, "group2": 0}[mapping]) == 0
     fn = C.CDLL(env._lib._name).rover_debug_set_scan_form
     fn.argtypes = [C.c_void_p, C.c_int]
     assert fn(env._h, FORMS[form]) == 0

@@ -31,4 +31,8 @@ def run(env):
 run(env)
 if os.environ.get("ROVER_ALSO_TWO_LAUNCH"):   # the same workload on the two-launch path (the traffic of the step kernel alone)
     cfg2 = RoverEnvCfg(); cfg2.scene.num_envs = n; cfg2.terrain.kind = "custom"; cfg2.log_reduction = "every_step"
-    run(RoverEnv(cfg2, terrain=ter))
+    env2 = RoverEnv(cfg2, terrain=ter)
+    import ctypes as C
+    ff = C.CDLL(env2._lib._name).rover_debug_set_fused; ff.argtypes = [C.c_void_p, C.c_int]
+    assert ff(env2._h, 0) == 0
+    run(env2)
