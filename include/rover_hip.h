@@ -193,10 +193,11 @@ int rover_step_finish(rover_sim *sim, const uint8_t *reset_mask, float *obs, flo
  * training loop), a random-action rollout never does.  With rover_set_log_deferred(sim, 1) rover_step leaves `log` alone; rover_flush_log
  * produces, at any later point on the same stream, exactly the vector the per-step reduction would hold there: [0..12] from the
  * latest step in which an env reset, [13] = the number of envs reset in the latest step (0 when the latest resets are older).
- * Flush at most once per step (a second flush without a step in between reports [13] = 0).  Deferral is also what lets
- * rover_step run as ONE kernel launch -- the height scan as the last phase of the step kernel's waves (group mapping, int16
- * terrain copy, a batch of at least eight envs per compute unit): without it a second launch would follow for the log alone.
- * Default: not deferred (two launches; the scan kernel's first workgroup reduces the log). */
+ * Flush at most once per step (a second flush without a step in between reports [13] = 0).  With deferral rover_step is ONE
+ * kernel launch wherever the one-launch form applies -- the height scan as the last phase of the step kernel's waves (group
+ * mapping, int16 terrain copy, at most 1024 rays, a batch of at least eight envs per compute unit); without it rover_log_kernel
+ * follows that launch.  Where the form does not apply a step is two launches (the scan kernel's first workgroup reduces the log).
+ * Default: not deferred. */
 int rover_set_log_deferred(rover_sim *sim, int32_t deferred);
 /* Observation rows with streaming (non-temporal) stores in the one-launch kernels: 1 = on.  Worth ~2 % of the step when nothing on
  * the device reads the rows next (a host-side consumer, a random-action rollout); leave it off (default) when a policy kernel

@@ -26,14 +26,16 @@ t0 = s[:, 0:1]
 step = {0: "start", 1: "physics done (before A)", 2: "after A2 (reset decided, final windows written)", 11: "ray table requested", 12: "group_store issued",
         13: "force rows stored", 14: "mdp terms", 15: "rewards + reset", 16: "command", 3: "tail done (log, final stores issued)", 4: "ray table / stores retired",
         5: "after B", 6: "env 1 share cast", 7: "after C", 8: "env 2 cast", 9: "after D", 10: "end (env 3 share cast)"}
-copy = {0: "before A (link work done)", 1: "after A", 2: "after A2", 3: "window 0 + ray table requested", 4: "... landed", 5: "env 0 cast",
-        6: "window 1 requested", 7: "after B (window 1 landed)", 8: "window 2 requested (+ env 1 share cast)", 9: "... window 2 landed",
+copy = {0: "before A (link work done)", 1: "after A", 2: "after A2", 3: "windows 0, 1 + ray table requested", 4: "... landed", 5: "env 0 cast",
+        6: "... its stores retired", 7: "after B", 8: "window 2 requested (+ env 1 share cast)", 9: "... window 2 landed",
         10: "after C", 11: "window 3 requested", 12: "env 2 share cast", 13: "... window 3 landed", 14: "after D", 15: "end (env 3 share cast)"}
 print(env.kernel_names()[0])
 for name, off, labels in (("step wave", 0, step), ("copy wave", 32, copy)):
     print(name)
     prev = None
     for i, lab in labels.items():
+        if not (s[:, off + i] > 0).all():      # a fine stamp (build K1LITEF only)
+            continue
         d = s[:, off + i] - t0[:, 0]
         m = np.median(d)
         print(f"  {lab:50s} {m:8.0f}  (p90 {np.percentile(d, 90):8.0f})" + (f"   +{m - prev:6.0f}" if prev is not None else ""))
