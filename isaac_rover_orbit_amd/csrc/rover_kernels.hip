@@ -1737,6 +1737,13 @@ __device__ __forceinline__ void group_load(const float *__restrict__ state, int 
 // -1.3 us, the copy waves' window requests queue behind them), a 16-way select ~15 VALU instructions.
 // (The select chain is a template recursion: written as a loop, hipcc recognises `x = v[r]` in it, turns it into a run-time index
 // and sends the whole array to scratch -- or, promoted, to LDS.)
+// word `row` of env e in an SoA array of rows of N floats, addressed by a 32-bit BYTE offset (rows x N x 4 < 4 GiB: checked at
+// bind time): the store becomes `global_store_dword voffset, vdata, s[base]` -- no 64-bit multiply-add per lane
+__device__ __forceinline__ float *soa_word(float *__restrict__ base, int row, int N, int e)
+{
+    const unsigned byte_off = ((unsigned)row * (unsigned)N + (unsigned)e) * 4u;
+    return reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off);
+}
 template <int I, int CNT, int OFF, int LEN>
 __device__ __forceinline__ float pick_by_lane(int r, const float (&v)[LEN], float x)
 {
@@ -1748,7 +1755,7 @@ __device__ __forceinline__ void store_rows_by_lane(float *__restrict__ state, in
 {
     static_assert(CNT >= 1 && CNT <= 16 && OFF + CNT <= LEN, "one row per lane of the group");
     const float x = pick_by_lane<1, CNT, OFF, LEN>(r, v, v[OFF]);
-    if (r < CNT) state[(size_t)(W0 + r) * N + e] = x;
+    if (r < CNT) *soa_word(state, W0 + r, N, e) = x;
 }
 __device__ __forceinline__ void group_store(float *__restrict__ state, int N, int e, const GroupIds &id, const GroupLane &g, int lane)
 {
@@ -1760,16 +1767,16 @@ __device__ __forceinline__ void group_store(float *__restrict__ state, int N, in
     }
     if (id.owner) {
         if ((id.slot & 1) == 0) {
-            state[(size_t)(ROVER_BOGIE_Q + id.j) * N + e] = g.bq;
-            state[(size_t)(ROVER_BOGIE_QD + id.j) * N + e] = g.bqd;
+            *soa_word(state, ROVER_BOGIE_Q + id.j, N, e) = g.bq;
+            *soa_word(state, ROVER_BOGIE_QD + id.j, N, e) = g.bqd;
         }
         if (id.si >= 0) {
-            state[(size_t)(ROVER_STEER_Q + id.si) * N + e] = g.sq;
-            state[(size_t)(ROVER_STEER_QD + id.si) * N + e] = g.sqd;
+            *soa_word(state, ROVER_STEER_Q + id.si, N, e) = g.sq;
+            *soa_word(state, ROVER_STEER_QD + id.si, N, e) = g.sqd;
         }
-        state[(size_t)(ROVER_WHEEL_Q + id.k) * N + e] = g.wq;
-        state[(size_t)(ROVER_WHEEL_QD + id.k) * N + e] = g.wqd;
-        state[(size_t)(ROVER_LAMBDA_N + id.k) * N + e] = g.lam;
+        *soa_word(state, ROVER_WHEEL_Q + id.k, N, e) = g.wq;
+        *soa_word(state, ROVER_WHEEL_QD + id.k, N, e) = g.wqd;
+        *soa_word(state, ROVER_LAMBDA_N + id.k, N, e) = g.lam;
     }
 }
 
@@ -2498,7 +2505,7 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
     K1_LITE_F(12);
     if (force && active && id.owner) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) force[(size_t)(id.body * 3 + i) * N + e] = Fw[i];
+        for (int i = 0; i < 3; ++i) *soa_word(force, id.body * 3 + i, N, e) = Fw[i];
     }
     if (force && active && (lane & 15) < 7) {   // the three rows of the seven link bodies
 #pragma unroll
@@ -2506,7 +2513,7 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
             float fb = F[i];
 #pragma unroll
             for (int b = 1; b < 7; ++b) fb = ((lane & 15) == b) ? F[b * 3 + i] : fb;
-            force[(size_t)((lane & 15) * 3 + i) * N + e] = fb;
+            *soa_word(force, (lane & 15) * 3 + i, N, e) = fb;
         }
     }
     K1_STAMP(23);
@@ -3694,6 +3701,8 @@ int rover_create(const rover_config *cfg, int32_t num_envs, int32_t env_id_offse
 {
     if (!cfg || !out) return fail(ROVER_ERR_INVALID, "cfg/out is NULL");
     if (num_envs <= 0 || env_id_offset < 0) return fail(ROVER_ERR_INVALID, "num_envs must be > 0 and env_id_offset >= 0");
+    if ((uint64_t)ROVER_STATE_WORDS * (uint64_t)num_envs * 4u >= (1ull << 32))   // soa_word(): 32-bit byte offsets into the SoA arrays
+        return fail(ROVER_ERR_UNSUPPORTED, "num_envs per handle must stay below 2^32 / (72 x 4) = 14.9 M (shard the batch over handles)");
     if (cfg->scan_nx > 64 || cfg->scan_ny > 64) return fail(ROVER_ERR_UNSUPPORTED, "scan grid larger than 64 x 64 rays");
     if (cfg->scan_nx <= 0 || cfg->scan_ny <= 0 || cfg->scan_resolution <= 0.0f || cfg->decimation < 0 ||
         cfg->solver_iterations < 0 || cfg->max_target_tries < 1 || cfg->sim_dt <= 0.0f || cfg->max_episode_length <= 0 ||
