@@ -2265,6 +2265,15 @@ __device__ __forceinline__ void scan_copy_wave(const RvParams &p, const float *_
     const int e_base = (int)(blockIdx.x * 4 + partner) * 4;
     const int n_env = max(0, min(4, p.n - e_base));
     PrivateWindows w;
+    // the ray table: the same 8 KB for every wave of every step.  Requested NOW -- this wave has registers to spare during the
+    // physics -- and not behind barrier A2, where its sixteen loads would queue in front of env 0's cast with the window requests
+    // (a load instruction costs ~120 cycles of the wave's issue there, whatever it carries)
+    f2 oxy[PRIVATE_ROUNDS];
+#pragma unroll
+    for (int m = 0; m < PRIVATE_ROUNDS; ++m) {
+        const float2 v = ray_xy[m * 64 + lane];
+        oxy[m] = (f2){v.x, v.y};
+    }
     {   // before anything of this step is known: what a reset of each of the partner's envs WOULD draw (spawn row, yaw, target with
         // its rejection loop, heading: functions of (global id, reset count) and the terrain).  The copy wave is asleep during the
         // physics anyway; the step wave's reset becomes a handful of LDS reads instead of Philox rounds and dependent loads.
@@ -2312,12 +2321,6 @@ __device__ __forceinline__ void scan_copy_wave(const RvParams &p, const float *_
     windows_from_lds(win, w);
     if (n_env > 0) private_issue(p, w, 0, tile0, lane);
     if (n_env > 1) private_issue(p, w, 1, tile1, lane);
-    f2 oxy[PRIVATE_ROUNDS];
-#pragma unroll
-    for (int m = 0; m < PRIVATE_ROUNDS; ++m) {
-        const float2 v = ray_xy[m * 64 + lane];
-        oxy[m] = (f2){v.x, v.y};
-    }
     K1_LITE(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     K1_LITE(4);
@@ -2607,10 +2610,9 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
                         state[(size_t)(ROVER_BOGIE_QD + id.j) * N + e] = 0.0f;
                     }
                 }
-                if (id.slot == 0 && !id.role_b) {
-#pragma unroll
-                    for (int i = ROVER_LINVEL; i < ROVER_BOGIE_Q; ++i) state[(size_t)i * N + e] = 0.0f;
-                }
+                // chassis velocities: by the lanes that stored them in group_store (lane r owns row r: same lane, same address,
+                // program order)
+                if ((lane & 15) >= ROVER_LINVEL && (lane & 15) < ROVER_BOGIE_Q) *soa_word(state, lane & 15, N, e) = 0.0f;
             }
         }
     }

@@ -10,7 +10,7 @@ _lib.LIB_PATH = os.path.join(ROOT, "build", "abl", f"librover_abl{os.environ.get
 from isaac_rover_orbit_amd import terrain as T
 from isaac_rover_orbit_amd.cfg import RoverEnvCfg
 from isaac_rover_orbit_amd.envs import RoverEnv
-n = 4096
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 ter = T.make_procedural_terrain((2048, 2048), seed=1234, n_rocks=400); ter.make_spawns(2 * n, seed=41)
 cfg = RoverEnvCfg(); cfg.scene.num_envs = n; cfg.terrain.kind = "custom"
 env = RoverEnv(cfg, terrain=ter); env.reset()
