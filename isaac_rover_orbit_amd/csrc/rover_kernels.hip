@@ -1587,7 +1587,7 @@ __device__ __forceinline__ void step_lane_body(const RvParams &p, float *__restr
             log_partial[(size_t)blockIdx.x * ROVER_LOG_WORDS + threadIdx.x] = vsel;
         }
         if (threadIdx.x == 0) {
-            atomicAdd(p.log_counter, 1u);
+            p.log_counter[0] = 1u;           // "rows to reduce": a flag (tested against zero, returned to zero by the reduction)
             p.log_counter[1] = p.step_tag;   // the latest launch with resets
         }
     }
@@ -2568,19 +2568,17 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
         }
         return;
     }
-    // episodic log contributions: only waves in which some env resets pay for the 14 wave reductions
+    // episodic log contributions (before the reset clears the sums): the manager words are replicated in the env's sixteen lanes,
+    // so lane r of the group forms word r of its env's contribution itself -- no transposition, ONE value per lane to reduce
     const bool any_reset = __ballot(do_reset && writer) != 0ull;
-    float lg[14];
-#pragma unroll
-    for (int i = 0; i < 14; ++i) lg[i] = 0.0f;
-    if (do_reset && writer) {
-#pragma unroll
-        for (int i = 0; i < ROVER_NUM_REW; ++i) lg[i] = S[ROVER_EP_SUM + i];
-#pragma unroll
-        for (int i = 0; i < ROVER_NUM_TERM; ++i) lg[7 + i] = term[i] ? 1.0f : 0.0f;
-        lg[11] = S[ROVER_METRIC_POS];
-        lg[12] = S[ROVER_METRIC_HEAD];
-        lg[13] = 1.0f;
+    float lgx = 0.0f;
+    if (do_reset && active) {
+        const float lgv[14] = {S[ROVER_EP_SUM + 0], S[ROVER_EP_SUM + 1], S[ROVER_EP_SUM + 2], S[ROVER_EP_SUM + 3], S[ROVER_EP_SUM + 4],
+                               S[ROVER_EP_SUM + 5], S[ROVER_EP_SUM + 6], term[0] ? 1.0f : 0.0f, term[1] ? 1.0f : 0.0f,
+                               term[2] ? 1.0f : 0.0f, term[3] ? 1.0f : 0.0f, S[ROVER_METRIC_POS], S[ROVER_METRIC_HEAD], 1.0f};
+        static_assert(ROVER_NUM_REW == 7 && ROVER_NUM_TERM == 4, "log row layout");
+        const float x = pick_by_lane<1, 14, 0, 14>(lane & 15, lgv, lgv[0]);
+        lgx = (lane & 15) < 14 ? x : 0.0f;
     }
     const uint32_t gid = (uint32_t)(p.env_id_offset + e);
     if (do_reset) {
@@ -2622,17 +2620,16 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
     K1_STAMP(22);
     K1_LITE_F(16);
 
-    if (any_reset) {   // this wave's row of the log partials, tagged with the step; counted for the scan kernel's reduction
-#pragma unroll
-        for (int i = 0; i < 14; ++i) lg[i] = wave_sum(lg[i]);
-        if (lane < 16) {
-            float vsel = lane == 15 ? __uint_as_float(p.step_tag) : 0.0f;
-#pragma unroll
-            for (int i = 0; i < 14; ++i) vsel = (lane == i) ? lg[i] : vsel;
-            log_partial[(size_t)wave * ROVER_LOG_WORDS + lane] = vsel;
-        }
+    if (any_reset) {   // this wave's row of the log partials, tagged with the step, and the flag for the reduction
+        // Sum over the wave's four envs in the order of the 64-lane butterfly this replaces -- (env 0 + env 2) + (env 1 + env 3),
+        // then the butterfly's four additions of the other lanes' +0, which only ever turn a -0 into +0: one addition of +0.
+        float x = lgx;
+        x += __shfl_xor(x, 32, 64);
+        x += __shfl_xor(x, 16, 64);
+        x = x + 0.0f;
+        if (lane < 16) log_partial[(size_t)wave * ROVER_LOG_WORDS + lane] = lane == 15 ? __uint_as_float(p.step_tag) : x;
         if (lane == 0) {
-            atomicAdd(p.log_counter, 1u);
+            p.log_counter[0] = 1u;           // "rows to reduce" (the reduction tests it against zero and returns it to zero)
             p.log_counter[1] = p.step_tag;   // the latest launch with resets (every wave of a launch stores the same value)
         }
     }

@@ -19,8 +19,14 @@ fn = env._lib.rover_debug_set_k1_stamps; fn.argtypes = [C.c_void_p]
 assert fn(C.c_void_p(stamps.data_ptr())) == 0
 g = torch.Generator(device="cuda").manual_seed(0)
 acts = torch.rand(40, n, 2, device="cuda", generator=g) * 2 - 1
-for k in range(40): env.step(acts[k])
+S = env.get_state()      # every 37th env times out in the LAST of the 40 steps: what do the workgroups with a reset cost?
+S[::37, 51] = torch.tensor([env.max_episode_length - 40], dtype=torch.int32).view(torch.float32).item()
+env.set_state(S)
+for k in range(40): out = env.step(acts[k])
 torch.cuda.synchronize()
+_r = torch.nonzero(out[2] | out[3]).flatten()
+reset_wg = torch.unique(_r // 16).cpu().numpy()      # workgroups with an env that reset in the last step
+reset_w0 = torch.unique(_r[(_r % 16) < 4] // 16).cpu().numpy()      # ... in their wave 0 (the stamped step wave)
 s = stamps.cpu().numpy().astype(np.float64)
 t0 = s[:, 0:1]
 step = {0: "start", 1: "physics done (before A)", 2: "after A2 (reset decided, final windows written)", 11: "ray table requested", 12: "group_store issued",
@@ -40,3 +46,21 @@ for name, off, labels in (("step wave", 0, step), ("copy wave", 32, copy)):
         m = np.median(d)
         print(f"  {lab:50s} {m:8.0f}  (p90 {np.percentile(d, 90):8.0f})" + (f"   +{m - prev:6.0f}" if prev is not None else ""))
         prev = m
+end = np.maximum(s[:, 10], s[:, 32 + 15]) - t0[:, 0]
+mask = np.zeros(end.shape[0], bool); mask[reset_wg] = True
+print(f"workgroup end (later of the two waves): median {np.median(end):.0f}, p90 {np.percentile(end, 90):.0f}, max {end.max():.0f}; "
+      f"the {mask.sum()} workgroups with a reset in this step: {np.sort(end[mask]).astype(int).tolist()}; start spread {s[:, 0].max() - s[:, 0].min():.0f} cycles; "
+      f"first start -> last end {(np.maximum(s[:, 10], s[:, 47]).max() - s[:, 0].min()):.0f} cycles")
+top = np.argsort(end)[-6:]
+for w in top:
+    print(f"  slow workgroup {w}: end {end[w]:.0f}  physics done {s[w, 1] - s[w, 0]:.0f}  A2 {s[w, 2] - s[w, 0]:.0f}  tail done {s[w, 3] - s[w, 0]:.0f}  B {s[w, 5] - s[w, 0]:.0f}  reset in it: {bool(mask[w])}")
+mask0 = np.zeros(end.shape[0], bool); mask0[reset_w0] = True
+if mask0.any() and (~mask).any():      # segment by segment: workgroups with a reset against the others (step wave; fine stamps if the build has them)
+    keys = [k for k in step if (s[:, k] > 0).all()]
+    prev = None
+    print(f"step wave 0, median cycles per segment: no reset in the workgroup / a reset in wave 0 ({mask0.sum()} workgroups)")
+    for k in keys:
+        if prev is not None:
+            d = s[:, k] - s[:, prev]
+            print(f"  {step[k]:50s} {np.median(d[~mask]):8.0f} {np.median(d[mask0]):8.0f}")
+        prev = k
