@@ -1022,52 +1022,19 @@ __device__ __forceinline__ void slot_sum4(float &a0, float &a1, float &a2, float
         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
 }
 
+// Phase stamps of the diagnostic builds (tools/build_diag.py); nothing in the product build.
 #if defined(RV_K1_STAMP) || defined(RV_K1_LITE)
-__device__ unsigned long long *g_k1_stamps;
+#include "rover_diag.inc"
 #endif
-// RV_K1_LITE: a timeline of the one-launch kernel's two waves on SIMD 0 (step wave 0: slots 0.., copy wave 4: slots 16..) from
-// stamps that do not wait for anything -- the waiting stamps below serialise the very overlap this timeline is about
-#ifdef RV_K1_LITE
-__device__ __forceinline__ void k1_lite(int slot)
-{
-    if ((threadIdx.x & 255) == 0) {
-        unsigned long long t;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-        g_k1_stamps[(size_t)blockIdx.x * 64 + (threadIdx.x >> 8) * 32 + slot] = t;
-    }
-}
-#define K1_LITE(k) k1_lite(k)
-#else
-#define K1_LITE(k) do { } while (0)
-#endif
-#ifdef RV_K1_LITE_FINE   // more stamps inside the manager tail / the first staging (each costs the wave several hundred cycles)
-#define K1_LITE_F(k) k1_lite(k)
-#else
-#define K1_LITE_F(k) do { } while (0)
-#endif
-#ifdef RV_K1_STAMP
-__device__ __forceinline__ void k1_stamp(int slot)
-{
-    if (threadIdx.x == 0) {
-        unsigned long long t;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-        g_k1_stamps[(size_t)blockIdx.x * 32 + slot] = t;
-    }
-}
-// a stamp that does not wait for the wave's outstanding memory operations (is an instruction's ISSUE what takes the time?)
-__device__ __forceinline__ void k1_stamp_nowait(int slot)
-{
-    if (threadIdx.x == 0) {
-        unsigned long long t;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-        g_k1_stamps[(size_t)blockIdx.x * 32 + slot] = t;
-    }
-}
-#define K1_STAMP(k) k1_stamp(k)
-#define K1_STAMP_NOWAIT(k) k1_stamp_nowait(k)
-#else
+#ifndef K1_STAMP
 #define K1_STAMP(k) do { } while (0)
 #define K1_STAMP_NOWAIT(k) do { } while (0)
+#endif
+#ifndef K1_LITE
+#define K1_LITE(k) do { } while (0)
+#endif
+#ifndef K1_LITE_F
+#define K1_LITE_F(k) do { } while (0)
 #endif
 // the projected-Jacobi iterations of one lane (wheel slot x role): see the arithmetic contract above RoleRows
 __device__ __forceinline__ void solver_iteration_generic(const StepConsts &K, Contact &ct, const RoleRows &rr, f2 *V, float cw,
