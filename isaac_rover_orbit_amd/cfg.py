@@ -13,8 +13,10 @@ a reward or termination entry whose ``func`` is a *callable* -- signature ``func
 ``mdp/rewards.py:14-137`` / ``mdp/terminations.py:14-64`` -- is kept and evaluated in torch by ``RoverEnv.step`` on the env's
 manager / scene facades between the two halves of the step (``rover_step_begin`` / ``rover_step_finish``: the SLOW path, three
 launches + the torch ops of the terms).  The built-in entries must stay in the table (a built-in reward is switched off with
-``weight=0``); with the stock table the env takes the one-launch fast path.  Observation terms are fixed (they define the row
-layout the policy checkpoint expects); ``noise`` / ``clip`` are not implemented.
+``weight=0``); with the stock table the env takes the one-launch fast path.  The observation TERMS are fixed (they define the row
+layout the policy checkpoint expects); their ORBIT post-processing -- ``noise`` (``Unoise(n_min, n_max)``, imported for that by
+``rover_env_cfg.py:23``), ``clip``, and a ``scale`` on the terms the kernels do not scale -- is applied in torch on the finished
+row, in ORBIT's order (noise, clip, scale), for the terms that ask for it (``RoverEnvCfg.observation_post``).
 """
 from __future__ import annotations
 
@@ -32,6 +34,8 @@ class TermCfg:
     scale: float = 1.0
     params: dict = field(default_factory=dict)
     time_out: bool = False
+    noise: Any = None    # observation terms: ORBIT NoiseCfg (``noise.func(data, noise)``) or an object with n_min / n_max, mean / std, bias
+    clip: Any = None     # observation terms: (min, max)
 
 
 @dataclass
@@ -215,6 +219,20 @@ class RoverEnvCfg:
         if self.commands.simple_heading:
             raise ValueError("simple_heading=True is not supported (the reference cfg uses False, rover_env_cfg.py:195)")
 
+    def observation_post(self) -> dict:
+        """Observation terms whose ORBIT post-processing (ObservationManager.compute_group: noise, then clip, then scale) is not
+        what the kernels compute: any ``noise`` / ``clip``, or a ``scale`` != 1 on ``actions`` / ``height_scan`` (the kernels scale
+        ``distance`` and ``heading`` only).  For these the kernels write the raw term (scale 1) and ``RoverEnv`` finishes the columns
+        in torch (three small ops per term and step: not the one-launch fast path any more, but the same step kernel)."""
+        out = {}
+        for name in OBS_ORDER:
+            t = self.observations[name]
+            if t.noise is not None or t.clip is not None or (name in ("actions", "height_scan") and float(t.scale) != 1.0):
+                if t.clip is not None and len(tuple(t.clip)) != 2:
+                    raise ValueError(f"observation term '{name}': clip must be (min, max)")
+                out[name] = t
+        return out
+
     @property
     def max_episode_length(self) -> int:
         # ORBIT: ceil(episode_length_s / (sim.dt * decimation))
@@ -244,8 +262,9 @@ class RoverEnvCfg:
         c.resample_time = self.commands.resampling_time_range[0]
         for i, name in enumerate(REWARD_ORDER):
             c.rew_weight[i] = self.rewards[name].weight
-        c.obs_scale_distance = self.observations["distance"].scale
-        c.obs_scale_heading = self.observations["heading"].scale
+        post = self.observation_post()         # terms finished in torch get their raw value from the kernels
+        c.obs_scale_distance = 1.0 if "distance" in post else self.observations["distance"].scale
+        c.obs_scale_heading = 1.0 if "heading" in post else self.observations["heading"].scale
         hs = self.height_scanner
         c.scan_resolution, c.scan_size_x, c.scan_size_y = hs.resolution, hs.size[0], hs.size[1]
         c.scan_nx, c.scan_ny = hs.grid

@@ -5,7 +5,7 @@ Field map (reference file:line -> here):
   scene.num_envs                                   rover_env_cfg.py:233-234      -> scene.num_envs
   sim.dt / decimation / episode_length_s           rover_env_cfg.py:269-271      -> sim.dt / decimation / episode_length_s
   actions.actions (AckermannActionCfg)             aau_rover/env_cfg.py:21-31    -> actions.*
-  observations.policy.<term>.scale                 rover_env_cfg.py:97-123       -> observations[...].scale
+  observations.policy.<term>.scale / noise / clip  rover_env_cfg.py:97-123       -> observations[...].scale / .noise / .clip
   rewards.<term>.weight / params                   rover_env_cfg.py:126-163      -> rewards[...]
   terminations.<term>.params / time_out            rover_env_cfg.py:166-183      -> terminations[...]
   commands.target_pose.*                           rover_env_cfg.py:187-200      -> commands.*
@@ -62,11 +62,12 @@ def from_reference_cfg(ref) -> RoverEnvCfg:
     a.min_steering_radius = act.min_steering_radius
 
     obs = _terms(ref.observations.policy, OBS_ORDER, "observation")
+    corrupt = bool(getattr(ref.observations.policy, "enable_corruption", False))   # ObservationManager: noise only if the group says so
     for name, t in obs.items():
+        clip = getattr(t, "clip", None)
         out.observations[name] = TermCfg(_func_name(t.func), scale=1.0 if t.scale is None else float(t.scale),
-                                         params=_plain_params(t.params))
-        if getattr(t, "noise", None) is not None or getattr(t, "clip", None) is not None:
-            raise ValueError(f"observation term '{name}': noise / clip are not implemented by the fused kernels")
+                                         params=_plain_params(t.params), noise=getattr(t, "noise", None) if corrupt else None,
+                                         clip=None if clip is None else (float(clip[0]), float(clip[1])))
     rew = _terms(ref.rewards, REWARD_ORDER, "reward", allow_custom=True)
     for name, fn in zip(REWARD_ORDER, REWARD_FUNCS):
         if name in rew:

@@ -335,10 +335,38 @@ class RLTaskEnvCfg(BaseEnvCfg):
     commands = None
 
 
+def additive_uniform_noise(data, cfg):       # omni.isaac.orbit.utils.noise (not in /root/reference): data + U(n_min, n_max)
+    import torch
+    return data + torch.rand_like(data) * (cfg.n_max - cfg.n_min) + cfg.n_min
+
+
+def additive_gaussian_noise(data, cfg):
+    import torch
+    return data + cfg.mean + cfg.std * torch.randn_like(data)
+
+
+def constant_bias_noise(data, cfg):
+    return data + cfg.bias
+
+
 @configclass
 class AdditiveUniformNoiseCfg:
+    func = staticmethod(additive_uniform_noise)
     n_min: float = -1.0
     n_max: float = 1.0
+
+
+@configclass
+class AdditiveGaussianNoiseCfg:
+    func = staticmethod(additive_gaussian_noise)
+    mean: float = 0.0
+    std: float = 1.0
+
+
+@configclass
+class ConstantBiasNoiseCfg:
+    func = staticmethod(constant_bias_noise)
+    bias: float = 0.0
 
 
 # ------------------------------------------------------------------------------------------------- marker classes
@@ -498,7 +526,8 @@ def build_modules() -> dict:
                          wrap_to_pi=wrap_to_pi)
     utils_cc = _module("omni.isaac.orbit.utils.configclass", configclass=configclass)
     utils = _module("omni.isaac.orbit.utils", configclass=configclass, math=utils_math,
-                    noise=_module("omni.isaac.orbit.utils.noise", AdditiveUniformNoiseCfg=AdditiveUniformNoiseCfg),
+                    noise=_module("omni.isaac.orbit.utils.noise", AdditiveUniformNoiseCfg=AdditiveUniformNoiseCfg,
+                                  AdditiveGaussianNoiseCfg=AdditiveGaussianNoiseCfg, ConstantBiasNoiseCfg=ConstantBiasNoiseCfg),
                     dict=_module("omni.isaac.orbit.utils.dict", print_dict=print_dict),
                     io=_module("omni.isaac.orbit.utils.io", dump_pickle=dump_pickle, dump_yaml=dump_yaml))
     utils.configclass = configclass   # `from omni.isaac.orbit.utils import configclass` must give the decorator

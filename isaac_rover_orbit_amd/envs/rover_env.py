@@ -153,7 +153,8 @@ class _RayCaster:
         d.pos_w = pos
         # between the two halves of a slow step the observation rows are still the previous step's: user terms get a scan of the
         # CURRENT pose (the reference's RayCaster has updated by the time rewards are computed, rover_env_cfg.py:275-276)
-        scan = env._fresh_scan() if env._in_user_terms else env.obs_buf["policy"][:, 4:]
+        # ... and with noise / clip / scale on the height_scan term the row no longer holds the raw scan at all
+        scan = env._fresh_scan() if (env._in_user_terms or env._obs_post_scan) else env.obs_buf["policy"][:, 4:]
         hit_z = pos[:, 2:3] - scan - env.cfg.height_scanner.height_offset
         q = env.state[_lib.QUAT:_lib.QUAT + 4].t()
         yaw = torch.atan2(2 * (q[:, 0] * q[:, 3] + q[:, 1] * q[:, 2]), 1 - 2 * (q[:, 2] ** 2 + q[:, 3] ** 2))
@@ -358,6 +359,12 @@ class RoverEnv(RLTaskEnv):
         self._user_rewards = list(self.cfg.custom_terms(self.cfg.rewards, REWARD_ORDER).items())
         self._user_terminations = list(self.cfg.custom_terms(self.cfg.terminations, TERMINATION_ORDER).items())
         self._slow_path = bool(self._user_rewards or self._user_terminations)
+        # ORBIT's observation post-processing (noise -> clip -> scale, ObservationManager.compute_group) for the terms that ask for
+        # it (cfg.observation_post): the kernels write those terms raw, the columns are finished in torch behind every step / reset
+        cols = {"actions": slice(0, 2), "distance": slice(2, 3), "heading": slice(3, 4), "height_scan": slice(4, 4 + self.num_rays)}
+        self._obs_post = [(cols[name], t) for name, t in self.cfg.observation_post().items()]
+        self._obs_post_scan = any(sl.start == 4 for sl, _ in self._obs_post)
+        self._obs_gen = torch.Generator(device=self.device).manual_seed(int(self.cfg.seed))
         self._in_user_terms = False
         self._scan_cache = None
         if self._slow_path:
@@ -445,6 +452,8 @@ class RoverEnv(RLTaskEnv):
         obs = self._obs[self._cur]
         _lib.check(self._lib.rover_reset(self._h, _ptr(obs), self._stream()), "rover_reset")
         self._bump_counter()
+        if self._obs_post:
+            self._post_observations(obs)
         self.obs_buf = {"policy": obs}
         return self.obs_buf, self.extras
 
@@ -467,6 +476,8 @@ class RoverEnv(RLTaskEnv):
         _lib.check(self._lib.rover_reset_with_draws(self._h, _ptr(mask_d), _ptr(row_d), _ptr(yaw_d), _ptr(th_d), _ptr(hd_d),
                                                     _ptr(obs), self._stream()), "rover_reset_with_draws")
         torch.cuda.current_stream(dev).synchronize()      # the draw tensors are temporaries
+        if self._obs_post:
+            self._post_observations(obs)
         self.obs_buf = {"policy": obs}
         return self.obs_buf, self.extras
 
@@ -493,6 +504,8 @@ class RoverEnv(RLTaskEnv):
         self.common_step_counter += 1
         self._log_pending = self._log_deferred
         self.obs_buf = self._obs_dicts[k]
+        if self._obs_post:
+            self._post_observations(self.obs_buf["policy"])
         self.reward_buf = self._rew[k]
         self.reset_terminated = self._term_b[k]
         self.reset_time_outs = self._trunc_b[k]
@@ -555,7 +568,32 @@ class RoverEnv(RLTaskEnv):
                    "rover_step_finish")
         self._log_pending = False        # the second half reduces the built-in log eagerly
         self.obs_buf = self._obs_dicts[k]
+        if self._obs_post:
+            self._post_observations(self.obs_buf["policy"])
         return self.obs_buf, self.reward_buf, self.reset_terminated, self.reset_time_outs, self.extras
+
+    def _post_observations(self, obs: torch.Tensor):
+        """noise, clip, scale of the observation terms in ``cfg.observation_post()`` on the finished row, in ORBIT's order."""
+        self._scan_cache = None          # the raw scan of the new pose, should a consumer of ray_hits_w ask for it
+        for sl, t in self._obs_post:
+            x = obs[:, sl]
+            nz = t.noise
+            if nz is not None:
+                if callable(getattr(nz, "func", None)):          # ORBIT NoiseCfg: noise.func(data, cfg) (torch's global generator)
+                    x = nz.func(x, nz)
+                elif hasattr(nz, "n_min"):                       # plain objects: this env's own generator (seeded by cfg.seed)
+                    x = x + torch.rand(x.shape, device=x.device, generator=self._obs_gen) * (nz.n_max - nz.n_min) + nz.n_min
+                elif hasattr(nz, "std"):
+                    x = x + getattr(nz, "mean", 0.0) + nz.std * torch.randn(x.shape, device=x.device, generator=self._obs_gen)
+                elif hasattr(nz, "bias"):
+                    x = x + nz.bias
+                else:
+                    raise TypeError(f"unsupported observation noise {nz!r}")
+            if t.clip is not None:
+                x = x.clip(min=float(t.clip[0]), max=float(t.clip[1]))
+            if float(t.scale) != 1.0:
+                x = x * float(t.scale)
+            obs[:, sl] = x
 
     def flush_log(self):
         """Bring ``extras["log"]`` / ``episode_log_vector`` up to date (``rover_flush_log``).  The log dictionary calls it on
@@ -578,6 +616,8 @@ class RoverEnv(RLTaskEnv):
         self.common_step_counter += 1
         self._log_pending = self._log_deferred
         self.obs_buf = self._obs_dicts[k]
+        if self._obs_post:
+            self._post_observations(self.obs_buf["policy"])
         self.reward_buf = self._rew[k]
         self.reset_terminated = self._term_b[k]
         self.reset_time_outs = self._trunc_b[k]

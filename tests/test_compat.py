@@ -7,6 +7,8 @@ import os
 import sys
 import types
 
+import math
+
 import pytest
 
 REF = "/root/reference"
@@ -126,6 +128,33 @@ def test_user_written_term_in_reference_cfg_is_kept(ref_env):
     cfg.rewards.oscillation = RewardTermCfg(func=bonus, weight=1.0)           # a built-in key with a foreign function
     with pytest.raises(ValueError):
         from_reference_cfg(cfg)
+
+
+def test_observation_noise_and_clip_of_a_reference_cfg_are_kept(ref_env):
+    """``Unoise`` is imported by the reference's cfg for exactly this (rover_env_cfg.py:23): ``noise=`` / ``clip=`` on an ObsTerm
+    survive the conversion (RoverEnv applies them in torch, ORBIT's order); the term is then written raw by the kernels (scale 1);
+    without ``enable_corruption`` the group's noise is dropped as ORBIT's ObservationManager drops it."""
+    import torch
+    from omni.isaac.orbit.utils.noise import AdditiveUniformNoiseCfg as Unoise
+    from omni.isaac.orbit_tasks.utils import parse_env_cfg
+    from isaac_rover_orbit_amd.compat.convert import from_reference_cfg
+    cfg = parse_env_cfg("AAURoverEnv-v0", num_envs=8)
+    assert not from_reference_cfg(cfg).observation_post()                      # the stock table: nothing to finish in torch
+    cfg.observations.policy.height_scan.noise = Unoise(n_min=-0.02, n_max=0.02)
+    cfg.observations.policy.height_scan.clip = (-1.0, 1.0)
+    cfg.observations.policy.distance.clip = (0.0, 50.0)
+    out = from_reference_cfg(cfg)
+    post = out.observation_post()
+    assert list(post) == ["distance", "height_scan"] and post["height_scan"].clip == (-1.0, 1.0)
+    nz = post["height_scan"].noise
+    x = torch.zeros(1000)
+    y = nz.func(x, nz)                                                          # ORBIT's call convention
+    assert float(y.min()) >= -0.02 and float(y.max()) <= 0.02 and float(y.std()) > 0.005
+    n = out.to_native()
+    assert n.obs_scale_distance == 1.0 and n.obs_scale_heading == pytest.approx(1 / math.pi)   # distance is finished in torch: raw from the kernel
+    cfg.observations.policy.enable_corruption = False
+    post = from_reference_cfg(cfg).observation_post()
+    assert post["height_scan"].noise is None and post["height_scan"].clip == (-1.0, 1.0)
 
 
 def test_configclass_semantics():

@@ -234,3 +234,62 @@ def test_robot_facade_body_frame_velocities_and_net_forces(terrain):
     s = env.scene.sensors["contact_sensor"].data
     assert s.net_forces_w.shape == (2048, 13, 3) and torch.equal(s.net_forces_w, s.force_matrix_w[:, :, 0])
     env.close()
+
+
+def test_observation_noise_clip_scale_follow_orbit_order(terrain):
+    """ORBIT's ObservationManager.compute_group post-processing on a built-in term (``Unoise`` is imported by rover_env_cfg.py:23 for
+    this): value -> + noise -> clip -> * scale.  Against a twin without post-processing, which holds the raw terms (scale 1 on the
+    scan, 0.11 on the distance): rays well inside the clip range differ from raw by the noise bounds times the scale, rays outside
+    sit on the bounds, misses (-inf) go to the lower bound; the untouched columns and everything else of the step are the same bits."""
+    from isaac_rover_orbit_amd.cfg import RoverEnvCfg
+    from isaac_rover_orbit_amd.envs import RoverEnv
+
+    class Unoise:                      # duck-typed AdditiveUniformNoiseCfg without .func: the env's own seeded generator draws
+        def __init__(self, n_min, n_max):
+            self.n_min, self.n_max = n_min, n_max
+
+    n = 2048
+
+    def make(post):
+        cfg = RoverEnvCfg(); cfg.scene.num_envs = n; cfg.terrain.kind = "custom"; cfg.seed = 7
+        if post:
+            hs = cfg.observations["height_scan"]
+            hs.noise, hs.clip, hs.scale = Unoise(-0.02, 0.03), (-0.25, 0.12), 2.0
+            cfg.observations["distance"].clip = (0.0, 4.0)              # scale 0.11 stays, applied AFTER the clip
+        return RoverEnv(cfg, terrain=terrain)
+
+    raw, post = make(False), make(True)
+    assert not raw._obs_post and [sl.start for sl, _ in post._obs_post] == [2, 4]
+    assert post.kernel_names() == raw.kernel_names()                    # the same one-launch step kernel underneath
+    o_r, _ = raw.reset(); o_p, _ = post.reset()
+    g = torch.Generator(device=raw.device).manual_seed(2)
+    seen_low = seen_high = 0
+    for k in range(12):
+        a = torch.rand(n, 2, device=raw.device, generator=g) * 2 - 1
+        o_r, r_r, t_r, u_r, _ = raw.step(a)
+        o_p, r_p, t_p, u_p, _ = post.step(a)
+        R, P = o_r["policy"], o_p["policy"]
+        assert torch.equal(R[:, :2], P[:, :2]) and torch.equal(R[:, 3], P[:, 3])                    # untouched terms: same bits
+        assert torch.equal(r_r, r_p) and torch.equal(t_r, t_p) and torch.equal(u_r, u_p)
+        d_raw = R[:, 2] / 0.11                                                                          # the twin's distance carries its scale
+        assert torch.allclose(P[:, 2], d_raw.clip(0.0, 4.0) * 0.11, rtol=1e-6, atol=1e-7)
+        scan_r, scan_p = R[:, 4:], P[:, 4:]
+        lo, hi = float(torch.tensor(-0.25, dtype=torch.float32) * 2.0), float(torch.tensor(0.12, dtype=torch.float32) * 2.0)   # fp32 bounds
+        assert float(scan_p.min()) >= lo and float(scan_p.max()) <= hi and torch.isfinite(scan_p).all()
+        inside = (scan_r > -0.2) & (scan_r < 0.08)
+        diff = scan_p[inside] / 2.0 - scan_r[inside]
+        assert float(diff.min()) >= -0.02 - 1e-6 and float(diff.max()) <= 0.03 + 1e-6 and float(diff.std()) > 0.01
+        assert (scan_p[scan_r < -0.3] == lo).all() and (scan_p[scan_r > 0.16] == hi).all()
+        seen_low += int((scan_r < -0.3).sum()); seen_high += int((scan_r > 0.16).sum())
+    assert seen_low > 0 and seen_high > 0
+    # the scene facade still reports the hits of the RAW scan
+    hits = post.scene.sensors["height_scanner"].data.ray_hits_w
+    assert torch.allclose(hits[..., 2], raw.scene.sensors["height_scanner"].data.ray_hits_w[..., 2], atol=1e-6, equal_nan=True)
+    # same seed, same draws
+    again = make(True); again.reset()
+    g = torch.Generator(device=raw.device).manual_seed(2)
+    post2 = make(True); post2.reset()
+    a = torch.rand(n, 2, device=raw.device, generator=g) * 2 - 1
+    assert torch.equal(again.step(a)[0]["policy"], post2.step(a)[0]["policy"])
+    for e in (raw, post, again, post2):
+        e.close()
