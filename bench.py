@@ -260,6 +260,22 @@ def rollout_loop_leg(env, dev, steps, profile_steps, ev_ms):
                     tracked += vv.item()
     torch.cuda.synchronize()
     dt_trainer = (time.perf_counter() - t0) / t_steps
+    # the same loop, unchanged, with cfg.log_values = "host": the dictionary's entries are views of a pinned host mirror that the
+    # first read after a step refreshes with ONE copy and ONE synchronisation
+    env.set_log_values("host")
+    tracked_h = 0.0
+    t0 = time.perf_counter()
+    for k in range(t_steps):
+        a_pol, _v = forward_pair(actor, critic, obs)
+        o, _r, _te, _tr, infos = env.step(a_pol)
+        obs = o["policy"]
+        if "episode" in infos:
+            for kk, vv in infos["episode"].items():
+                if isinstance(vv, torch.Tensor) and vv.numel() == 1:
+                    tracked_h += vv.item()
+    torch.cuda.synchronize()
+    dt_trainer_h = (time.perf_counter() - t0) / t_steps
+    env.set_log_values("device")
     flops = 2.0 * n * sum(kk * nn for kk, nn in zip(K, Nn + [2]))
     return {"ms_per_step": dt * 1e3, "env_steps_per_s": n / dt,
             "kernels_us_events": {"rover_policy_kernel (actor)": t_act / reps * 1e3 - ev_ms * 1e3,
@@ -273,6 +289,10 @@ def rollout_loop_leg(env, dev, steps, profile_steps, ev_ms):
                              "note": "pair + env.step + .item() on every entry of infos['episode'] after every step, as "
                                      "skrl_utils.py:139-142 does: the log reduction launches behind every step and the host "
                                      "synchronises once per entry (13 per step)", "checksum": tracked},
+            "trainer_loop_host_log": {"ms_per_step": dt_trainer_h * 1e3, "env_steps_per_s": n / dt_trainer_h, "steps": t_steps,
+                                      "note": "the same loop with cfg.log_values = 'host' (extras['log'] entries = views of a pinned "
+                                              "host mirror: one copy + one synchronisation per step, .item() is then free)",
+                                      "checksum": tracked_h},
             "observations_finite": bool(torch.isfinite(obs).all()),
             "actor_TFLOPs_f32": flops / ((t_act / reps - ev_ms) * 1e-3) / 1e12, "f32_mfma_peak_TFLOPs": 157.0,
             "note": "closed loop: the actor's mean action drives the env (observations with -inf rays are what the kernel reads; "

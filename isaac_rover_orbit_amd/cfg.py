@@ -181,6 +181,8 @@ class RoverEnvCfg:
     # observation rows written with streaming (non-temporal) stores by the one-launch kernels: ~2 % faster step when nothing on the
     # device reads the rows next; off by default because a policy kernel behind the step finds plainly stored rows in L2
     stream_observations: bool = False
+    log_values: str = "device"              # extras["log"] entries: 0-d device tensors (ORBIT) | "host": views of a pinned mirror, ONE
+                                            # synchronisation per step for a trainer that .item()s every entry (skrl_utils.py:139-142)
     # multi-GPU sharding: this process simulates global env ids [env_id_offset, env_id_offset + num_envs)
     env_id_offset: int = 0
     global_num_envs: int | None = None

@@ -13,6 +13,11 @@ class LogDict(dict):
         super().__init__(items)
         self._env = env
 
+    def _rebind(self, items):
+        """Swap the stored tensors (``RoverEnv.set_log_values``: device views <-> views of the pinned host mirror)."""
+        super().clear()
+        super().update(items)
+
     def __getitem__(self, k):
         self._env.flush_log()
         return super().__getitem__(k)

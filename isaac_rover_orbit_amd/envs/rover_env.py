@@ -355,6 +355,7 @@ class RoverEnv(RLTaskEnv):
         _lib.check(self._lib.rover_set_log_deferred(self._h, int(self._log_deferred)), "rover_set_log_deferred")
         _lib.check(self._lib.rover_set_obs_streaming(self._h, int(bool(getattr(self.cfg, "stream_observations", False)))), "rover_set_obs_streaming")
         log_items = {k: self._log[i] for i, k in enumerate(LOG_KEYS)}
+        self._log_slots = {k: i for i, k in enumerate(LOG_KEYS)}       # key -> word of the host mirror (set_log_values)
         # ---- user-written terms (cfg.py): evaluated in torch between the two halves of the step
         self._user_rewards = list(self.cfg.custom_terms(self.cfg.rewards, REWARD_ORDER).items())
         self._user_terminations = list(self.cfg.custom_terms(self.cfg.terminations, TERMINATION_ORDER).items())
@@ -376,9 +377,16 @@ class RoverEnv(RLTaskEnv):
                 self._reset_mask = torch.zeros(n, dtype=torch.uint8, device=dev)
             for i, (name, _) in enumerate(self._user_rewards):
                 log_items[f"Episode Reward/{name}"] = self._user_log[i]
+                self._log_slots[f"Episode Reward/{name}"] = self._log.numel() + i
             for i, (name, _) in enumerate(self._user_terminations):
                 log_items[f"Episode Termination/{name}"] = self._user_log[len(self._user_rewards) + i]
+                self._log_slots[f"Episode Termination/{name}"] = self._log.numel() + len(self._user_rewards) + i
+        self._log_items_device = dict(log_items)
+        self._log_host = None
+        self._log_host_stale = True
         self._log_dict = LogDict(self, log_items)
+        if getattr(self.cfg, "log_values", "device") != "device":
+            self.set_log_values(self.cfg.log_values)
         self.extras = {"log": self._log_dict, "episode": self._log_dict}   # rover_env.py:39
 
         # ---- manager / scene facades + spaces
@@ -503,6 +511,7 @@ class RoverEnv(RLTaskEnv):
         self._bump_counter()
         self.common_step_counter += 1
         self._log_pending = self._log_deferred
+        self._log_host_stale = True
         self.obs_buf = self._obs_dicts[k]
         if self._obs_post:
             self._post_observations(self.obs_buf["policy"])
@@ -567,6 +576,7 @@ class RoverEnv(RLTaskEnv):
         _lib.check(self._lib.rover_step_finish(self._h, _ptr(self._reset_mask), self._obs_ptr[k], self._force_ptr, self._log_ptr, st),
                    "rover_step_finish")
         self._log_pending = False        # the second half reduces the built-in log eagerly
+        self._log_host_stale = True
         self.obs_buf = self._obs_dicts[k]
         if self._obs_post:
             self._post_observations(self.obs_buf["policy"])
@@ -601,6 +611,32 @@ class RoverEnv(RLTaskEnv):
         if self._log_pending:
             self._log_pending = False
             _lib.check(self._lib.rover_flush_log(self._h, self._log_ptr, self._stream()), "rover_flush_log")
+        if self._log_host is not None and self._log_host_stale:      # log_values = "host": ONE copy + ONE synchronisation per step
+            self._log_host_stale = False
+            nb = self._log.numel()
+            self._log_host[:nb].copy_(self._log, non_blocking=True)
+            if self._log_host.numel() > nb:
+                self._log_host[nb:].copy_(self._user_log, non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()
+
+    def set_log_values(self, where: str = "device"):
+        """Where the 0-d tensors of ``extras["log"]`` / ``extras["episode"]`` live.  ``"device"`` (ORBIT's way): views of the device
+        log vector -- a consumer that calls ``.item()`` on each of them, as the reference's trainer does after every step
+        (skrl_utils.py:139-142), synchronises once per entry.  ``"host"``: views of a pinned host mirror that the first read after a
+        step refreshes with one copy and one synchronisation; the ``.item()`` calls are then free.  Same numbers either way."""
+        if where not in ("device", "host"):
+            raise ValueError("log_values must be 'device' or 'host'")
+        self.flush_log()
+        if where == "device":
+            self._log_host = None
+            self._log_dict._rebind(self._log_items_device)
+            return
+        nb = self._log.numel()
+        nu = self._user_log.numel() if self._slow_path else 0
+        self._log_host = torch.zeros(nb + nu, dtype=torch.float32).pin_memory()
+        self._log_host_stale = True
+        items = {key: self._log_host[self._log_slots[key]] for key in self._log_items_device}
+        self._log_dict._rebind(items)
 
     def profile_step(self, action: torch.Tensor):
         """``step`` (same validation and bookkeeping) with HIP-event timing of the two kernels; returns
@@ -615,6 +651,7 @@ class RoverEnv(RLTaskEnv):
         self._bump_counter()
         self.common_step_counter += 1
         self._log_pending = self._log_deferred
+        self._log_host_stale = True
         self.obs_buf = self._obs_dicts[k]
         if self._obs_post:
             self._post_observations(self.obs_buf["policy"])

@@ -293,3 +293,33 @@ def test_observation_noise_clip_scale_follow_orbit_order(terrain):
     assert torch.equal(again.step(a)[0]["policy"], post2.step(a)[0]["policy"])
     for e in (raw, post, again, post2):
         e.close()
+
+
+def test_log_values_on_the_host_are_the_device_values(terrain):
+    """``cfg.log_values = "host"``: the entries of extras["log"] are 0-d CPU tensors (views of a pinned mirror refreshed by the first
+    read after a step) holding exactly what the device entries hold; the reference trainer's read loop (skrl_utils.py:139-142) works
+    on them unchanged; switching back restores the device views."""
+    n = 2048
+    dev_env, host_env = _make(n, terrain), _make(n, terrain)
+    host_env.set_log_values("host")
+    dev_env.reset(); host_env.reset()
+    S = dev_env.get_state()
+    S[::23, 51] = torch.tensor([745], dtype=torch.int32).view(torch.float32).item()      # time-outs within a few steps
+    dev_env.set_state(S); host_env.set_state(S)
+    g = torch.Generator(device=dev_env.device).manual_seed(9)
+    changed = 0
+    prev = None
+    for k in range(12):
+        a = torch.rand(n, 2, device=dev_env.device, generator=g) * 2 - 1
+        info_d = dev_env.step(a)[4]; info_h = host_env.step(a)[4]
+        vals = []
+        for (kd, vd), (kh, vh) in zip(info_d["episode"].items(), info_h["episode"].items()):
+            assert kd == kh and vh.device.type == "cpu" and vd.device.type == "cuda" and vh.numel() == 1
+            assert vh.item() == vd.item(), (k, kd)
+            vals.append(vh.item())
+        changed += int(prev is not None and vals != prev)
+        prev = vals
+    assert changed >= 1                                   # the log moved while we watched (the time-outs of step 5)
+    host_env.set_log_values("device")
+    assert all(v.device.type == "cuda" for v in host_env.extras["log"].values())
+    dev_env.close(); host_env.close()
