@@ -4161,6 +4161,6 @@ int rover_model_constants(float *out, int32_t cap)
 int rover_state_words(void) { return ROVER_STATE_WORDS; }
 size_t rover_config_bytes(void) { return sizeof(rover_config); }
 const char *rover_last_error(void) { return g_err; }
-const char *rover_version(void) { return "isaac_rover_orbit_amd 0.3.0 (gfx950)"; }
+const char *rover_version(void) { return "isaac_rover_orbit_amd 0.4.0 (gfx950)"; }
 
 }  // extern "C"
