@@ -25,7 +25,7 @@ VARIANTS = {"K1STAMP": ("rover_kernels.hip", "-DRV_K1_STAMP"),            # s_me
             "NOSLP": ("rover_kernels.hip", "-fno-slp-vectorize"),
             # rounds (whole quads) of envs 1 / 2 / 3 cast by the step wave, the rest by its copy wave (tools/quick_bench.py)
             **{f"SH_{a}_{b_}_{c}": ("rover_kernels.hip", f"-DRV_SHARE_1={a} -DRV_SHARE_2={b_} -DRV_SHARE_3={c}")
-               for (a, b_, c) in ((16, 16, 8), (16, 16, 12), (16, 16, 4), (16, 16, 16), (12, 16, 8), (16, 12, 8))},
+               for (a, b_, c) in ((12, 16, 12), (12, 16, 16), (8, 16, 12), (12, 16, 8), (8, 16, 8), (16, 16, 12), (12, 12, 12))},
             # policy pair kernel: round 3's sequential form; queue depths of the weight fragments
             "P_SEQ": ("policy_kernels.hip", "-DPOL_PAIR_SEQUENTIAL"), "P_QD1_3": ("policy_kernels.hip", "-DPOL_STAMP -DPOL_QD1=3"),
             "P_QD4_8": ("policy_kernels.hip", "-DPOL_STAMP -DPOL_QD4=8 -DPOL_QD5=10")}
