@@ -1866,6 +1866,8 @@ __device__ __forceinline__ float private_ray(const RvParams &p, const int16_t *t
 // compare-and-branch on M0 -- five instructions.  (hipcc's loop around the builtin took fifteen per load -- a mask and a branch
 // around every load, a 64-bit address add, M0 through a move and a nop -- and one wave per SIMD issues them one by one: 2.5 k
 // cycles per window, which round 3 read as the cost of the LDS-DMA instruction itself.)
+// (Cache-policy bits on these loads, measured at 4096 envs: `nt` 38.3 us per step instead of 33.8 -- the windows of neighbouring
+// envs overlap and want to stay in L2 --, `sc0` / `sc1` no difference.)
 __device__ __forceinline__ void private_issue(const RvParams &p, const PrivateWindows &w, int j, int16_t *tile, int lane)
 {
     const int th = w.pk[j] & 0x7FFF, tw4 = max(w.pk[j] >> 16, 1);
@@ -2264,6 +2266,11 @@ __device__ __forceinline__ float *fused_link(float *lds, const RvParams &p, int 
 // (cast under the manager tail, so that tile 0 is free for window 2 before barrier B); beside env 2 it stages window 3.
 // tools/quick_bench.py, us per step at 4096 envs, shares of envs 1 / 2 / 3: 12 / 16 / 12 33.7, 12 / 16 / 8 33.85, 8 / 16 / 12 34.0,
 // 12 / 12 / 12 33.9, 12 / 16 / 16 34.15, 16 / 16 / 12 34.2.
+#ifndef RV_AHEAD_SUBSTEPS
+#define RV_AHEAD_SUBSTEPS 2   // substeps between the pose the windows of envs 0 / 1 are staged for and the end of the physics
+                              // (us per step at 4096 envs: 2 -> 33.7, 3 -> 34.8, 4 -> 36.5, no staging ahead 34.1: every substep that
+                              // runs beside the staged windows' traffic is ~1 k cycles slower -- 4 % of the windows missed at 3)
+#endif
 #ifndef RV_SHARE_1
 #define RV_SHARE_1 12
 #endif
@@ -2486,11 +2493,12 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
             }
             __syncthreads();                                            // L0
         };
+        const int s_ahead = max(c.decimation - RV_AHEAD_SUBSTEPS, 0);   // the hand-over happens in front of this substep
         for (int s = 0; s < c.decimation - 1; ++s) {
-            if (s == c.decimation - 2) post_ahead();
+            if (s == s_ahead) post_ahead();
             physics_substep_group<false>(p, K, g, nullptr, s);
         }
-        if (c.decimation < 2) post_ahead();
+        if (c.decimation - 1 <= s_ahead) post_ahead();
     } else {
         for (int s = 0; s < c.decimation - 1; ++s) physics_substep_group<false>(p, K, g, nullptr, s);
     }

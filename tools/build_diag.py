@@ -19,7 +19,7 @@ from isaac_rover_orbit_amd import build as b  # noqa: E402
 VARIANTS = {"K1STAMP": ("rover_kernels.hip", "-DRV_K1_STAMP"),            # s_memtime phase stamps in the step kernels (tools/k1_stamps.py)
             "K1LITE": ("rover_kernels.hip", "-DRV_K1_LITE"),              # no-wait timeline of a step wave and its copy wave (tools/k1_lite.py)
             "K1LITEF": ("rover_kernels.hip", "-DRV_K1_LITE -DRV_K1_LITE_FINE"),
-            "PREV": ("rover_kernels.hip", ""),                             # rover_kernels.hip of the last commit (A/B in one gpurun call)
+            "PREV": ("rover_kernels.hip", ""),                             # rover_kernels.hip of the last commit, or of $PREV_REV (A/B in one gpurun call)
             "LIFTSTAMP": ("lift_kernels.hip", "-DLF_STAMP"),               # ... in the lift step kernel (tools/lift_stamps.py)
             "POLSTAMP": ("policy_kernels.hip", "-DPOL_STAMP"),             # ... in the policy kernels (tools/policy_stamps.py [pair])
             "NOSLP": ("rover_kernels.hip", "-fno-slp-vectorize"),
@@ -46,7 +46,7 @@ def main():
         if tag == "PREV":                    # A/B against the last commit: its rover_kernels.hip, same flags, same other objects
             src = os.path.join(out_dir, "prev_" + src_name)
             with open(src, "w") as f:
-                f.write(subprocess.check_output(["git", "-C", ROOT, "show", "HEAD:isaac_rover_orbit_amd/csrc/" + src_name], text=True))
+                f.write(subprocess.check_output(["git", "-C", ROOT, "show", os.environ.get("PREV_REV", "HEAD") + ":isaac_rover_orbit_amd/csrc/" + src_name], text=True))
             define += " -I" + os.path.join(ROOT, "isaac_rover_orbit_amd", "csrc") + " -I" + os.path.join(ROOT, "include")
         subprocess.check_call([hipcc, *b.FLAGS, *define.split(), "-c", "-o", obj, src])
         objs = [obj if os.path.basename(s) == src_name else os.path.join(b.OBJ_DIR, os.path.splitext(os.path.basename(s))[0] + ".o")

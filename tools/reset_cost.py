@@ -29,6 +29,9 @@ if sys.argv[1] == "--join":
         print(f"steps {i:4d}..{min(i + k, n) - 1:4d}: mean resets {resets[i:i + k].mean():7.2f}  kernel mean {dur[i:i + k].mean():7.2f} us")
     sys.exit(0)
 import torch
+if os.environ.get("ABLTAG"):      # a tools/build_diag.py variant instead of the product library
+    from isaac_rover_orbit_amd import _lib
+    _lib.LIB_PATH = os.path.join(ROOT, "build", "abl", f"librover_abl{os.environ['ABLTAG']}.so")
 from isaac_rover_orbit_amd import terrain as T
 from isaac_rover_orbit_amd.cfg import RoverEnvCfg
 from isaac_rover_orbit_amd.envs import RoverEnv
