@@ -447,6 +447,7 @@ class RoverEnv(RLTaskEnv):
             lo, hi = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
             self._native_cfg.seed_lo, self._native_cfg.seed_hi = lo, hi
             _lib.check(self._lib.rover_set_seed(self._h, lo, hi), "rover_set_seed")
+            self._obs_gen.manual_seed(seed)      # the observation-noise draws of plain (non-ORBIT) noise objects
         return int(self.cfg.seed)
 
     def reset(self, seed: int | None = None, options=None):
