@@ -19,6 +19,16 @@ fn = env._lib.rover_debug_set_k1_stamps; fn.argtypes = [C.c_void_p]
 assert fn(C.c_void_p(stamps.data_ptr())) == 0
 g = torch.Generator(device="cuda").manual_seed(0)
 acts = torch.rand(40, n, 2, device="cuda", generator=g) * 2 - 1
+if len(sys.argv) > 2 and sys.argv[2] == "misses":      # how often does the containment test of the windows staged ahead fail?
+    steps, seen, m0, m1 = int(sys.argv[3]) if len(sys.argv) > 3 else 400, 0, 0, 0
+    for k in range(steps):
+        out = env.step(torch.rand(n, 2, device="cuda", generator=g) * 2 - 1)
+        if k >= 200:       # steady-state episodes (random driving, ~4 resets per step)
+            f = stamps[:, 32 + 20].cpu().numpy().astype(np.int64) - 1000
+            seen += f.size; m0 += int((f & 1).sum()); m1 += int(((f >> 1) & 1).sum())
+    print(f"windows staged ahead, {steps - 200} steps x {n // 16} sampled wave pairs (copy wave 4 of every workgroup), random actions: "
+          f"env 0 missed {m0} times, env 1 {m1} times of {seen} each = {100.0 * (m0 + m1) / (2 * seen):.3f} %")
+    sys.exit(0)
 S = env.get_state()      # every 37th env times out in the LAST of the 40 steps: what do the workgroups with a reset cost?
 S[::37, 51] = torch.tensor([env.max_episode_length - 40], dtype=torch.int32).view(torch.float32).item()
 env.set_state(S)
