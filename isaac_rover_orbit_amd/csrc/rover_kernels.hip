@@ -1406,50 +1406,6 @@ __device__ __forceinline__ ScanWindow scan_window(const RvParams &p, const float
                  (w.py + ey < p.y_max - m) && (i_hi - i_lo + 1 <= p.tile_dim) && (((j_hi - j_lo + cc) >> sh) <= (p.tile_pitch >> sh));
     return w;
 }
-// A window staged AHEAD of the pose it will be used for (one-launch kernel: two substeps before the end of the physics): the
-// window of (pos, unnormalised (cos, sin) yaw = (a, b)) grown by up to MARGIN cells per side wherever the LDS tile has room for
-// them.  Only its cell box matters (the rays are cast with the FINAL pose; the box must contain the final window's box).
-__device__ __forceinline__ ScanWindow scan_window_ahead(const RvParams &p, const float *pos, float a, float b)
-{
-    constexpr int MARGIN = 2;
-    const rover_config &c = p.cfg;
-    ScanWindow w;
-    const float inv = 1.0f / sqrtf(a * a + b * b);
-    w.px = pos[0]; w.py = pos[1]; w.pz = pos[2];
-    w.cy = a * inv;
-    w.sy = b * inv;
-    const float inv_res = p.inv_res;
-    const float hx = 0.5f * c.scan_size_x, hy = 0.5f * c.scan_size_y;
-    const float ex = fabsf(w.cy) * hx + fabsf(w.sy) * hy, ey = fabsf(w.sy) * hx + fabsf(w.cy) * hy;
-    int j_lo = (int)floorf((w.px - ex - p.min_x) * inv_res) - 1;
-    int i_lo = (int)floorf((w.py - ey - p.min_y) * inv_res) - 1;
-    int j_hi = (int)floorf((w.px + ex - p.min_x) * inv_res) + 2;
-    int i_hi = (int)floorf((w.py + ey - p.min_y) * inv_res) + 2;
-    const int cc = p.chunk_cells, sh = (cc == 8) ? 3 : 2;
-    {   // rows: what the tile has beyond the window's own rows, split between the two sides
-        const int spare = max(p.tile_dim - (i_hi - i_lo + 1), 0);
-        const int lo_m = min(spare >> 1, MARGIN), hi_m = min(spare - lo_m, MARGIN);
-        i_lo -= lo_m; i_hi += hi_m;
-    }
-    {   // columns: the widest margin whose chunk count still fits a tile row (the left edge is aligned down to a chunk)
-        int mcol = 0;
-#pragma unroll
-        for (int m = 1; m <= MARGIN; ++m) {
-            const int tl = (j_lo - m) & ~(cc - 1);
-            if (((j_hi + m - tl + cc) >> sh) <= (p.tile_pitch >> sh)) mcol = m;
-        }
-        j_lo -= mcol; j_hi += mcol;
-    }
-    j_lo = max(0, min(j_lo, p.W - 1)); j_hi = max(0, min(j_hi, p.W - 1));
-    i_lo = max(0, min(i_lo, p.H - 1)); i_hi = max(0, min(i_hi, p.H - 1));
-    j_lo &= ~(cc - 1);
-    w.i_lo = i_lo;
-    w.j_lo = j_lo;
-    w.th = min(i_hi - i_lo + 1, p.tile_dim);
-    w.tw4 = min(min((j_hi - j_lo + cc) >> sh, p.tile_pitch >> sh), (p.W - j_lo + cc - 1) >> sh);
-    w.interior = 0;   // (not meaningful for a box staged ahead: the final window's flag is what the cast uses)
-    return w;
-}
 __device__ __forceinline__ void write_scan_desc(const RvParams &p, const float *pos, const float *quat, int e)
 {
     const ScanWindow w = scan_window(p, pos, quat);
@@ -1866,8 +1822,6 @@ __device__ __forceinline__ float private_ray(const RvParams &p, const int16_t *t
 // compare-and-branch on M0 -- five instructions.  (hipcc's loop around the builtin took fifteen per load -- a mask and a branch
 // around every load, a 64-bit address add, M0 through a move and a nop -- and one wave per SIMD issues them one by one: 2.5 k
 // cycles per window, which round 3 read as the cost of the LDS-DMA instruction itself.)
-// (Cache-policy bits on these loads, measured at 4096 envs: `nt` 38.3 us per step instead of 33.8 -- the windows of neighbouring
-// envs overlap and want to stay in L2 --, `sc0` / `sc1` no difference.)
 __device__ __forceinline__ void private_issue(const RvParams &p, const PrivateWindows &w, int j, int16_t *tile, int lane)
 {
     const int th = w.pk[j] & 0x7FFF, tw4 = max(w.pk[j] >> 16, 1);
@@ -2214,24 +2168,17 @@ __device__ __forceinline__ void scan_single_tile_wave(const RvParams &p, int16_t
 // copy wave k + 4 stages the windows of step wave k.  During the physics it draws what a reset of each env WOULD draw (reset_draw)
 // and, during the LAST substep, evaluates the link-body sample points and the wheels' obstacle look-ups of the contact report.
 // The reset is decided by the step wave right after the physics (mdp_terminations: the other termination terms are functions of
-// words loaded before the physics), so the windows handed over are those of the FINAL pose.  The windows of envs 0 and 1 are
-// staged AHEAD, two substeps before the end of the physics, for the pose of that moment and a margin of up to two cells per side
-// (scan_window_ahead; for an env whose reset is already certain: for the spawn pose the copy wave drew) -- the LDS tiles and the
-// CU's L2 port are idle then; at the end of the step a containment test decides whether the staged box serves (it does unless
-// the env collided into a reset, turned faster than the margin allows or sits at the map's edge: then the exact window is
-// requested as it used to be).  Windows travel through LDS (win[wave][env][8 words]); SEVEN workgroup barriers, executed by all
-// eight waves on every path:
-//   L0  pose two substeps before the end + "reset certain" flags written | copy: windows 0, 1 staged ahead | step: substep 5 of 6
+// words loaded before the physics), so the windows handed over are those of the FINAL pose; the copy wave stages the first two and
+// casts env 0 under the step wave's manager tail.  Windows travel through LDS (win[wave][env][8 words]); SIX workgroup barriers,
+// executed by all eight waves on every path (no path depends on whether an env reset):
 //   L   pose + bogie angles of the last substep's start written | copy: link-point forces, obstacle heights | step: the last substep
 //   A   link forces written                                     | step: contact report, collision flag, reset decision, final windows
-//   A2  final windows written | copy: containment test (misses: exact windows 0 / 1), rays of env 0, window 2 -> tile 0 | step: manager tail
-//   B   env 0 cast, env 1's box published                       | rays of env 1: step wave rounds [0, SHARE_1), copy wave the rest
-//   C   window 2 landed, tile 1 free | copy: window 3 -> tile 1  | step: rays of env 2
+//   A2  final windows written | copy: stage windows 0, 1, wait, rays of env 0, wait       | step: manager tail, ray table
+//   B   env 0 cast, window 1 landed | copy: stage window 2 into tile 0, wait              | step: rays of env 1
+//   C   window 2 landed, tile 1 free | copy: stage window 3 into tile 1, wait             | step: rays of env 2
 //   D   window 3 landed                                         | both: rays of env 3 (rounds [0, SHARE_3) / [SHARE_3, 16))
 // A cast is bound by the SIMD's instruction issue, not by latency: two waves casting the same env together take as long as one
 // (16 rounds: 2.9 k cycles against 3.0 k; tools/k1_lite.py), so sharing an env pays only where the other wave would idle anyway.
-// (What staging ahead buys is small -- 0.45 us of 34.1: the requests it moves cost the step wave the issue slots they take during
-// the physics, 1.2 k cycles, against the 3 k they free behind it.)
 __device__ __forceinline__ void windows_to_lds(float *win, const ScanWindow &sw, int lane)
 {
     if ((lane & 15) == 0) {
@@ -2264,21 +2211,14 @@ __device__ __forceinline__ float *fused_win(float *lds, const RvParams &p, int w
 __device__ __forceinline__ float *fused_link(float *lds, const RvParams &p, int wv) { return fused_win(lds, p, 0) + 256 + wv * RV_HAND; }
 // Rounds (whole quads) of an env's sixteen cast by the STEP wave; the copy wave takes the rest.  Env 0 is the copy wave's alone
 // (cast under the manager tail, so that tile 0 is free for window 2 before barrier B); beside env 2 it stages window 3.
-// tools/quick_bench.py, us per step at 4096 envs, shares of envs 1 / 2 / 3: 12 / 16 / 12 33.7, 12 / 16 / 8 33.85, 8 / 16 / 12 34.0,
-// 12 / 12 / 12 33.9, 12 / 16 / 16 34.15, 16 / 16 / 12 34.2.
-#ifndef RV_AHEAD_SUBSTEPS
-#define RV_AHEAD_SUBSTEPS 2   // substeps between the pose the windows of envs 0 / 1 are staged for and the end of the physics
-                              // (us per step at 4096 envs: 2 -> 33.7, 3 -> 34.8, 4 -> 36.5, no staging ahead 34.1: every substep that
-                              // runs beside the staged windows' traffic is ~1 k cycles slower -- 4 % of the windows missed at 3)
-#endif
 #ifndef RV_SHARE_1
-#define RV_SHARE_1 12
+#define RV_SHARE_1 16
 #endif
 #ifndef RV_SHARE_2
 #define RV_SHARE_2 16
 #endif
 #ifndef RV_SHARE_3
-#define RV_SHARE_3 12
+#define RV_SHARE_3 8
 #endif
 constexpr int SHARE_1 = RV_SHARE_1, SHARE_2 = RV_SHARE_2, SHARE_3 = RV_SHARE_3;
 constexpr int SHARE_MAX = SHARE_1 > SHARE_2 ? (SHARE_1 > SHARE_3 ? SHARE_1 : SHARE_3) : (SHARE_2 > SHARE_3 ? SHARE_2 : SHARE_3);
@@ -2315,22 +2255,6 @@ __device__ __forceinline__ void scan_copy_wave(const RvParams &p, const float *_
             d[2] = make_float4(ro.heading_cmd, 0.0f, 0.0f, 0.0f);
         }
     }
-    PrivateWindows wa;      // the windows of envs 0 and 1 staged AHEAD (entries 2, 3 unused)
-    {   // L0: the pose two substeps before the end (or "this env resets whatever the physics does": then the spawn pose drawn above)
-        __syncthreads();                                                // L0
-        const float *lk = fused_link(lds, p, partner);
-        const float4 a0 = reinterpret_cast<const float4 *>(lk + 48)[lane >> 4], a1 = reinterpret_cast<const float4 *>(lk + 304)[lane >> 4];
-        const float4 r0 = reinterpret_cast<const float4 *>(lk + 256 + (lane >> 4) * 12)[0], r1 = reinterpret_cast<const float4 *>(lk + 256 + (lane >> 4) * 12)[1];
-        const bool certain = a0.w != 0.0f;
-        const float pa[3] = {certain ? r0.x : a0.x, certain ? r0.y : a0.y, certain ? r0.z : a0.z};
-        // spawn orientation (qw, 0, 0, qz): the same (cos, sin)-of-yaw expressions scan_window forms from a quaternion
-        const float ca = certain ? 1.0f - 2.0f * (r1.x * r1.x) : a1.x, cb = certain ? 2.0f * (r0.w * r1.x) : a1.y;
-        float *spec = const_cast<float *>(win) + 32;
-        windows_to_lds(spec, scan_window_ahead(p, pa, ca, cb), lane);
-        windows_from_lds(spec, wa);
-        if (n_env > 0) private_issue(p, wa, 0, tile0, lane);
-        if (n_env > 1) private_issue(p, wa, 1, tile1, lane);
-    }
     {   // L: the step wave has left the pose of the last substep's start; this lane evaluates the link-body sample point of its
         // twin (same slot, same role: same constants, same arithmetic -- link_point_fetch / link_point_eval) and the obstacle
         // layer under the twin's wheel (the patch terrain_sample<true> would gather: same cell, same weights) while the twin solves
@@ -2362,39 +2286,20 @@ __device__ __forceinline__ void scan_copy_wave(const RvParams &p, const float *_
     __syncthreads();                                                    // A2: the windows of the FINAL poses (resets decided)
     K1_LITE(2);
     windows_from_lds(win, w);
-    // envs 0 and 1: is the final window inside the box staged ahead?  Then the rays are cast from that box (its origin and row pitch,
-    // the FINAL pose); else -- a collision reset, a rover that turned faster than the margin allows, a window at the map's edge --
-    // the exact window is requested now, as it used to be for every env.
-    bool miss[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int th_f = w.pk[j] & 0x7FFF, tw_f = w.pk[j] >> 16, th_a = wa.pk[j] & 0x7FFF, tw_a = wa.pk[j] >> 16;
-        const bool inside = ((w.pk[j] >> 15) & 1) && w.i_lo[j] >= wa.i_lo[j] && w.i_lo[j] + th_f <= wa.i_lo[j] + th_a &&
-                            w.j_lo[j] >= wa.j_lo[j] && w.j_lo[j] + 8 * tw_f <= wa.j_lo[j] + 8 * tw_a;
-        miss[j] = !inside;
-        if (!miss[j]) { w.i_lo[j] = wa.i_lo[j]; w.j_lo[j] = wa.j_lo[j]; w.pk[j] = (wa.pk[j] & ~0x8000) | 0x8000; }
-    }
-    if (miss[0] && n_env > 0) private_issue(p, w, 0, tile0, lane);
-    if (miss[1] && n_env > 1) private_issue(p, w, 1, tile1, lane);
-#ifdef RV_K1_LITE
-    if (threadIdx.x == 256) g_k1_stamps[(size_t)blockIdx.x * 64 + 32 + 20] = 1000ull + (miss[0] ? 1u : 0u) + (miss[1] ? 2u : 0u);   // hit / miss of the windows staged ahead
-#endif
-    // env 1 is the step wave's to cast (after its tail): it must see the box the cells of env 1 actually sit in
-    if (lane == 0) {
-        float *w1 = const_cast<float *>(win) + 8;
-        w1[5] = __int_as_float(w.i_lo[1]); w1[6] = __int_as_float(w.j_lo[1]); w1[7] = __int_as_float(w.pk[1]);
-    }
+    if (n_env > 0) private_issue(p, w, 0, tile0, lane);
+    if (n_env > 1) private_issue(p, w, 1, tile1, lane);
     K1_LITE(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     K1_LITE(4);
-    // env 0 under the step wave's manager tail; then tile 0 is free for window 2
+    // env 0 under the step wave's manager tail.  (Measured, us per step at 4096 envs: this order 33.8; window 2 requested before
+    // barrier B as well 34.35 -- the step wave waits for the request's issue; window 1 requested only after env 0's cast 34.35.)
     if (n_env > 0) private_cast<TRI, 0, PRIVATE_ROUNDS>(p, w, 0, tile0, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
     K1_LITE(5);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (n_env > 2) private_issue(p, w, 2, tile0, lane);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     K1_LITE(6);
-    __syncthreads();                                                    // B: env 0 is cast, env 1's box is published
+    __syncthreads();                                                    // B: env 0 is cast, tile 0 is free
     K1_LITE(7);
+    if (n_env > 2) private_issue(p, w, 2, tile0, lane);
     if (n_env > 1) private_cast<TRI, SHARE_1, PRIVATE_ROUNDS>(p, w, 1, tile1, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
     K1_LITE(8);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -2477,31 +2382,7 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
     float Fw[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};   // [0..2] this wheel's force, [3..5] this lane's link-point force
     f2 oxy[PRIVATE_ROUNDS];   // the scan phase's ray table (one-launch forms)
     K1_STAMP(1);
-    if constexpr (FUSE == 1 || FUSE == 2) {
-        // L0, two substeps before the end: the copy wave stages the windows of envs 0 and 1 AHEAD, for this pose and a margin
-        // (scan_window_ahead) -- or, where a reset is already certain (time-out / success / far are functions of words loaded
-        // before the physics), for the spawn pose it drew.  What remains for the end of the step is a containment test.
-        auto post_ahead = [&]() {
-            const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-            float *lk = fused_link(lds, p, wv);
-            if ((lane & 15) == 0) {
-                bool t[ROVER_NUM_TERM];
-                mdp_terminations(c, S + ROVER_CMD_B, __float_as_int(S[ROVER_EP_LEN]) + 1, false, t);
-                const float qw = g.quat[0], qx = g.quat[1], qy = g.quat[2], qz = g.quat[3];
-                reinterpret_cast<float4 *>(lk + 48)[lane >> 4] = make_float4(g.pos[0], g.pos[1], g.pos[2], (t[0] | t[1] | t[2]) ? 1.0f : 0.0f);
-                reinterpret_cast<float4 *>(lk + 304)[lane >> 4] = make_float4(1.0f - 2.0f * (qy * qy + qz * qz), 2.0f * (qw * qz + qx * qy), 0.0f, 0.0f);
-            }
-            __syncthreads();                                            // L0
-        };
-        const int s_ahead = max(c.decimation - RV_AHEAD_SUBSTEPS, 0);   // the hand-over happens in front of this substep
-        for (int s = 0; s < c.decimation - 1; ++s) {
-            if (s == s_ahead) post_ahead();
-            physics_substep_group<false>(p, K, g, nullptr, s);
-        }
-        if (c.decimation - 1 <= s_ahead) post_ahead();
-    } else {
-        for (int s = 0; s < c.decimation - 1; ++s) physics_substep_group<false>(p, K, g, nullptr, s);
-    }
+    for (int s = 0; s < c.decimation - 1; ++s) physics_substep_group<false>(p, K, g, nullptr, s);
     if constexpr (FUSE == 1 || FUSE == 2) {
         // copy-wave form: the link-body sample points of the contact report (evaluated at the pose of the last substep's START)
         // are the copy wave's work -- it is asleep until now; this wave goes straight into the substep
@@ -2759,13 +2640,13 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
         float *win = fused_win(lds, p, wv);
         const int n_scan = max(0, min(4, p.n - wave * 4));
         const int e_base = wave * 4;
+        // the windows of the final poses: written by this wave before barrier A2 (the reset was decided there)
+        PrivateWindows pw;
+        windows_from_lds(win, pw);
         K1_LITE(3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the ray table
         K1_LITE(4);
         __syncthreads();                                                // B: the copy wave has cast env 0 and requested window 2
-        // the windows of the final poses (written by this wave before barrier A2; env 1's box as the copy wave found it staged)
-        PrivateWindows pw;
-        windows_from_lds(win, pw);
         K1_LITE(5);
         K1_STAMP(27);
         if (n_scan > 1) private_cast<FUSE == 2, 0, SHARE_1>(p, pw, 1, tile1, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);

@@ -34,7 +34,7 @@ names.update({20: "physics done", 23: "state stored + force gathered", 24: "mdp 
 order = [0, 1] + [k for i in range(6) for k in (2 + 3 * i, 3 + 3 * i, 4 + 3 * i)] + [20, 23, 24, 21, 22, 25]
 fused = env.kernel_names()[0].startswith("rover_step_scan_kernel")
 if fused:
-    names.update({27: "scan: barrier B (the copy wave has cast env 0 under the tail)", 28: "scan: env 1 cast",
+    names.update({27: "scan: barrier B (the copy wave has cast env 0 under the tail)", 28: "scan: env 1 cast (both waves)",
                   29: "scan: barrier C, env 2 cast", 26: "scan: barrier D, env 3 cast (both waves)"})
     order += [27, 28, 29, 26]
 keys = order

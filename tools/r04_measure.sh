@@ -1,8 +1,8 @@
 #!/bin/bash
 # Dev tool (GPU box): the round-4 measurement set (needs `python tools/build_diag.py K1STAMP POLSTAMP LIFTSTAMP` first).  Every step
-# writes under gpurun_out/r04h; the chain stops at the first failing GPU step.  $1: 1 = first half, 2 = second half (two gpurun calls).
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04h; mkdir -p $O
-TAG="r04_h build (one-launch step kernel: reset decided after the physics, windows of envs 0 and 1 staged ahead with a containment test, env 0 cast under the manager tail, seven barriers; chassis / manager words stored one row per lane; pipelined packed ray cast, 16-byte row stores, lean LDS-DMA loop; contact report with horizontal components; policy pair kernel layer by layer)"
+# writes under gpurun_out/r04i; the chain stops at the first failing GPU step.  $1: 1 = first half, 2 = second half (two gpurun calls).
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04i; mkdir -p $O
+TAG="r04_i build (one-launch step kernel: reset decided after the physics, final windows to the copy wave, env 0 cast under the manager tail, six barriers; chassis / manager words stored one row per lane through 32-bit offsets; reset log row one value per lane; pipelined packed ray cast, 16-byte row stores, lean LDS-DMA loop; contact report with horizontal components; policy pair kernel layer by layer)"
 cd /tmp && export TMPDIR=/tmp
 export ROVER_ALSO_TWO_LAUNCH=1   # pmc_run.py: the two-launch path behind the product run (traffic of both forms)
 if [ "${1:-1}" = "1" ]; then
@@ -38,7 +38,7 @@ python3 tools/policy_stamps.py pair > $O/policy_stamps_pair.txt 2>&1 && \
 python3 tools/policy_stamps.py > $O/policy_stamps.txt 2>&1 && \
 python3 tools/lift_stamps.py 2048 > $O/lift_stamps.txt 2>&1 && \
 python3 tools/host_path.py > $O/host_path.txt 2>&1 && \
-bash tools/r04_reset_cost.sh r04h_reset > /dev/null 2>&1 && cp gpurun_out/r04h_reset/reset_cost.txt $O/reset_cost.txt && \
+bash tools/r04_reset_cost.sh r04i_reset > /dev/null 2>&1 && cp gpurun_out/r04i_reset/reset_cost.txt $O/reset_cost.txt && \
 python3 tools/n_sweep.py > $O/n_sweep.txt 2>&1
 echo "half 2 rc=$?"
 fi
