@@ -91,6 +91,31 @@ def synthetic_obs(n, seed=0):
     return obs
 
 
+def policy_forward_fixture(golden_dir):
+    """tests/golden/policy_forward.npz (tools/gen_golden.py::gen_policy_forward): outputs of the REFERENCE's own
+    GaussianNeuralNetwork.compute / DeterministicNeuralNetwork.compute (learning/skrl/models.py:89-102, 151-163).  The weights
+    and the synthetic rows are regenerated from the recorded seeds and checked against the recorded digests.
+    Returns {"policy": (ws, bs), "value": (ws, bs)}, obs (320, 965), expected mean (320, 2), expected value (320, 1)."""
+    import hashlib
+    import os
+    g = np.load(os.path.join(golden_dir, "policy_forward.npz"))
+
+    def digest(arrs):
+        h = hashlib.sha256()
+        for a in arrs:
+            h.update(np.ascontiguousarray(a, dtype=np.float32).tobytes())
+        return h.hexdigest()
+    scale = float(g["weight_scale"])
+    nets = {"policy": random_policy_weights(seed=int(g["weight_seed_policy"]), out_dim=2, scale=scale),
+            "value": random_policy_weights(seed=int(g["weight_seed_value"]), out_dim=1, scale=scale)}
+    for role, (ws, bs) in nets.items():
+        assert digest(ws + bs) == str(g[f"weights_sha256_{role}"]), f"{role}: regenerated weights differ from the fixture's"
+    syn = synthetic_obs(int(g["synthetic_rows"]), seed=int(g["synthetic_seed"]))
+    assert digest([syn]) == str(g["synthetic_sha256"]), "regenerated synthetic rows differ from the fixture's"
+    obs = np.concatenate([syn, g["env_rows"]], 0).astype(np.float32)
+    return nets, obs, g["policy_mean"], g["value"]
+
+
 # ---------------------------------------------------------------------------------------------- reset fixture
 def reset_fixture_case(g, batch):
     """Per-env arrays (scattered from the batch's env_ids) of tests/golden/reset.npz: what ``reset_with_draws`` consumes

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import random_policy_weights, synthetic_obs, torch_policy_reference
+from helpers import policy_forward_fixture, random_policy_weights, synthetic_obs, torch_policy_reference
 
 pytestmark = pytest.mark.gpu
 
@@ -33,6 +33,25 @@ def test_forward_bit_exact_vs_oracle(po, out_dim, final_act, n):
     assert np.array_equal(got, ref), f"max |diff| {np.abs(got - ref).max()}"
     tor = torch_policy_reference(ws, bs, obs, final_act == "tanh", device="cuda")
     assert np.abs(got - tor).max() <= 2e-5
+
+
+def test_forward_and_pair_match_the_reference_networks_fixture(po, golden_dir):
+    """SURVEY 8f-3 pin on the GPU: rover_policy_forward and rover_policy_forward_pair against the outputs of the reference's OWN
+    GaussianNeuralNetwork / DeterministicNeuralNetwork (tests/golden/policy_forward.npz; models.py:89-102, 151-163), |diff| <= 2e-5
+    (fp32 accumulation order: MFMA k-chains vs torch's CPU GEMM), and bit-exact against the oracle on the same rows."""
+    from isaac_rover_orbit_amd.policy import RoverNet, forward_pair
+    nets, obs, mean, value = policy_forward_fixture(golden_dir)
+    actor = RoverNet(*nets["policy"], n_enc=2, final_act="tanh")
+    critic = RoverNet(*nets["value"], n_enc=2, final_act="none")
+    o = torch.from_numpy(obs).cuda()
+    a1, v1 = actor(o).cpu().numpy(), critic(o).cpu().numpy()
+    a2, v2 = (t.cpu().numpy() for t in forward_pair(actor, critic, o))
+    vtol = 2e-5 * max(1.0, float(np.abs(value).max()))
+    for a, v in ((a1, v1), (a2, v2)):
+        assert np.abs(a - mean).max() <= 2e-5 and np.abs(v - value).max() <= vtol
+    assert np.array_equal(a1, a2) and np.array_equal(v1, v2)
+    assert np.array_equal(a1, po.forward(po.desc_from(actor.desc), *nets["policy"], obs))
+    assert np.array_equal(v1, po.forward(po.desc_from(critic.desc), *nets["value"], obs))
 
 
 def test_full_batch_and_from_state_dict(po):

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import random_policy_weights, synthetic_obs, torch_policy_reference
+from helpers import policy_forward_fixture, random_policy_weights, synthetic_obs, torch_policy_reference
 
 CKPT = "/root/reference/rover_envs/envs/navigation/robots/aau_rover/policies/best_agent.pt"
 
@@ -28,6 +28,52 @@ def test_oracle_matches_torch_fp32(po, out_dim, final_tanh):
     got = po.forward(po.default_desc(out_dim, final_tanh), ws, bs, obs)
     assert got.shape == ref.shape == (300, out_dim)
     assert np.abs(ref).max() > 0.05 and np.abs(got - ref).max() <= 2e-5
+
+
+def test_oracle_matches_the_reference_networks_fixture(po, golden_dir):
+    """SURVEY 8f-3 pin: the oracle against outputs recorded from the reference's OWN model classes (models.py:89-102, 151-163)
+    -- not against this repository's torch restatement.  Tolerance: fp32 accumulation order (fmaf chain vs torch's CPU GEMM)
+    on O(1) outputs, |diff| <= 2e-5."""
+    nets, obs, mean, value = policy_forward_fixture(golden_dir)
+    got_a = po.forward(po.default_desc(2, True), *nets["policy"], obs)
+    got_v = po.forward(po.default_desc(1, False), *nets["value"], obs)
+    assert got_a.shape == mean.shape == (320, 2) and got_v.shape == value.shape == (320, 1)
+    assert np.abs(mean).max() > 0.5 and np.abs(value).max() > 1.0                     # the fixture is not degenerate
+    assert np.abs(got_a - mean).max() <= 2e-5, np.abs(got_a - mean).max()
+    assert np.abs(got_v - value).max() <= 2e-5 * max(1.0, float(np.abs(value).max())), np.abs(got_v - value).max()
+    # the builder's torch restatement (used by the other tests as the fp32 reference) agrees with the reference's classes too
+    assert np.abs(torch_policy_reference(*nets["policy"], obs, True) - mean).max() <= 2e-6
+
+
+@pytest.mark.skipif(not os.path.exists(CKPT), reason="reference checkpoint not mounted (build container only)")
+def test_oracle_matches_the_reference_networks_with_the_shipped_checkpoint(po, golden_dir):
+    """best_agent.pt loaded into the reference's own classes (as eval.py:146-149 does) vs the oracle on the same weights."""
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    saved_path, before = list(sys.path), set(sys.modules)
+    sys.path.insert(0, os.path.join(root, "tools"))
+    try:
+        import gen_golden as gg
+        models = gg._load_reference_models()
+        ck = torch.load(CKPT, map_location="cpu", weights_only=False)
+        nets = gg.reference_networks(models, {})
+        _, obs, _, _ = policy_forward_fixture(golden_dir)
+        for role, out_dim, final_tanh in (("policy", 2, True), ("value", 1, False)):
+            nets[role].load_state_dict(ck[role])
+            with torch.no_grad():
+                ref = nets[role].compute({"states": torch.from_numpy(obs)}, role=role)[0].numpy()
+            sd = ck[role]
+            ws = [sd[f"dense_encoder.encoder_layers.{i}.weight"].numpy() for i in (0, 2)] + [sd[f"mlp.{i}.weight"].numpy() for i in (0, 2, 4, 6)]
+            bs = [sd[f"dense_encoder.encoder_layers.{i}.bias"].numpy() for i in (0, 2)] + [sd[f"mlp.{i}.bias"].numpy() for i in (0, 2, 4, 6)]
+            got = po.forward(po.default_desc(out_dim, final_tanh), ws, bs, obs)
+            assert got.shape == ref.shape
+            assert np.abs(got - ref).max() <= 2e-5 * max(1.0, float(np.abs(ref).max())), (role, np.abs(got - ref).max())
+    finally:
+        sys.path[:] = saved_path
+        for name in set(sys.modules) - before:
+            if name.split(".")[0] in ("rover_envs", "skrl", "omni", "carb", "pxr", "pymeshlab", "cv2", "gen_golden", "reference_stubs", "_ref_skrl_models"):
+                sys.modules.pop(name, None)
 
 
 @pytest.mark.skipif(not os.path.exists(CKPT), reason="reference checkpoint not mounted (build container only)")

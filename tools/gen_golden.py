@@ -27,6 +27,12 @@ Outputs (small .npz files, data only -- inputs and the reference's outputs):
                           ``subtract_frame_transforms``, third-party, absent) are supplied as a restatement of their
                           documented quaternion algebra -- that part is restated, not pinned
 
+* ``policy_forward.npz`` -- SURVEY 8f-3: ``GaussianNeuralNetwork.compute`` / ``DeterministicNeuralNetwork.compute`` of the
+                          reference's OWN model classes (rover_envs/envs/navigation/learning/skrl/models.py:24-36, 89-102, 151-163;
+                          skrl's base classes by tests/doubles/skrl) with seeded random weights generated here and loaded via
+                          ``load_state_dict``, on 256 synthetic rows + 64 rows an env produced.  Stored: the generating seeds
+                          with sha256 digests of the regenerated weights / synthetic rows, the env rows, the outputs.
+
 Functions that live in third-party code absent from the container (ORBIT math utils, PhysX, Warp
 ray-caster, cv2 morphology) cannot be evaluated and are NOT covered here; see DESIGN.md "parity".
 """
@@ -458,7 +464,107 @@ def gen_lift_terms():
     print("lift_terms:", {k: tuple(v.shape) for k, v in out.items()})
 
 
+# --------------------------------------------------------------------------------------- policy forward (f-3)
+def _test_paths():
+    tests = os.path.dirname(OUT)
+    for p in (os.path.join(tests, "doubles"), tests, os.path.dirname(tests)):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _load_reference_models():
+    """rover_envs/envs/navigation/learning/skrl/models.py by path, with tests/doubles/skrl standing in for skrl 1.1.0's three
+    base classes (Model, GaussianMixin, DeterministicMixin -- none of them takes part in ``compute``)."""
+    import importlib.util
+    _test_paths()
+    spec = importlib.util.spec_from_file_location(
+        "_ref_skrl_models", os.path.join(reference_stubs.REFERENCE_ROOT, "rover_envs", "envs", "navigation", "learning", "skrl", "models.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def reference_networks(models, ws_bs_by_role):
+    """The reference's actor / critic built as get_models.py:36-62 builds them, with the given weights loaded."""
+    space = types.SimpleNamespace(shape=(965,))
+    aspace = types.SimpleNamespace(shape=(2,))
+    kw = dict(observation_space=space, action_space=aspace, device="cpu", mlp_input_size=4, mlp_layers=[256, 160, 128],
+              mlp_activation="leaky_relu", encoder_input_size=961, encoder_layers=[80, 60], encoder_activation="leaky_relu")
+    nets = {"policy": models.GaussianNeuralNetwork(**kw), "value": models.DeterministicNeuralNetwork(**kw)}
+    for role, (ws, bs) in ws_bs_by_role.items():
+        sd = nets[role].state_dict()
+        names = [f"dense_encoder.encoder_layers.{i}" for i in (0, 2)] + [f"mlp.{i}" for i in (0, 2, 4, 6)]
+        for nm, w, b in zip(names, ws, bs):
+            assert tuple(sd[nm + ".weight"].shape) == w.shape
+            sd[nm + ".weight"] = torch.from_numpy(w.copy())
+            sd[nm + ".bias"] = torch.from_numpy(b.copy())
+        nets[role].load_state_dict(sd)
+        nets[role].eval()
+    return nets
+
+
+def _env_rows(n_rows=64):
+    """Observation rows as the env produces them (CPU oracle == HIP path bit for bit): 16 envs x 4 points of a random-action rollout
+    on the small procedural test terrain."""
+    _test_paths()
+    from helpers import oracle_config_from, oracle_terrain, small_procedural
+    from isaac_rover_orbit_amd.cfg import RoverEnvCfg
+    from oracle import rover_oracle as ro
+    n = 16
+    ter = small_procedural()
+    ter.make_spawns(2 * n)
+    cfg = RoverEnvCfg()
+    cfg.scene.num_envs = n
+    ocfg = oracle_config_from(ro, cfg.to_native())
+    oter = oracle_terrain(ro, ter)
+    S = ro.new_state(n)
+    rows = [ro.reset_all(ocfg, oter, S)]
+    rng = np.random.RandomState(11)
+    for t in range(1, 16):
+        o = ro.step(ocfg, oter, S, rng.uniform(-1, 1, (n, 2)).astype(np.float32))[0]
+        if t % 5 == 0:
+            rows.append(o)
+    rows = np.concatenate(rows, 0)[:n_rows].astype(np.float32)
+    assert rows.shape == (n_rows, 965) and np.isfinite(rows).all()
+    return rows
+
+
+def gen_policy_forward():
+    import hashlib
+    _test_paths()
+    from helpers import random_policy_weights, synthetic_obs
+    models = _load_reference_models()
+    seeds = {"policy": 101, "value": 202}
+    scale = 3.0                      # 3 x the torch default init range: O(1) outputs, the tanh head is exercised
+    wb = {"policy": random_policy_weights(seed=seeds["policy"], out_dim=2, scale=scale),
+          "value": random_policy_weights(seed=seeds["value"], out_dim=1, scale=scale)}
+    nets = reference_networks(models, wb)
+    syn_seed = 77
+    syn = synthetic_obs(256, seed=syn_seed)
+    env_rows = _env_rows(64)
+    obs = torch.from_numpy(np.concatenate([syn, env_rows], 0))
+    with torch.no_grad():
+        mean, log_std, _ = nets["policy"].compute({"states": obs}, role="policy")       # models.py:89-102 (tanh head :86)
+        value, _ = nets["value"].compute({"states": obs}, role="value")                   # models.py:151-163
+    assert mean.shape == (320, 2) and value.shape == (320, 1) and float(log_std.abs().max()) == 0.0
+
+    def digest(arrs):
+        h = hashlib.sha256()
+        for a in arrs:
+            h.update(np.ascontiguousarray(a, dtype=np.float32).tobytes())
+        return h.hexdigest()
+    out = {"weight_seed_policy": np.int64(seeds["policy"]), "weight_seed_value": np.int64(seeds["value"]),
+           "weight_scale": np.float64(scale), "synthetic_seed": np.int64(syn_seed), "synthetic_rows": np.int64(256),
+           "weights_sha256_policy": np.array(digest(wb["policy"][0] + wb["policy"][1])),
+           "weights_sha256_value": np.array(digest(wb["value"][0] + wb["value"][1])),
+           "synthetic_sha256": np.array(digest([syn])),
+           "env_rows": env_rows, "policy_mean": mean.numpy(), "value": value.numpy()}
+    np.savez_compressed(os.path.join(OUT, "policy_forward.npz"), **out)
+    print("policy_forward:", mean.shape, value.shape, "|mean| max", float(mean.abs().max()), "|value| max", float(value.abs().max()))
+
+
 if __name__ == "__main__":
+    gen_policy_forward()
     gen_lift_terms()
     gen_reset()
     gen_ackermann()
