@@ -90,6 +90,13 @@ typedef struct rover_config {
                                 rover_env_cfg.py:84): 0 = the TRIANGLE MESH of the heightfield (every 0.05 m cell split
                                 along its (i, j) - (i+1, j+1) diagonal: what a mesh ray-cast of that terrain returns),
                                 1 = the bilinear patch (smooth; the wheels' contact surface) */
+    int32_t mass_model;      /* where the rover's 25 kg act (rover_envs/assets/robots/aau_rover_simple/rover_instance.usd link table,
+                                tests/golden/rover_model.json): 1 (default) = the weight of each bogie SUBTREE (beam + steer links +
+                                wheels: 7 + 7 + 9 kg) acts at its own centre of mass -- a generalised gravity force on the bogie
+                                coordinate: the statics of the articulated rover (centre : front wheel load 0.74 : 1); 0 = the
+                                model of rounds 1 - 4: all mass lumped at the chassis centre of mass (1.96 : 1 by lever arms) */
+    float rew_success_threshold, rew_far_threshold; /* thresholds of the reached_target / far_from_target REWARD terms
+                                (rover_env_cfg.py:136,162) -- table entries of their own beside the terminations' (:173,177) */
 } rover_config;
 
 typedef struct rover_sim rover_sim;

@@ -170,7 +170,11 @@ class RoverEnvCfg:
     spawn_draw: str = "distinct"
     seed: int = 0
     friction: float = 0.75
-    solver_iterations: int = 16             # Jacobi sweeps of the contact solver (ORBIT cfg: 32 position iterations)
+    solver_iterations: int = 32             # Jacobi sweeps of the contact solver = the reference's solver_position_iteration_count
+                                            # (aau_rover_simple.py:33); rounds 1-4 ran 16
+    # where the rover's 25 kg act: "subtree_weights" = the weight of each bogie subtree (beam + steer links + wheels: 7 + 7 + 9 kg
+    # of the USD link table) at its own centre of mass -- the static wheel loads of the articulated rover; "lumped" = rounds 1-4
+    mass_model: str = "subtree_weights"
     step_mapping: str = "auto"              # "auto" | "lane" (one env per lane) | "group" (sixteen lanes per env)
     record_contact_forces: bool = True       # materialise contact_sensor.data.force_matrix_w every step
     use_int16_terrain: bool = True           # stage the exact int16 copy of the heightfield in the scan kernel when it exists
@@ -218,6 +222,10 @@ class RoverEnvCfg:
             raise ValueError("reset_velocities must be 'reference' or 'zero'")
         if self.spawn_draw not in ("distinct", "independent"):
             raise ValueError("spawn_draw must be 'distinct' or 'independent'")
+        if self.log_values not in ("device", "host"):
+            raise ValueError("log_values must be 'device' or 'host'")
+        if self.mass_model not in ("lumped", "subtree_weights"):
+            raise ValueError("mass_model must be 'subtree_weights' or 'lumped'")
         if self.commands.simple_heading:
             raise ValueError("simple_heading=True is not supported (the reference cfg uses False, rover_env_cfg.py:195)")
 
@@ -252,11 +260,11 @@ class RoverEnvCfg:
         c.sim_dt, c.decimation = self.sim.dt, self.decimation
         c.max_episode_length = self.max_episode_length
         c.max_episode_length_s = self.episode_length_s
-        succ = self.terminations["is_success"].params["threshold"]
-        far = self.terminations["far_from_target"].params["threshold"]
-        c.success_threshold, c.far_threshold = succ, far
-        if self.rewards["reached_target"].params["threshold"] != succ or self.rewards["far_from_target"].params["threshold"] != far:
-            raise ValueError("reward and termination thresholds must agree (as in rover_env_cfg.py:136,162,173,177)")
+        # four independent table entries in the reference (rover_env_cfg.py:136, 162 rewards; :173, 177 terminations)
+        c.success_threshold = self.terminations["is_success"].params["threshold"]
+        c.far_threshold = self.terminations["far_from_target"].params["threshold"]
+        c.rew_success_threshold = self.rewards["reached_target"].params["threshold"]
+        c.rew_far_threshold = self.rewards["far_from_target"].params["threshold"]
         c.target_distance = self.commands.target_distance
         c.heading_lo, c.heading_hi = self.commands.heading_range
         if self.commands.resampling_time_range[0] != self.commands.resampling_time_range[1]:
@@ -278,6 +286,7 @@ class RoverEnvCfg:
         c.seed_lo, c.seed_hi = self.seed & 0xFFFFFFFF, (self.seed >> 32) & 0xFFFFFFFF
         c.friction_mu = self.friction
         c.solver_iterations = self.solver_iterations
+        c.mass_model = {"lumped": 0, "subtree_weights": 1}[self.mass_model]
         c.max_target_tries = self.commands.max_target_tries
         c.step_mapping = {"auto": 0, "lane": 1, "group": 2}[self.step_mapping]
         return c

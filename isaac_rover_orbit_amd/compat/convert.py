@@ -14,7 +14,10 @@ Built-in term functions are matched by table key and ``func.__name__``.  A rewar
 is a USER-WRITTEN term (the reference's tables hold arbitrary ``func=``, rover_env_cfg.py:126-183): its callable and params
 are kept as they are (``SceneEntityCfg`` objects included) and ``RoverEnv.step`` evaluates it in torch between the two halves
 of the step (the slow path).  A built-in reward that the cfg omits is switched off (weight 0); an omitted ``is_success`` /
-``far_from_target`` termination gets a threshold no distance can meet; ``time_limit`` and ``collision`` cannot be omitted.
+``far_from_target`` termination gets a threshold no distance can meet -- the REWARD term of the same name keeps its own threshold
+(``rover_config.rew_success_threshold`` / ``rew_far_threshold``: rover_env_cfg.py:136,162 vs :173,177 are independent entries);
+``time_limit`` and ``collision`` cannot be omitted.
+``log_values`` of a converted cfg is ``"host"`` (the reference trainer's per-step ``.item()`` reads, skrl_utils.py:139-142).
 """
 from __future__ import annotations
 
@@ -89,11 +92,9 @@ def from_reference_cfg(ref) -> RoverEnvCfg:
                 raise ValueError(f"termination term '{name}' is a built-in name and must use '{fn}' (got '{_func_name(ter[name].func)}')")
             out.terminations[name] = TermCfg(fn, params=_plain_params(ter[name].params), time_out=bool(ter[name].time_out))
         elif name == "is_success":
-            out.terminations[name].params["threshold"] = -1.0           # d < -1 never holds
-            out.rewards["reached_target"].params["threshold"] = -1.0
-        elif name == "far_from_target":
+            out.terminations[name].params["threshold"] = -1.0           # d < -1 never holds; the reached_target REWARD keeps its own
+        elif name == "far_from_target":                                 # threshold (rover_env_cfg.py:136 / :162 are entries of their own)
             out.terminations[name].params["threshold"] = float("inf")   # d > inf never holds
-            out.rewards["far_from_target"].params["threshold"] = float("inf")
         else:
             raise ValueError(f"the built-in termination '{name}' cannot be omitted (the episode clock / the contact report end episodes in the kernel)")
     for name, t in ter.items():
@@ -118,5 +119,10 @@ def from_reference_cfg(ref) -> RoverEnvCfg:
     rnd = getattr(ref, "randomization", None)
     if rnd is not None and hasattr(rnd, "reset_state"):
         out.reset_z_offset = float(rnd.reset_state.params.get("z_offset", 0.5))
+    # The consumer of a converted cfg is the reference's own trainer stack, which calls .item() on every entry of infos["episode"]
+    # after EVERY step (rover_envs/utils/skrl_utils.py:139-142): with 0-d DEVICE tensors that is thirteen host synchronisations per
+    # step (~290 us), with the pinned host mirror one copy and one synchronisation (~100 us) -- same numbers, and 0-d CPU tensors
+    # satisfy the isinstance / numel() checks of that loop.  The native RoverEnvCfg keeps ORBIT's "device".
+    out.log_values = "host"
     out.validate()
     return out

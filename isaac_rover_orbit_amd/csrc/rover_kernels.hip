@@ -47,11 +47,13 @@ struct StepConsts {
     float steer_hkp, steer_den_inv, steer_i_over_h, steer_dv_max;
     float wheel_den_inv, wheel_h_over_i, lt_motor;
     float bogie_keep[3], b_winv[3];
+    float bogie_gq[3];   // cfg.mass_model = 1: -(m_j g) h / I_j, the bogie-rate change per unit of (R (ax x arm_j)).z
 };
 __host__ __device__ inline void make_step_consts(float h, StepConsts &k)
 {
     constexpr float INERTIA_B[3] = RV_INERTIA_B_INIT;
     constexpr float BOGIE_INERTIA[3] = RV_BOGIE_INERTIA_INIT;
+    constexpr float SUBTREE_MASS[3] = RV_SUBTREE_MASS_INIT;
     k.h = h;
     k.inv_h = 1.0f / h;
     k.inv_m = 1.0f / RV_M_TOTAL;
@@ -66,6 +68,7 @@ __host__ __device__ inline void make_step_consts(float h, StepConsts &k)
     for (int j = 0; j < 3; ++j) {
         k.bogie_keep[j] = 1.0f / (1.0f + h * RV_BOGIE_DAMPING / BOGIE_INERTIA[j]);
         k.b_winv[j] = 1.0f / BOGIE_INERTIA[j];
+        k.bogie_gq[j] = (-(SUBTREE_MASS[j] * RV_GRAVITY) * h) * k.b_winv[j];
     }
 }
 
@@ -386,7 +389,7 @@ __device__ __forceinline__ void mdp_terms_one(const rover_config &c, const float
     const float d = sqrtf(cmd_b[0] * cmd_b[0] + cmd_b[1] * cmd_b[1]);
     const float angle = rv_atan2f(cmd_b[1], cmd_b[0]);
     rew[0] = (1.0f / (1.0f + (0.11f * d * d))) / L;
-    rew[1] = (d < c.success_threshold) ? (float)(c.max_episode_length - ep_len) / L : 0.0f;
+    rew[1] = (d < c.rew_success_threshold) ? (float)(c.max_episode_length - ep_len) / L : 0.0f;   // the REWARD entry's threshold (rover_env_cfg.py:136)
     {
         const float linear_diff = action[1] - prev_action[1];
         const float angular_diff = action[0] - prev_action[0];
@@ -400,7 +403,7 @@ __device__ __forceinline__ void mdp_terms_one(const rover_config &c, const float
     rew[4] = (action[0] < 0.0f) ? (float)(1.0 / (double)c.max_episode_length) : 0.0f;
     const bool coll = coll_known >= 0 ? coll_known != 0 : (no_force ? false : collision_measure(F) > 1.0f);  // hard-coded 1, `threshold` ignored (B-8)
     rew[5] = coll ? 1.0f : 0.0f;
-    rew[6] = (d > c.far_threshold) ? 1.0f : 0.0f;
+    rew[6] = (d > c.rew_far_threshold) ? 1.0f : 0.0f;   // rover_env_cfg.py:162
     term[0] = ep_len >= c.max_episode_length;
     term[1] = d < c.success_threshold;
     term[2] = d > c.far_threshold;
@@ -512,6 +515,24 @@ __device__ __forceinline__ ArmConsts make_arm(const float *wb, const float *P, c
     a.ad = dot3f(ax, a.d0);
     return a;
 }
+// cfg.mass_model = 1: the weight of a bogie's SUBTREE (beam + steer links + wheels) acts at its own centre of mass c_j: generalised
+// gravity force on the bogie coordinate Q_j = -m_j g z . R (ax x arm_j), arm_j = c_j - P rotated by the bogie angle, with
+// ax x arm = (ax (ax . d0) - d0) sin q + (ax x d0) cos q for d0 = c_j(q = 0) - P.  `sub` = make_arm(c_j(0), P, ax); gq = K.bogie_gq[j].
+// Returns the bogie rate after the gravity impulse of one substep (oracle/rover_oracle.c physics_substep, same operations).
+__device__ __forceinline__ float bogie_gravity(const ArmConsts &sub, const float *ax, const float R[3][3], float sb, float cb, float gq,
+                                               float bd)
+{
+    float vb[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) vb[i] = fmaf(fmaf(ax[i], sub.ad, -sub.d0[i]), sb, sub.axd[i] * cb);
+    const float vwz = fmaf(R[2][2], vb[2], fmaf(R[2][1], vb[1], R[2][0] * vb[0]));
+    return fmaf(gq, vwz, bd);
+}
+__device__ __forceinline__ void bogie_sincos(float bq, float *sb, float *cb)
+{
+    if (fabsf(bq) < 0.75f) rv_sincosf_small(bq, sb, cb);   // always, for states the integrator produced (|bq| <= 10 deg)
+    else rv_sincosf(bq, sb, cb);
+}
 // One contact row of a wheel: angular Jacobian R^T (r x dir) in the body frame, bogie Jacobian dir . (ax x rp) with the
 // unilateral lock of a bogie that sits on a stop (normal row: only against the stop; friction rows: fully), split effective mass
 struct RowQ {
@@ -576,8 +597,8 @@ __device__ __forceinline__ LinkSample link_point_fetch(const RvParams &p, const 
     s.o00 = o[0]; s.o01 = o[1]; s.o10 = o[p.W]; s.o11 = o[p.W + 1];
     return s;
 }
-// force[3]: along the obstacle surface's un-normalised normal (-gx, -gy, 1): vertical component k x penetration (the value
-// round 3 reported alone), horizontal components from the slope of the surface patch under the point
+// force[3]: k x penetration along the obstacle surface's UNIT normal (-gx, -gy, 1) / sqrt(1 + gx^2 + gy^2): horizontal components
+// from the slope of the surface patch under the point
 __device__ __forceinline__ void link_point_eval(const LinkSample &s, float inv_res, float *force)
 {
     const float dx0 = s.h01 - s.h00, dx1 = s.h11 - s.h10, dy0 = s.h10 - s.h00, dy1 = s.h11 - s.h01;
@@ -588,7 +609,9 @@ __device__ __forceinline__ void link_point_eval(const LinkSample &s, float inv_r
     const float o0 = s.o00 + s.fx * (s.o01 - s.o00), o1 = s.o10 + s.fx * (s.o11 - s.o10);
     const float obst = o0 + s.fy * (o1 - o0);
     const float pen = hgt - s.z;
-    const float fz = (obst > RV_OBSTACLE_EPS && pen > 0.0f) ? RV_LINK_STIFFNESS * pen : 0.0f;
+    // k x (vertical) penetration along the UNIT normal: the magnitude does not grow with the slope of the face
+    const float fk = (obst > RV_OBSTACLE_EPS && pen > 0.0f) ? RV_LINK_STIFFNESS * pen : 0.0f;
+    const float fz = fk * rv_rsqrtf(fmaf(gx, gx, fmaf(gy, gy, 1.0f)));
     force[0] = -gx * fz;
     force[1] = -gy * fz;
     force[2] = fz;
@@ -855,6 +878,18 @@ __device__ __forceinline__ void physics_substep(const RvParams &p, const StepCon
         at_hi[j] = bq[j] >= RV_BOGIE_QLIM - 1.0e-5f;
         at_lo[j] = bq[j] <= -RV_BOGIE_QLIM + 1.0e-5f;
     }
+    if (p.cfg.mass_model == 1) {
+        constexpr float SUBTREE_COM[3][3] = RV_SUBTREE_COM_INIT;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float P[3] = {BOGIE_PIVOT[j][0], BOGIE_PIVOT[j][1], BOGIE_PIVOT[j][2]};
+            const float ax[3] = {BOGIE_AXIS[j][0], BOGIE_AXIS[j][1], BOGIE_AXIS[j][2]};
+            const float cj[3] = {SUBTREE_COM[j][0], SUBTREE_COM[j][1], SUBTREE_COM[j][2]};
+            float sb, cb;
+            bogie_sincos(bq[j], &sb, &cb);
+            bd[j] = bogie_gravity(make_arm(cj, P, ax), ax, R, sb, cb, K.bogie_gq[j], bd[j]);
+        }
+    }
     // ---- 3. contact geometry (slot order), warm start
     Contact C[6];
     const f2 minvA0 = {K.inv_m, K.inv_I[0]}, minvA1 = {K.inv_m, K.inv_I[1]}, minvB0 = {K.inv_m, K.inv_I[2]};
@@ -980,6 +1015,8 @@ struct GroupLane {
     float steer_t, wheel_t;
     // constants of this lane's slot
     float P[3], ax[3], b_winv, bogie_keep;
+    float bogie_gq;   // K.bogie_gq of the lane's bogie (cfg.mass_model = 1)
+    ArmConsts sub;    // arm of the bogie subtree's centre of mass about the pivot (cfg.mass_model = 1)
     float lp[3];   // this lane's link-body sample point
     ArmConsts arm;
     f2 minv0, minv1;  // inverse mass pairs of the lane's two channels (negated in idle slot 7, see physics_substep_group)
@@ -1167,6 +1204,11 @@ __device__ __forceinline__ void physics_substep_group(const RvParams &p, const S
     mat_tvecf(R, g.angvel, w);
     const float bq = g.bq;
     float bd = g.bqd * g.bogie_keep;
+    if (p.cfg.mass_model == 1) {   // the subtree's weight on the bogie coordinate (wave-uniform branch)
+        float sb, cb;
+        bogie_sincos(bq, &sb, &cb);
+        bd = bogie_gravity(g.sub, g.ax, R, sb, cb, g.bogie_gq, bd);
+    }
     const bool at_hi = bq >= RV_BOGIE_QLIM - 1.0e-5f, at_lo = bq <= -RV_BOGIE_QLIM + 1.0e-5f;
     Contact ct;
     LinkSample ls;
@@ -1595,10 +1637,14 @@ struct SlotConst {
     float wb[3], P[3], ax[3];
     int32_t k, j, si, body;   // wheel, bogie, steer joint (-1: none), contact-sensor body row
     float lp[2][3];           // link-body sample point of the role-A / role-B lane (RV_LINK_POINT_INIT)
-    int32_t pad;
+    float sc[3];              // centre of mass of the bogie's subtree at q = 0 (RV_SUBTREE_COM_INIT)
+    int32_t pad[2];
 };
 #define RV_SLOT_ROW(k_, j_, si_, body_, s_) \
-    {{RV_WB_##k_}, {RV_BP_##j_}, {RV_BA_##j_}, k_, j_, si_, body_, RV_LP_##s_, 0}
+    {{RV_WB_##k_}, {RV_BP_##j_}, {RV_BA_##j_}, k_, j_, si_, body_, RV_LP_##s_, {RV_SC_##j_}, {0, 0}}
+#define RV_SC_0 0.27019f, 0.38237f, -0.06738f
+#define RV_SC_1 0.27019f, -0.38237f, -0.06738f
+#define RV_SC_2 -0.40167f, 0.0f, -0.07031f
 #define RV_LP_0 {{0.44f, 0.3125f, -0.10f}, {0.29675f, 0.3075f, 0.0175f}}
 #define RV_LP_1 {{0.08025f, 0.3055f, -0.0685f}, {0.007f, 0.3085f, -0.12f}}
 #define RV_LP_2 {{0.44f, -0.3125f, -0.10f}, {0.29675f, -0.3075f, 0.0175f}}
@@ -1621,7 +1667,12 @@ struct SlotConst {
 __device__ const SlotConst d_SLOT[8] = {
     RV_SLOT_ROW(0, 0, 0, 9, 0), RV_SLOT_ROW(2, 0, -1, 7, 1), RV_SLOT_ROW(1, 1, 1, 10, 2), RV_SLOT_ROW(3, 1, -1, 8, 3),
     RV_SLOT_ROW(4, 2, 2, 11, 4), RV_SLOT_ROW(5, 2, 3, 12, 5), RV_SLOT_ROW(5, 2, 3, 12, 5), RV_SLOT_ROW(5, 2, 3, 12, 5)};
-static_assert(sizeof(SlotConst) == 80, "SlotConst row");
+static_assert(sizeof(SlotConst) == 96, "SlotConst row");
+static float d_SLOT_host_sc(int j, int i)
+{
+    const float sc[3][3] = {{RV_SC_0}, {RV_SC_1}, {RV_SC_2}};
+    return sc[j][i];
+}
 // host copy of the sample-point columns of d_SLOT (consistency check against RV_LINK_POINT_INIT in rover_model_constants)
 static float d_SLOT_host_lp(int slot, int role, int i)
 {
@@ -1681,6 +1732,11 @@ __device__ __forceinline__ void group_load(const float *__restrict__ state, int 
         for (int j = 1; j < 3; ++j) { bw = (id.j == j) ? K.b_winv[j] : bw; bk = (id.j == j) ? K.bogie_keep[j] : bk; }
         g.b_winv = bw;
         g.bogie_keep = bk;
+        float gq = K.bogie_gq[0];
+#pragma unroll
+        for (int j = 1; j < 3; ++j) gq = (id.j == j) ? K.bogie_gq[j] : gq;
+        g.bogie_gq = gq;
+        g.sub = make_arm(sc.sc, sc.P, sc.ax);
     }
     g.steerable = id.si >= 0;
     g.wheel_active = id.wheel_active;
@@ -3654,12 +3710,14 @@ int rover_default_config(rover_config *c)
     c->reset_mode = 0;
     c->seed_lo = 0u; c->seed_hi = 0u;
     c->friction_mu = 0.75f;
-    c->solver_iterations = 16;
+    c->solver_iterations = 32;                             // aau_rover_simple.py:33 solver_position_iteration_count
     c->step_mapping = 0;
     c->max_target_tries = 32;
     c->scan_surface = 0;
     c->spawn_draw = 1;
     c->counter_lo = 0u; c->counter_hi = 0u;
+    c->mass_model = 1;
+    c->rew_success_threshold = 0.18f; c->rew_far_threshold = 11.0f;   // rover_env_cfg.py:136,162
     return ROVER_OK;
 }
 
@@ -3672,7 +3730,8 @@ int rover_create(const rover_config *cfg, int32_t num_envs, int32_t env_id_offse
     if (cfg->scan_nx > 64 || cfg->scan_ny > 64) return fail(ROVER_ERR_UNSUPPORTED, "scan grid larger than 64 x 64 rays");
     if (cfg->scan_nx <= 0 || cfg->scan_ny <= 0 || cfg->scan_resolution <= 0.0f || cfg->decimation < 0 ||
         cfg->solver_iterations < 0 || cfg->max_target_tries < 1 || cfg->sim_dt <= 0.0f || cfg->max_episode_length <= 0 ||
-        cfg->scan_surface < 0 || cfg->scan_surface > 1 || cfg->spawn_draw < 0 || cfg->spawn_draw > 1)
+        cfg->scan_surface < 0 || cfg->scan_surface > 1 || cfg->spawn_draw < 0 || cfg->spawn_draw > 1 || cfg->mass_model < 0 ||
+        cfg->mass_model > 1)
         return fail(ROVER_ERR_INVALID, "invalid rover_config");
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count));
@@ -4154,6 +4213,14 @@ int rover_model_constants(float *out, int32_t cap)
             if (d_SLOT_host_lp(sl, r, i) != lp[sl][r][i]) return -1;      // the group mapping's table must be the same points
         t[n++] = RV_LINK_STIFFNESS;
     }
+    {
+        const float sm[3] = RV_SUBTREE_MASS_INIT, scom[3][3] = RV_SUBTREE_COM_INIT;
+        for (int j = 0; j < 3; ++j) t[n++] = sm[j];
+        for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) {
+            if (d_SLOT_host_sc(j, i) != scom[j][i]) return -1;         // the group mapping's table must hold the same centres
+            t[n++] = scom[j][i];
+        }
+    }
     if (out) for (int i = 0; i < n && i < cap; ++i) out[i] = t[i];
     return n;
 }
@@ -4161,6 +4228,6 @@ int rover_model_constants(float *out, int32_t cap)
 int rover_state_words(void) { return ROVER_STATE_WORDS; }
 size_t rover_config_bytes(void) { return sizeof(rover_config); }
 const char *rover_last_error(void) { return g_err; }
-const char *rover_version(void) { return "isaac_rover_orbit_amd 0.4.0 (gfx950)"; }
+const char *rover_version(void) { return "isaac_rover_orbit_amd 0.5.0 (gfx950)"; }
 
 }  // extern "C"

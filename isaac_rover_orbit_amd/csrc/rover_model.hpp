@@ -21,6 +21,10 @@
 #define RV_BOGIE_PIVOT_INIT {{0.1535f, 0.2225f, 0.03f}, {0.1535f, -0.2225f, 0.03f}, {-0.325f, 0.0f, 0.03f}}
 #define RV_BOGIE_AXIS_INIT {{0.0f, 1.0f, 0.0f}, {0.0f, -1.0f, 0.0f}, {1.0f, 0.0f, 0.0f}}
 #define RV_BOGIE_INERTIA_INIT {0.47474f, 0.47474f, 1.141279f}
+// the three bogie subtrees (beam + steer links + wheels) at q = 0: mass and centre of mass (body frame) from the USD link table
+// (tools/derive_rover_model.py -> tests/golden/rover_model.json "subtrees"): cfg.mass_model = 1
+#define RV_SUBTREE_MASS_INIT {7.0f, 7.0f, 9.0f}
+#define RV_SUBTREE_COM_INIT {{0.27019f, 0.38237f, -0.06738f}, {0.27019f, -0.38237f, -0.06738f}, {-0.40167f, 0.0f, -0.07031f}}
 #define RV_WHEEL_CONTACT_RADIUS 0.10179f  // 0.26878 (observations.py:45) - 0.16699
 // actuators: aau_rover_simple.py:42-64
 #define RV_STEER_INERTIA 0.005f

@@ -81,6 +81,12 @@ typedef struct {
     int32_t spawn_draw;          /* 1 = distinct rows per reset batch (affine bijection of the env ids), 0 = independent   */
     uint32_t counter_lo, counter_hi; /* call counter keying the per-batch spawn permutation (the caller increments it)  */
     int32_t scan_surface;        /* 0 = triangle mesh of the heightfield (cells split along (i,j)-(i+1,j+1)), 1 = bilinear */
+    int32_t mass_model;          /* 1 (default) = the weight of each bogie SUBTREE (beam + steer links + wheels: 7 + 7 + 9 of the USD's
+                                    25 kg) acts at its own centre of mass: a generalised gravity force on the bogie coordinate -- the
+                                    statics of the articulated rover (centre : front wheel load 0.74 : 1); 0 = rounds 1-4: everything
+                                    lumped at the chassis centre of mass (2 : 1) */
+    float rew_success_threshold, rew_far_threshold; /* thresholds of the reached_target / far_from_target REWARD terms
+                                    (rover_env_cfg.py:136,162: table entries of their own, beside the terminations' :173,177) */
 } rvo_config;
 
 typedef struct {

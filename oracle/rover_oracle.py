@@ -40,7 +40,8 @@ class Config(C.Structure):
         ("reset_z_offset", C.c_float), ("reset_mode", C.c_int32), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
         ("friction_mu", C.c_float), ("solver_iterations", C.c_int32), ("max_target_tries", C.c_int32),
         ("step_mapping", C.c_int32), ("spawn_draw", C.c_int32), ("counter_lo", C.c_uint32), ("counter_hi", C.c_uint32),
-        ("scan_surface", C.c_int32),
+        ("scan_surface", C.c_int32), ("mass_model", C.c_int32),
+        ("rew_success_threshold", C.c_float), ("rew_far_threshold", C.c_float),
     ]
 
 

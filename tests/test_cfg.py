@@ -38,7 +38,17 @@ def test_unknown_terms_are_rejected():
     c.terminations["is_success"].func = "something_else"
     with pytest.raises(ValueError):
         c.validate()
+    # reward and termination thresholds are independent table entries (rover_env_cfg.py:136,162 vs :173,177) and reach the
+    # parameter block as such
     c = RoverEnvCfg()
-    c.rewards["reached_target"].params["threshold"] = 0.5     # must agree with the termination threshold
+    c.rewards["reached_target"].params["threshold"] = 0.5
+    c.terminations["far_from_target"].params["threshold"] = 12.5
+    n = c.to_native()
+    assert abs(n.rew_success_threshold - 0.5) < 1e-7 and abs(n.success_threshold - 0.18) < 1e-7
+    assert abs(n.rew_far_threshold - 11.0) < 1e-7 and abs(n.far_threshold - 12.5) < 1e-7
+    assert n.mass_model == 1 and n.solver_iterations == 32                   # aau_rover_simple.py:33; the USD link table's statics
+    c.mass_model = "lumped"
+    assert c.to_native().mass_model == 0
+    c.mass_model = "point"
     with pytest.raises(ValueError):
         c.to_native()

@@ -73,7 +73,12 @@ def test_reference_registration_and_cfg_drive_the_kernels(ref_env):
     cfg = parse_env_cfg("AAURoverEnv-v0", use_gpu=True, num_envs=4096)
     assert type(cfg).__module__ == "rover_envs.envs.navigation.robots.aau_rover.env_cfg"   # the reference's own class
     assert cfg.scene.num_envs == 4096 and cfg.decimation == 6 and cfg.episode_length_s == 150
-    native = from_reference_cfg(cfg).to_native()
+    converted = from_reference_cfg(cfg)
+    # the gym-redirect / compat path serves the reference's trainer, which .item()s every log entry after every step
+    # (skrl_utils.py:139-142): extras["log"] lives in the pinned host mirror there; the native cfg keeps ORBIT's device tensors
+    from isaac_rover_orbit_amd.cfg import RoverEnvCfg
+    assert converted.log_values == "host" and RoverEnvCfg().log_values == "device"
+    native = converted.to_native()
     default = _lib.default_config()
     for name, _ in _lib.RoverConfig._fields_:
         a, b = getattr(native, name), getattr(default, name)
@@ -88,6 +93,20 @@ def test_reference_registration_and_cfg_drive_the_kernels(ref_env):
     assert n2.rew_weight[5] == -7.0 and n2.offset_lin == 0.0 and n2.scan_nx == 16 and abs(n2.success_threshold - 0.25) < 1e-7
     with pytest.raises(RuntimeError):
         parse_env_cfg("AAURoverEnv-v0", use_gpu=False)                         # no CPU pipeline on this path
+
+
+def test_termination_omitted_but_reward_kept(ref_env):
+    """a cfg that drops the ``is_success`` / ``far_from_target`` TERMINATION but keeps the reward of the same name
+    (independent entries in the reference: rover_env_cfg.py:136 / 162 vs :173 / 177) must keep that reward as configured."""
+    from omni.isaac.orbit_tasks.utils import parse_env_cfg
+    from isaac_rover_orbit_amd.compat.convert import from_reference_cfg
+    cfg = parse_env_cfg("AAURoverEnv-v0", num_envs=8)
+    del cfg.terminations.is_success
+    del cfg.terminations.far_from_target
+    n = from_reference_cfg(cfg).to_native()
+    assert n.success_threshold == -1.0 and n.far_threshold == float("inf")         # the terminations can never fire
+    assert abs(n.rew_success_threshold - 0.18) < 1e-7 and abs(n.rew_far_threshold - 11.0) < 1e-7   # the rewards are untouched
+    assert n.rew_weight[1] == 5.0 and n.rew_weight[6] == -2.0
 
 
 def test_reference_learning_glue_imports(ref_env):

@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_replay_reference_trainer_transcript(golden_dir):
+@pytest.mark.parametrize("log_values", ["host", "device"])   # "host" = what compat.convert gives the reference's trainer; "device" = native default
+def test_replay_reference_trainer_transcript(golden_dir, log_values):
     sys.path.insert(0, os.path.join(ROOT, "tests", "doubles"))
     from skrl.envs.wrappers.torch import wrap_env
     from isaac_rover_orbit_amd.cfg import RoverEnvCfg
@@ -28,6 +29,7 @@ def test_replay_reference_trainer_transcript(golden_dir):
     cfg = RoverEnvCfg()                     # = the reference's AAURoverEnvCfg field by field (tests/test_compat.py)
     cfg.scene.num_envs = n
     cfg.seed = int(g["seed"])
+    cfg.log_values = log_values
     assert list(g["terrain"]) == [cfg.terrain.kind, str(tuple(cfg.terrain.shape)), str(cfg.terrain.seed), str(cfg.terrain.sigma_z),
                                   str(cfg.terrain.n_rocks)]
     env = RoverEnv(cfg, headless=True, viewport=False)                  # train.py:123
@@ -53,6 +55,7 @@ def test_replay_reference_trainer_transcript(golden_dir):
         for i, k in enumerate(LOG_KEYS):
             v = infos["episode"][k]
             assert isinstance(v, torch.Tensor) and v.numel() == 1                          # :141
+            assert v.device.type == ("cpu" if log_values == "host" else "cuda")
             if g["log"][t][13] > 0:
                 assert abs(v.item() - g["log"][t][i]) <= 1e-5 * max(1.0, abs(g["log"][t][i])), (t, k)
         states.copy_(next_states)                                                          # :148

@@ -20,17 +20,63 @@ def fresh(ro, n=1, xy=(25.6, 25.6), z=0.5):
     return S
 
 
-def test_static_rest_height_and_load_sharing(oracle):
+def link_table_wheel_loads(golden_dir):
+    """Static wheel loads (N) of the articulated rover on flat ground from the USD link table alone (tests/golden/rover_model.json:
+    per-link masses and centres of mass, bogie pivots, wheel centres) -- no solver involved.  Frictionless statics are determinate:
+    vertical force, pitch and roll about the total centre of mass, and one moment balance per bogie about its pivot axis (the
+    subtree's weight at ITS centre of mass against the two wheels' loads).  Order FL, FR, CL, CR, RL, RR."""
+    import json
+    import os
+    m = json.load(open(os.path.join(golden_dir, "rover_model.json")))
+    g = 9.81
+    links = m["links"]
+    mass = sum(l["mass"] for l in links.values())
+    com = sum(l["mass"] * np.array(l["com"]) for l in links.values()) / mass
+    names = ["FL", "FR", "CL", "CR", "RL", "RR"]
+    wc = np.array([m["wheel_centres"][k] for k in names])
+    A, b = [], []
+    A.append(np.ones(6)); b.append(mass * g)                                    # vertical force
+    A.append(wc[:, 0] - com[0]); b.append(0.0)                                  # pitch about the centre of mass
+    A.append(wc[:, 1] - com[1]); b.append(0.0)                                  # roll
+    for bogie, sub in m["subtrees"].items():
+        piv, ax = np.array(m["bogies"][bogie]["pivot"]), np.array(m["bogies"][bogie]["axis"])
+        ms = sum(links[l]["mass"] for l in sub["links"])
+        cs = sum(links[l]["mass"] * np.array(links[l]["com"]) for l in sub["links"]) / ms
+        row = np.zeros(6)
+        for i, k in enumerate(names):
+            if m["wheel_bogie"][k] == bogie:
+                row[i] = np.dot(ax, np.cross(wc[i] - piv, [0.0, 0.0, 1.0]))     # moment of a unit load at the wheel about the axis
+        A.append(row); b.append(np.dot(ax, np.cross(cs - piv, [0.0, 0.0, ms * g])))
+    return np.linalg.solve(np.array(A), np.array(b)), mass
+
+
+def test_static_rest_height_and_load_sharing(oracle, golden_dir):
+    """The static wheel-load split is what the reference asset's link table says: 23 of the 25 kg sit in the
+    three bogie subtrees, the front ones' centres of mass ahead of their pivots -- the front wheels carry MORE than the centre
+    wheels (centre : front = 0.74 : 1).  Rounds 1-4 lumped the mass at the chassis (cfg.mass_model = 0: 1.96 : 1 by lever arms alone)."""
     ro = oracle
-    cfg, t = ro.default_config(), oracle_terrain(ro, flat(), 2)
+    expect, mass = link_table_wheel_loads(golden_dir)
+    assert abs(mass - 25.0) < 1e-9 and 0.70 < expect[2] / expect[0] < 0.78
+    t = oracle_terrain(ro, flat(), 2)
+    # frictionless: the normal loads are statically determinate -> the solver must land on the link table's figures
+    S = settle(ro, ro.default_config(friction_mu=0.0), t, fresh(ro), 300)
+    lam = S[0, ro.LAMBDA_N:ro.LAMBDA_N + 6] / H
+    assert np.abs(lam - expect).max() < 0.25, (lam, expect)                      # N, of 30 .. 45 N per wheel
+    assert abs(lam[2] / lam[0] - expect[2] / expect[0]) < 0.005
+    # the lumped model of rounds 1-4, for the record: the lever arms of a massless bogie
+    S0 = settle(ro, ro.default_config(friction_mu=0.0, mass_model=0), t, fresh(ro), 300)
+    lam0 = S0[0, ro.LAMBDA_N:ro.LAMBDA_N + 6] / H
+    assert 1.9 < lam0[2] / lam0[0] < 2.0
+    # default configuration (friction 0.75, braked wheels): friction pre-stress between the axles shifts the split a little
+    cfg = ro.default_config()
+    assert cfg.mass_model == 1 and cfg.solver_iterations == 32                   # aau_rover_simple.py:33
     S = settle(ro, cfg, t, fresh(ro))
     # body origin rests 0.26878 m above the contact plane (observations.py:45) => flat-ground height scan == 0
     assert abs(S[0, ro.POS + 2] - 0.26878) < 2e-4
     lam = S[0, ro.LAMBDA_N:ro.LAMBDA_N + 6] / H
     assert abs(lam.sum() - 25.0 * 9.81) < 0.5                                 # wheels carry the weight
     assert abs(lam[0] - lam[1]) < 1.0 and abs(lam[2] - lam[3]) < 1.0 and abs(lam[4] - lam[5]) < 1.0   # left/right symmetric
-    # front bogie: pivot at x = 0.1535 between the front (0.44) and centre (0.007) wheels => centre ~ 2x front
-    assert 1.7 < lam[2] / lam[0] < 2.3
+    assert abs(lam[2] / lam[0] - expect[2] / expect[0]) < 0.12
     assert np.abs(S[0, ro.BOGIE_Q:ro.BOGIE_Q + 3]).max() < 1e-3 and np.abs(S[0, ro.LINVEL:ro.ANGVEL + 3]).max() < 1e-3
     scan = ro.height_scan(cfg, t, S)
     assert np.abs(scan).max() < 3e-4
@@ -127,12 +173,15 @@ def test_energy_does_not_grow_on_flat_ground(oracle):
     S[0, ro.ANGVEL + 2] = 0.4
     S[0, ro.WHEEL_QD:ro.WHEEL_QD + 6] = 0.0
     z4, z6 = np.zeros((1, 4), np.float32), np.zeros((1, 6), np.float32)
+    ke0 = 0.5 * 25 * (0.5 ** 2 + 0.2 ** 2) + 0.5 * 6.15 * 0.4 ** 2      # 4.1 J
     ke_prev = np.inf
     for _ in range(30):
         ro.physics_step(cfg, t, S, z4, z6, 3)
         v, w = S[0, ro.LINVEL:ro.LINVEL + 3], S[0, ro.ANGVEL:ro.ANGVEL + 3]
         ke = 0.5 * 25 * (v @ v) + 0.5 * 6.15 * w[2] ** 2
-        assert ke <= ke_prev + 1e-4
+        # braking pitches the weighted bogies by ~0.8 deg (cfg.mass_model = 1); what they give back while they settle is the
+        # only rebound: < 0.05 % of the initial kinetic energy
+        assert ke <= ke_prev + 5e-4 * ke0
         ke_prev = ke
     assert ke_prev < 1e-3                                              # braked wheels stop the rover
 

@@ -35,6 +35,9 @@ def test_reference_train_script_runs_to_completion(clean_modules, golden_dir):
     # the trainer loop: one reset, `steps` steps, close (train.py:143)
     assert env.calls == ["reset"] + ["step"] * steps + ["close"]
     assert env.ctor_kwargs == {"headless": True, "viewport": False}            # train.py:123 gym.make(..., headless=, viewport=)
+    # the cfg train.py built (parse_env_cfg -> the reference's AAURoverEnvCfg) reaches the env through compat.convert: that path
+    # serves THIS trainer, whose loop .item()s every log entry after every step (skrl_utils.py:139-142) -> host mirror by default
+    assert env.cfg.log_values == "host"
     # the reference's factories built ITS networks on the env's surface (train.py:131-139, get_models.py:39)
     assert type(agent.policy).__name__ == "GaussianNeuralNetwork" and type(agent.value).__name__ == "DeterministicNeuralNetwork"
     assert agent.policy.dense_encoder.encoder_layers[0].in_features == 961 and agent.policy.mlp[0].in_features == 64

@@ -129,6 +129,21 @@ def main():
             ib += m * np.dot(d_perp, d_perp) + float(ax @ box_inertia(m, ext) @ ax)
         bogies[b] = {"pivot": piv.round(6).tolist(), "axis": ax.tolist(), "inertia": round(ib, 6)}
 
+    # the three bogie SUBTREES (beam + steer links + wheels) at q = 0: mass, centre of mass, box-model inertia about that centre --
+    # what cfg.mass_model = 1 needs (the subtree's weight as a generalised force on its bogie coordinate) and the static
+    # wheel-load check of tests/test_oracle_physics.py derives its expectation from
+    subtrees = {}
+    for b, links in SUBTREE.items():
+        mb = sum(LINKS[l][0] for l in links)
+        cb = sum(LINKS[l][0] * coms[l] for l in links) / mb
+        ib = np.zeros((3, 3))
+        for l in links:
+            m, _, ext = LINKS[l]
+            d = coms[l] - cb
+            ib += box_inertia(m, ext) + m * (np.dot(d, d) * np.eye(3) - np.outer(d, d))
+        subtrees[b] = {"mass": mb, "com": cb.round(5).tolist(), "inertia_com_diag": np.diag(ib).round(4).tolist(), "links": links}
+    link_table = {l: {"mass": LINKS[l][0], "com": coms[l].round(6).tolist()} for l in LINKS}
+
     wheels = {k: frames[f"{k}_Drive"][0].round(6).tolist() for k in ["FL", "FR", "CL", "CR", "RL", "RR"]}
     out = {
         "source": "rover_envs/assets/robots/aau_rover_simple/rover_instance.usd via SURVEY.md App. A/E",
@@ -139,6 +154,8 @@ def main():
         "wheel_centres": wheels,
         "wheel_bogie": BOGIE_OF,
         "bogies": bogies,
+        "subtrees": subtrees,
+        "links": link_table,
         "steer_axis": {k: joint_axis[f"{k}_Steer"][1].round(6).tolist() for k in ["FL", "FR", "RL", "RR"]},
         "drive_axis": {k: joint_axis[f"{k}_Drive"][1].round(6).tolist() for k in wheels},
         "link_frames": {k: {"pos": v[0].round(6).tolist(), "quat_wxyz": v[1].round(6).tolist()} for k, v in frames.items()},
@@ -151,7 +168,7 @@ def main():
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps({k: out[k] for k in ["total_mass", "com", "inertia_diag", "inertia_offdiag_xy_xz_yz",
-                                          "wheel_centres", "bogies", "wheel_contact_radius"]}, indent=1))
+                                          "wheel_centres", "bogies", "subtrees", "wheel_contact_radius"]}, indent=1))
 
 
 if __name__ == "__main__":

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Dev tool (GPU box): us per env.step() at N envs for one build of the library (ABLTAG = a tools/build_diag.py variant).
-usage: [ABLTAG=tag] quick_bench.py [n] [steps]"""
+usage: [ABLTAG=tag] [QB_ITERS=n] [QB_MASS=lumped|subtree_weights] quick_bench.py [n] [steps]"""
 import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,6 +15,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 ter = T.make_procedural_terrain((2048, 2048), seed=1234, n_rocks=400); ter.make_spawns(2 * n, seed=41)
 cfg = RoverEnvCfg(); cfg.scene.num_envs = n; cfg.terrain.kind = "custom"
+if os.environ.get("QB_ITERS"): cfg.solver_iterations = int(os.environ["QB_ITERS"])
+if os.environ.get("QB_MASS"): cfg.mass_model = os.environ["QB_MASS"]
 env = RoverEnv(cfg, terrain=ter)
 env.reset()
 g = torch.Generator(device="cuda").manual_seed(0)
@@ -25,4 +27,4 @@ for rep in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for k in range(steps): env.step(acts[k % 256])
     torch.cuda.synchronize(); res.append((time.perf_counter() - t0) / steps * 1e6)
-print(os.environ.get("ABLTAG", "product"), env.kernel_names()[0], "us per step:", " ".join(f"{r:.2f}" for r in res), f"-> {n / min(res):.1f} M env-steps/s")
+print(os.environ.get("ABLTAG", "product"), f"iters={cfg.solver_iterations} mass={cfg.mass_model}", env.kernel_names()[0], "us per step:", " ".join(f"{r:.2f}" for r in res), f"-> {n / min(res):.1f} M env-steps/s")
