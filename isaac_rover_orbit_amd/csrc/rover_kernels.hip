@@ -519,12 +519,22 @@ __device__ __forceinline__ ArmConsts make_arm(const float *wb, const float *P, c
 // gravity force on the bogie coordinate Q_j = -m_j g z . R (ax x arm_j), arm_j = c_j - P rotated by the bogie angle, with
 // ax x arm = (ax (ax . d0) - d0) sin q + (ax x d0) cos q for d0 = c_j(q = 0) - P.  `sub` = make_arm(c_j(0), P, ax); gq = K.bogie_gq[j].
 // Returns the bogie rate after the gravity impulse of one substep (oracle/rover_oracle.c physics_substep, same operations).
-__device__ __forceinline__ float bogie_gravity(const ArmConsts &sub, const float *ax, const float R[3][3], float sb, float cb, float gq,
-                                               float bd)
+struct SubConsts {
+    float e1[3], e2[3];   // ax (ax . d0) - d0 and ax x d0: the coefficients of sin q and cos q in ax x arm
+};
+__device__ __forceinline__ SubConsts make_sub(const float *cj, const float *P, const float *ax)
+{
+    const ArmConsts a = make_arm(cj, P, ax);
+    SubConsts s;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { s.e1[i] = fmaf(ax[i], a.ad, -a.d0[i]); s.e2[i] = a.axd[i]; }
+    return s;
+}
+__device__ __forceinline__ float bogie_gravity(const SubConsts &sub, const float R[3][3], float sb, float cb, float gq, float bd)
 {
     float vb[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) vb[i] = fmaf(fmaf(ax[i], sub.ad, -sub.d0[i]), sb, sub.axd[i] * cb);
+    for (int i = 0; i < 3; ++i) vb[i] = fmaf(sub.e1[i], sb, sub.e2[i] * cb);
     const float vwz = fmaf(R[2][2], vb[2], fmaf(R[2][1], vb[1], R[2][0] * vb[0]));
     return fmaf(gq, vwz, bd);
 }
@@ -887,7 +897,7 @@ __device__ __forceinline__ void physics_substep(const RvParams &p, const StepCon
             const float cj[3] = {SUBTREE_COM[j][0], SUBTREE_COM[j][1], SUBTREE_COM[j][2]};
             float sb, cb;
             bogie_sincos(bq[j], &sb, &cb);
-            bd[j] = bogie_gravity(make_arm(cj, P, ax), ax, R, sb, cb, K.bogie_gq[j], bd[j]);
+            bd[j] = bogie_gravity(make_sub(cj, P, ax), R, sb, cb, K.bogie_gq[j], bd[j]);
         }
     }
     // ---- 3. contact geometry (slot order), warm start
@@ -1016,7 +1026,7 @@ struct GroupLane {
     // constants of this lane's slot
     float P[3], ax[3], b_winv, bogie_keep;
     float bogie_gq;   // K.bogie_gq of the lane's bogie (cfg.mass_model = 1)
-    ArmConsts sub;    // arm of the bogie subtree's centre of mass about the pivot (cfg.mass_model = 1)
+    SubConsts sub;    // arm of the bogie subtree's centre of mass about the pivot (cfg.mass_model = 1)
     float lp[3];   // this lane's link-body sample point
     ArmConsts arm;
     f2 minv0, minv1;  // inverse mass pairs of the lane's two channels (negated in idle slot 7, see physics_substep_group)
@@ -1207,7 +1217,7 @@ __device__ __forceinline__ void physics_substep_group(const RvParams &p, const S
     if (p.cfg.mass_model == 1) {   // the subtree's weight on the bogie coordinate (wave-uniform branch)
         float sb, cb;
         bogie_sincos(bq, &sb, &cb);
-        bd = bogie_gravity(g.sub, g.ax, R, sb, cb, g.bogie_gq, bd);
+        bd = bogie_gravity(g.sub, R, sb, cb, g.bogie_gq, bd);
     }
     const bool at_hi = bq >= RV_BOGIE_QLIM - 1.0e-5f, at_lo = bq <= -RV_BOGIE_QLIM + 1.0e-5f;
     Contact ct;
@@ -1736,7 +1746,7 @@ __device__ __forceinline__ void group_load(const float *__restrict__ state, int 
 #pragma unroll
         for (int j = 1; j < 3; ++j) gq = (id.j == j) ? K.bogie_gq[j] : gq;
         g.bogie_gq = gq;
-        g.sub = make_arm(sc.sc, sc.P, sc.ax);
+        g.sub = make_sub(sc.sc, sc.P, sc.ax);
     }
     g.steerable = id.si >= 0;
     g.wheel_active = id.wheel_active;
@@ -1960,6 +1970,23 @@ __device__ __forceinline__ void lds_cell4_issue(unsigned row0, unsigned row1, in
                  "ds_read_i16 %3, %5 offset:2"
                  : "=&v"(h00), "=&v"(h01), "=&v"(h10), "=&v"(h11) : "v"(row0), "v"(row1));
 }
+// The TRIANGLE surface needs three of the four corners: 00, 11 and ONE of 01 / 10 -- fx >= fy (lower triangle) picks 01, and is known
+// before the reads are issued: the select moves from the value to the ADDRESS (`mid` = lower ? a0 : a0 + 2 pitch - 2, read at offset 2;
+// `r1m` = a0 + 2 pitch - 2, corner 11 at offset 4): three LDS instructions per ray instead of four, the same three operands into the
+// same arithmetic.  (The conflict cycles of a 64-lane 16-bit read are a property of the instruction, DESIGN.md: the lever is the COUNT.)
+__device__ __forceinline__ void lds_cell3_issue(unsigned a0, unsigned mid, unsigned r1m, int &h00, int &hm, int &h11)
+{
+    asm volatile("ds_read_i16 %0, %3\n\t"
+                 "ds_read_i16 %1, %4 offset:2\n\t"
+                 "ds_read_i16 %2, %5 offset:4"
+                 : "=&v"(h00), "=&v"(hm), "=&v"(h11) : "v"(a0), "v"(mid), "v"(r1m));
+}
+template <int CNT>
+__device__ __forceinline__ void lds_cell3_wait(int (&h00)[4], int (&hm)[4], int (&h11)[4])
+{
+    asm volatile("s_waitcnt lgkmcnt(%12)" : "+v"(h00[0]), "+v"(hm[0]), "+v"(h11[0]), "+v"(h00[1]), "+v"(hm[1]), "+v"(h11[1]),
+                 "+v"(h00[2]), "+v"(hm[2]), "+v"(h11[2]), "+v"(h00[3]), "+v"(hm[3]), "+v"(h11[3]) : "n"(CNT));
+}
 template <int CNT>
 __device__ __forceinline__ void lds_cell_wait(int (&h00)[4], int (&h01)[4], int (&h10)[4], int (&h11)[4])
 {
@@ -2059,7 +2086,8 @@ __device__ __forceinline__ void private_cast(const RvParams &p, const PrivateWin
         float nqs = -p.q_scale, pz = w.pz[j], hoff = p.cfg.scan_height_offset;
         asm volatile("" : "+v"(nqs), "+v"(pz), "+v"(hoff));
         float fx[2][G], fy[2][G];
-        int h00[2][G], h01[2][G], h10[2][G], h11[2][G];
+        int h00[2][G], h01[2][G], h10[2][G], h11[2][G];   // TRI: h01 holds the ONE middle corner (01 or 10), h10 is unused
+        const unsigned row1m = 2u * (unsigned)pitch - 2u;   // byte distance from cell (i, j) to cell (i + 1, j) minus one cell
         constexpr int NG = (M1 - M0 + G - 1) / G;
 #pragma unroll
         for (int g = 0; g <= NG; ++g) {
@@ -2080,13 +2108,19 @@ __device__ __forceinline__ void private_cast(const RvParams &p, const PrivateWin
                               fx[b][q] = t1[q].x; fy[b][q] = t1[q].y;)
                 RV_CAST_STAGE(a0[q] = __umul24((int)t0[q].y, pitch) + (unsigned)(int)t0[q].x;)
                 RV_CAST_STAGE(a0[q] = (a0[q] << 1) + base;)
+                unsigned r1m[G], mid[G];
+                if (TRI) {
+                    RV_CAST_STAGE(r1m[q] = a0[q] + row1m;)
+                    RV_CAST_STAGE(mid[q] = fx[b][q] >= fy[b][q] ? a0[q] : r1m[q];)
+                }
 #undef RV_CAST_STAGE
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < G; ++q) {
                     const int m = M0 + g * G + q;
                     if (m < M1) {
-                        lds_cell4_issue(a0[q], a0[q] + 2u * (unsigned)pitch, h00[b][q], h01[b][q], h10[b][q], h11[b][q]);
+                        if (TRI) lds_cell3_issue(a0[q], mid[q], r1m[q], h00[b][q], h01[b][q], h11[b][q]);
+                        else lds_cell4_issue(a0[q], a0[q] + 2u * (unsigned)pitch, h00[b][q], h01[b][q], h10[b][q], h11[b][q]);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -2096,8 +2130,14 @@ __device__ __forceinline__ void private_cast(const RvParams &p, const PrivateWin
                 float ov[G];
                 // the previous group's sixteen reads have returned when at most the fifteen youngest LDS operations are outstanding
                 // (LDS returns in order; the group issued just above is sixteen operations); after the last group: all of them
-                if (g < NG) lds_cell_wait<15>(h00[pb], h01[pb], h10[pb], h11[pb]);
-                else lds_cell_wait<0>(h00[pb], h01[pb], h10[pb], h11[pb]);
+                // (triangle surface: three reads per ray, the group above is twelve operations)
+                if (TRI) {
+                    if (g < NG) lds_cell3_wait<12>(h00[pb], h01[pb], h11[pb]);
+                    else lds_cell3_wait<0>(h00[pb], h01[pb], h11[pb]);
+                } else {
+                    if (g < NG) lds_cell_wait<15>(h00[pb], h01[pb], h10[pb], h11[pb]);
+                    else lds_cell_wait<0>(h00[pb], h01[pb], h10[pb], h11[pb]);
+                }
 #pragma unroll
                 for (int q = 0; q < G; ++q) {
                     const int m = M0 + (g - 1) * G + q;
@@ -2106,7 +2146,7 @@ __device__ __forceinline__ void private_cast(const RvParams &p, const PrivateWin
                         const float f00 = (float)h00[pb][q], f11 = (float)h11[pb][q];
                         if (TRI) {
                             const bool lower = fx[pb][q] >= fy[pb][q];
-                            const float pm = (float)(lower ? h01[pb][q] : h10[pb][q]);
+                            const float pm = (float)h01[pb][q];   // the middle corner the address select fetched: 01 (lower) or 10
                             const float d1 = pm - f00, d2 = f11 - pm;
                             const float ta = lower ? d1 : d2, tb = lower ? d2 : d1;
                             hgt = fmaf(fy[pb][q], tb, fmaf(fx[pb][q], ta, f00));

@@ -14,6 +14,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 ter = T.make_procedural_terrain((2048, 2048)); ter.make_spawns(2 * n)
 cfg = RoverEnvCfg(); cfg.scene.num_envs = n; cfg.terrain.kind = "custom"
+if os.environ.get("QB_ITERS"): cfg.solver_iterations = int(os.environ["QB_ITERS"])      # e.g. the round-4 model: 16 / lumped
+if os.environ.get("QB_MASS"): cfg.mass_model = os.environ["QB_MASS"]
 cfg.roctx_markers = len(sys.argv) > 3 and sys.argv[3] == "markers"     # rocprofv3 --marker-trace: one range per env step
 env = RoverEnv(cfg, terrain=ter)
 if os.environ.get("ROVER_SCAN_FORM"):   # 3 = 8 x 8 ray blocks per wave, 4 = lines (rover_debug_set_scan_form)
@@ -31,6 +33,7 @@ def run(env):
 run(env)
 if os.environ.get("ROVER_ALSO_TWO_LAUNCH"):   # the same workload on the two-launch path (the traffic of the step kernel alone)
     cfg2 = RoverEnvCfg(); cfg2.scene.num_envs = n; cfg2.terrain.kind = "custom"; cfg2.log_reduction = "every_step"
+    cfg2.solver_iterations, cfg2.mass_model = cfg.solver_iterations, cfg.mass_model
     env2 = RoverEnv(cfg2, terrain=ter)
     import ctypes as C
     ff = C.CDLL(env2._lib._name).rover_debug_set_fused; ff.argtypes = [C.c_void_p, C.c_int]
