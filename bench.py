@@ -17,7 +17,8 @@ collective).  Rank 0 prints ONE JSON line.  Extra legs (not in the timed region)
                      actually bounds the kernel (VALU issue of one to two waves per SIMD), from the committed PMC summary
   * cpu_baseline  -- the CPU oracle ("port") timed on a bounded sample of the same workload (N=1 only)
   * extra         -- (N=1, config 2, unless --no-extra) short runs of BASELINE configs 4 and 5, of the rollout loop with both
-                     networks and the trainer's per-step log read, and of the step at the reference's configured 32 solver iterations
+                     networks and the trainer's per-step log read, of the env alone with the log reduced behind EVERY step, and of the
+                     step at rounds 1-4's settings (16 solver iterations; 16 iterations + lumped mass)
   * ranks / rollout_gather (N>1) -- which devices the ranks ran on; one RCCL all_gather of a 60-step rollout shard, plain and
                      overlapped with the next rollout on a side stream (BASELINE config 3)
 """
@@ -49,6 +50,17 @@ def algorithmic_bytes(rays: int):
 def _load_json(name):
     try:
         return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return None
+
+
+def library_digest():
+    """sha256[:16] of the librover_hip.so this process loaded -- what tools/pmc_issue.py / tools/pmc_traffic.py record beside the
+    counters they collect (`_lib_sha256`): a committed counter summary is printed as measured only for the build it was measured on."""
+    import hashlib
+    from isaac_rover_orbit_amd import _lib
+    try:
+        return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]
     except Exception:
         return None
 
@@ -133,26 +145,17 @@ def lift_line(num_envs, steps, warmup, profile_steps, cpu_seconds):
 
 
 # ------------------------------------------------------------------------------------------------ rover legs
-def make_rover(dev, n, config, shard=None, solver_iterations=None, no_forces=False, terrain_cache=None, stream_obs=False):
-    """SURVEY 8d config 2 (procedural 2048^2 heightfield @ 0.05 m, fBm sigma_z 0.15 m seed 1234, ~400 rocks) or config 4
-    (same map generator at sigma_z 0.4 m, 32 x 32 rays at 0.05 m spacing)."""
-    from isaac_rover_orbit_amd import terrain as T
+def shard_cfg(n, shard, config, dev="cuda:0", solver_iterations=None, no_forces=False, stream_obs=False, mass_model=None,
+              log_reduction=None):
+    """The env cfg of one rank and the size of the spawn table it needs: 2 x the GLOBAL env count (terrain_utils.py:123-124), so that
+    the per-call spawn permutation is a bijection of all global env ids (no GPU needed: tests/test_distributed.py runs it for
+    eight ranks)."""
     from isaac_rover_orbit_amd.cfg import RoverEnvCfg
-    from isaac_rover_orbit_amd.envs import RoverEnv
-    sigma_z = 0.15 if config == 2 else 0.4
-    n_global = shard.global_num_envs if shard else n
-    key = (sigma_z, n_global)
-    if terrain_cache is not None and key in terrain_cache:
-        ter = terrain_cache[key]
-    else:
-        ter = T.make_procedural_terrain((2048, 2048), seed=1234, sigma_z=sigma_z, n_rocks=400)
-        ter.make_spawns(2 * n_global, seed=41)
-        if terrain_cache is not None:
-            terrain_cache[key] = ter
     cfg = RoverEnvCfg()
     cfg.scene.num_envs = n
     cfg.sim.device = str(dev)
     cfg.terrain.kind = "custom"
+    n_global = shard.global_num_envs if shard else n
     if shard:
         cfg.env_id_offset = shard.env_id_offset
         cfg.global_num_envs = shard.global_num_envs
@@ -160,15 +163,37 @@ def make_rover(dev, n, config, shard=None, solver_iterations=None, no_forces=Fal
     cfg.stream_observations = bool(stream_obs)
     if solver_iterations is not None:
         cfg.solver_iterations = int(solver_iterations)
+    if mass_model is not None:
+        cfg.mass_model = mass_model
+    if log_reduction is not None:
+        cfg.log_reduction = log_reduction
     if config == 4:
         cfg.height_scanner.resolution, cfg.height_scanner.size = 0.05, (1.55, 1.55)
+    return cfg, 2 * n_global
+
+
+def make_rover(dev, n, config, shard=None, terrain_cache=None, **cfg_kw):
+    """SURVEY 8d config 2 (procedural 2048^2 heightfield @ 0.05 m, fBm sigma_z 0.15 m seed 1234, ~400 rocks) or config 4
+    (same map generator at sigma_z 0.4 m, 32 x 32 rays at 0.05 m spacing)."""
+    from isaac_rover_orbit_amd import terrain as T
+    from isaac_rover_orbit_amd.envs import RoverEnv
+    sigma_z = 0.15 if config == 2 else 0.4
+    cfg, n_spawns = shard_cfg(n, shard, config, dev=dev, **cfg_kw)
+    key = (sigma_z, n_spawns)
+    if terrain_cache is not None and key in terrain_cache:
+        ter = terrain_cache[key]
+    else:
+        ter = T.make_procedural_terrain((2048, 2048), seed=1234, sigma_z=sigma_z, n_rocks=400)
+        ter.make_spawns(n_spawns, seed=41)
+        if terrain_cache is not None:
+            terrain_cache[key] = ter
     return RoverEnv(cfg, terrain=ter), ter, cfg, sigma_z
 
 
-def short_rover_run(dev, config, steps=300, warmup=360, solver_iterations=None, terrain_cache=None, stream_obs=False):
-    """One short run of a rover configuration (an ``extra`` leg): value, ms_per_step, kernel name."""
+def short_rover_run(dev, config, steps=300, warmup=360, terrain_cache=None, **cfg_kw):
+    """One short run of a rover configuration (an ``extra`` leg): value, ms_per_step, kernel name(s)."""
     import torch
-    env, _, cfg, _ = make_rover(dev, 4096, config, solver_iterations=solver_iterations, terrain_cache=terrain_cache, stream_obs=stream_obs)
+    env, _, cfg, _ = make_rover(dev, 4096, config, terrain_cache=terrain_cache, **cfg_kw)
     g = torch.Generator(device=dev).manual_seed(0)
     acts = torch.rand(128, 4096, 2, device=dev, generator=g) * 2 - 1
     env.reset()
@@ -182,7 +207,8 @@ def short_rover_run(dev, config, steps=300, warmup=360, solver_iterations=None, 
     dt = (time.perf_counter() - t0) / steps
     scan_b, dyn_b = algorithmic_bytes(env.num_rays)
     out = {"value": 4096 / dt, "unit": "env-steps/s", "ms_per_step": dt * 1e3, "steps": steps, "warmup": warmup, "num_envs": 4096,
-           "rays": env.num_rays, "solver_iterations": cfg.solver_iterations, "kernel": env.kernel_names()[0],
+           "rays": env.num_rays, "solver_iterations": cfg.solver_iterations, "mass_model": cfg.mass_model,
+           "log_reduction": cfg.log_reduction, "kernel": env.kernel_names()[0], "second_kernel": env.kernel_names()[1],
            "whole_step_frac": (scan_b + dyn_b) * 4096 / dt / 1e9 / HBM_PEAK_GBS}
     env.close()
     return out
@@ -285,14 +311,17 @@ def rollout_loop_leg(env, dev, steps, profile_steps, ev_ms):
                      "rover_policy_ref_pair_kernel_us_events": t_pair / reps * 1e3 - ev_ms * 1e3},
             "pair_with_device_log": {"ms_per_step": dt_flush * 1e3, "env_steps_per_s": n / dt_flush,
                                      "note": "pair + env.step + rover_flush_log behind every step (the log vector stays on the device)"},
-            "trainer_loop": {"ms_per_step": dt_trainer * 1e3, "env_steps_per_s": n / dt_trainer, "steps": t_steps,
+            "trainer_loop": {"ms_per_step": dt_trainer_h * 1e3, "env_steps_per_s": n / dt_trainer_h, "steps": t_steps,
+                             "log_values": "host",
                              "note": "pair + env.step + .item() on every entry of infos['episode'] after every step, as "
-                                     "skrl_utils.py:139-142 does: the log reduction launches behind every step and the host "
-                                     "synchronises once per entry (13 per step)", "checksum": tracked},
-            "trainer_loop_host_log": {"ms_per_step": dt_trainer_h * 1e3, "env_steps_per_s": n / dt_trainer_h, "steps": t_steps,
-                                      "note": "the same loop with cfg.log_values = 'host' (extras['log'] entries = views of a pinned "
-                                              "host mirror: one copy + one synchronisation per step, .item() is then free)",
-                                      "checksum": tracked_h},
+                                     "skrl_utils.py:139-142 does, with cfg.log_values = 'host' -- what compat.convert gives the "
+                                     "reference's own trainer (the gym-redirect path): the entries are views of a pinned host mirror, "
+                                     "ONE copy + ONE synchronisation per step, .item() is then free", "checksum": tracked_h},
+            "trainer_loop_device_log": {"ms_per_step": dt_trainer * 1e3, "env_steps_per_s": n / dt_trainer, "steps": t_steps,
+                                        "log_values": "device",
+                                        "note": "the same loop on ORBIT-style 0-d DEVICE tensors (the native RoverEnvCfg default): the log "
+                                                "reduction launches behind every step and the host synchronises once per entry (13 per step)",
+                                        "checksum": tracked},
             "observations_finite": bool(torch.isfinite(obs).all()),
             "actor_TFLOPs_f32": flops / ((t_act / reps - ev_ms) * 1e-3) / 1e12, "f32_mfma_peak_TFLOPs": 157.0,
             "note": "closed loop: the actor's mean action drives the env (observations with -inf rays are what the kernel reads; "
@@ -311,7 +340,7 @@ def main():
     ap.add_argument("--preroll", type=int, default=400,
                     help="untimed env steps BEFORE the warm-up steps: the rollout reaches its steady state (episodes of mixed age, resets "
                          "in every step) and the GPU its sustained clock -- the first ~150 steps after an idle device run ~5 %% slower")
-    ap.add_argument("--no-extra", action="store_true", help="skip the `extra` block (configs 4 / 5, rollout loop, 32 solver iterations)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the `extra` block (configs 4 / 5, rollout loop, log every step, 16 iterations)")
     ap.add_argument("--no-forces", action="store_true", help="do not materialise contact_sensor.force_matrix_w")
     ap.add_argument("--with-policy", action="store_true",
                     help="top-level `with_policy` leg (outside `value`): the rollout loop a trainer runs -- actor + critic forward "
@@ -411,11 +440,22 @@ def main():
         }
         basis = "HIP events minus the empty event pair"
     dom = max(kernels, key=lambda k: kernels[k]["ms"])
+    # committed PMC summaries (profiles/hbm_traffic.json, profiles/issue_counters.json) belong to ONE build and ONE configuration:
+    # they are printed as this run's figures only when the loaded library's digest and the solver / mass settings are the ones they
+    # were collected with; otherwise the line says so instead of showing another build's counters beside a fresh ms_per_step
+    digest = library_digest()
+
+    def current(summary):
+        return (summary is not None and summary.get("_lib_sha256") == digest and
+                summary.get("_solver_iterations") == cfg.solver_iterations and summary.get("_mass_model") == cfg.mass_model)
     traffic = traffic_build = None
     tr = _load_json("hbm_traffic.json") if (args.config == 2 and n == 4096) else None
-    if tr:
+    traffic_stale = tr is not None and not current(tr)
+    if tr and not traffic_stale:
         traffic = tr.get(dom, {}).get("bytes_per_launch")
         traffic_build = tr.get("_build")
+    elif tr:
+        traffic_build = {"stale": True, "counters_of_build": tr.get("_lib_sha256"), "this_build": digest, "note": tr.get("_build")}
     roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": kernels[dom]["GB/s"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_build": traffic_build,
                 "duration_basis": basis, "event_pair_overhead_ms": ev_ms,
@@ -424,7 +464,9 @@ def main():
     # what bounds the kernel: at ~12 % of the HBM roofline the honest bound is instruction issue -- one step wave (+ one copy wave)
     # per SIMD, a wave64 VALU instruction occupies the SIMD's 16 lanes for 4 cycles.  From the committed PMC summary of this build.
     ic = _load_json("issue_counters.json") if (args.config == 2 and n == 4096) else None
-    if ic and dom in ic:
+    if ic and not current(ic):
+        roofline["issue"] = {"stale": True, "counters_of_build": ic.get("_lib_sha256"), "this_build": digest, "build": ic.get("_build")}
+    elif ic and dom in ic:
         c = ic[dom]
         simds = float(c.get("simds", 1024))
         wave_cycles = 4.0 * c["SQ_WAVE_CYCLES"] / c["SQ_WAVES"]
@@ -435,7 +477,8 @@ def main():
                              "valu_busy_frac": 4.0 * c["SQ_ACTIVE_INST_VALU"] / (simds * wave_cycles),
                              "waves_per_simd": c["SQ_WAVES"] / simds,
                              "bound": "valu issue (4 cycles per wave64 instruction per SIMD)", "build": ic.get("_build"),
-                             "source": "profiles/issue_counters.json (rocprofv3 --pmc, tools/r04_counters.sh)"}
+                             "lib_sha256": ic.get("_lib_sha256"),
+                             "source": "profiles/issue_counters.json (rocprofv3 --pmc, tools/r05_measure.sh)"}
 
     out = {
         "metric": "env-steps/sec AAURoverEnv-v0 @ num_envs=4096; 1/2/4/8 MI355X", "value": value, "unit": "env-steps/s",
@@ -449,6 +492,7 @@ def main():
                    "baseline_config": args.config,
                    "num_envs_per_gpu": n, "global_num_envs": shard.global_num_envs, "rays": env.num_rays,
                    "decimation": cfg.decimation, "sim_dt": cfg.sim.dt, "solver_iterations": cfg.solver_iterations,
+                   "mass_model": cfg.mass_model, "lib_sha256": digest,
                    "contact_forces_materialised": cfg.record_contact_forces, "parallelism": f"env-shard x{world}",
                    "scan_surface": env.cfg.height_scanner.surface, "spawn_draw": env.cfg.spawn_draw,
                    "log_reduction": getattr(cfg, "log_reduction", "on_demand"), "preroll_steps": args.preroll,
@@ -587,7 +631,9 @@ def main():
         env = None
         for key, fn in (("config4", lambda: short_rover_run(dev, 4, terrain_cache=terrain_cache)),
                         ("stream_observations", lambda: short_rover_run(dev, 2, terrain_cache=terrain_cache, stream_obs=True)),
-                        ("solver_iterations_32", lambda: short_rover_run(dev, 2, solver_iterations=32, terrain_cache=terrain_cache)),
+                        ("log_every_step", lambda: short_rover_run(dev, 2, terrain_cache=terrain_cache, log_reduction="every_step")),
+                        ("solver_iterations_16", lambda: short_rover_run(dev, 2, solver_iterations=16, terrain_cache=terrain_cache)),
+                        ("round4_model", lambda: short_rover_run(dev, 2, solver_iterations=16, mass_model="lumped", terrain_cache=terrain_cache)),
                         ("config5", lambda: {k: v for k, v in lift_line(2048, 300, 360, 40, 0.0).items()
                                              if k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "roofline")})):
             try:
@@ -598,9 +644,18 @@ def main():
             extra["stream_observations"]["note"] = ("config 2 with cfg.stream_observations = True (non-temporal stores of the observation rows): faster "
                                                     "when nothing on the device reads the rows next, as in this random-action rollout; the headline "
                                                     "keeps the default (plain stores: the policy kernel behind a step finds the rows in L2)")
-        if isinstance(extra.get("solver_iterations_32"), dict) and "ms_per_step" in extra["solver_iterations_32"]:
-            extra["solver_iterations_32"]["note"] = ("the reference configures 32 position iterations (aau_rover_simple.py:33); the "
-                                                     "headline runs cfg.solver_iterations = 16 (DESIGN.md section 4)")
+        if isinstance(extra.get("log_every_step"), dict) and "ms_per_step" in extra["log_every_step"]:
+            extra["log_every_step"]["note"] = ("the env ALONE (random actions, no policy) with cfg.log_reduction = 'every_step': the one-launch step kernel "
+                                               "followed by rover_log_kernel behind EVERY step -- the reference rebuilds extras['log'] inside _reset_idx in "
+                                               "every step that resets (rover_env.py:36-39; ~4 envs per step at 4096 envs).  The difference to `value` "
+                                               "is one dependent dispatch (~2.3 us boundary, profiles/r03_boundary_ubench.txt) + the reduction kernel")
+            extra["log_every_step"]["delta_ms_vs_value"] = extra["log_every_step"]["ms_per_step"] - ms_per_step
+        if isinstance(extra.get("solver_iterations_16"), dict) and "ms_per_step" in extra["solver_iterations_16"]:
+            extra["solver_iterations_16"]["note"] = ("the headline runs the reference's 32 position iterations (aau_rover_simple.py:33); rounds 1-4 "
+                                                     "ran 16: this line is that setting on this round's mass model")
+        if isinstance(extra.get("round4_model"), dict) and "ms_per_step" in extra["round4_model"]:
+            extra["round4_model"]["note"] = ("16 iterations + cfg.mass_model = 'lumped': the model BENCH_r04's `value` was measured on, on this "
+                                             "round's kernels (like-for-like with 110.2 M driver-timed / 120 M long-run of round 4)")
         out["extra"] = extra
 
     if env is not None:

@@ -15,7 +15,8 @@ HEADERS = [os.path.join(_PKG, "csrc", "rover_model.hpp"), os.path.join(_PKG, "cs
            os.path.join(os.path.dirname(_PKG), "include", "rover_lift.h"),
            os.path.join(os.path.dirname(_PKG), "include", "rover_hip.h"),
            os.path.join(os.path.dirname(_PKG), "include", "rover_terrain.h"),
-           os.path.join(os.path.dirname(_PKG), "include", "rover_policy.h")]
+           os.path.join(os.path.dirname(_PKG), "include", "rover_policy.h"),
+           os.path.join(os.path.dirname(_PKG), "include", "rover_debug.h")]
 OBJ_DIR = os.path.join(os.path.dirname(_PKG), "build", "obj")
 OUTPUT = os.path.join(_PKG, "librover_hip.so")
 # fp32 parity with the CPU oracle: no contraction, no fast-math (correctly rounded div / sqrt are hipcc defaults)

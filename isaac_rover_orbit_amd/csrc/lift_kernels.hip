@@ -29,6 +29,7 @@
 
 #include "../../include/rover_hip.h"
 #include "../../include/rover_lift.h"
+#include "../../include/rover_debug.h"
 #include "rover_internal.hpp"
 
 namespace {

@@ -706,12 +706,14 @@ __device__ __forceinline__ void pq_store(const v4f &acc, float bv, float *dst, i
         if (4 * akq + j < rows && 16 * tile + arow < N) pd[j * pitch] = activate(acc[j] + bv, ROVER_ACT_LEAKY_RELU, slope);
 }
 __device__ __forceinline__ void ref_pair_network(const rover_policy_desc &da, const rover_policy_desc &db, const PolLaunch &L,
+                                                 unsigned copy_floats_b,
                                                  const float *__restrict__ packed_a, const float *__restrict__ packed_b,
                                                  const float *__restrict__ obs, int n, float *__restrict__ out_a,
                                                  float *__restrict__ out_b, float *lds)
 {
     packed_a += (size_t)(blockIdx.x % (unsigned)L.n_copies) * L.copy_floats;
-    packed_b += (size_t)(blockIdx.x % (unsigned)L.n_copies) * L.copy_floats;
+    packed_b += (size_t)(blockIdx.x % (unsigned)L.n_copies) * copy_floats_b;   // the critic's own replica stride: the padded bias of
+                                                                                // the last layer (N rounded up to 4) may differ from the actor's
     PSTAMP(0);
     constexpr int OBS = 965, PROP = 4, ENC_OFF = 3;
     constexpr int G1 = 61, GW1 = 8, T1 = 5, G2 = 5, G3 = 4, G4 = 16, G5 = 10;
@@ -986,8 +988,9 @@ __global__ __launch_bounds__(POL_THREADS) void rover_policy_ref_pair_kernel(rove
     ref_network<true>(da, La, packed_a, obs, n, out_a, lds);
     ref_network<false>(db, Lb, packed_b, obs, n, out_b, lds);
 #else
-    (void)Lb;                // same carve for both networks (identical shapes up to the last layer's width)
-    ref_pair_network(da, db, La, packed_a, packed_b, obs, n, out_a, out_b, lds);
+    // same LDS carve and the same hidden-layer slope for both networks (identical shapes up to the last layer's width; the host
+    // entry refuses a pair with different slopes); the weight replicas of each network at its own stride
+    ref_pair_network(da, db, La, Lb.copy_floats, packed_a, packed_b, obs, n, out_a, out_b, lds);
 #endif
 }
 
@@ -1141,6 +1144,9 @@ int rover_policy_forward_pair(const rover_policy_desc *da, const float *packed_a
     if (!is_reference_architecture(da) || !is_reference_architecture(db))
         return rover_internal_fail(ROVER_ERR_UNSUPPORTED, "rover_policy_forward_pair: both networks must have the reference architecture "
                                                           "(call rover_policy_forward twice otherwise)");
+    if (da->leaky_slope != db->leaky_slope)   // the pair kernel activates the hidden layers of both networks with one slope
+        return rover_internal_fail(ROVER_ERR_UNSUPPORTED, "rover_policy_forward_pair: the two networks use different leaky-ReLU slopes "
+                                                          "(call rover_policy_forward twice)");
     PolLaunch L[2];
     size_t lds = 0;
     const rover_policy_desc *dd[2] = {da, db};

@@ -35,6 +35,7 @@
 #include <dlfcn.h>
 
 #include "../../include/rover_hip.h"
+#include "../../include/rover_debug.h"
 #include "rover_model.hpp"
 #include "rover_internal.hpp"
 
@@ -191,9 +192,14 @@ __device__ __forceinline__ float rv_atan2f(float y, float x)
     if (ax == 0.0f) {
         a = (ay == 0.0f) ? 0.0f : 1.5707963267948966f;
     } else {
-        float t = ay / ax, y0 = 0.0f;
-        if (t > 2.414213562373095f) { y0 = 1.5707963267948966f; t = -(1.0f / t); }
-        else if (t > 0.4142135623730950f) { y0 = 0.7853981633974483f; t = (t - 1.0f) / (t + 1.0f); }
+        // Cephes' range reduction -- t -> -(1 / t) above tan(3 pi / 8), t -> (t - 1) / (t + 1) above tan(pi / 8) -- as ONE division of
+        // selected operands: (-1) / t == -(1 / t) and t / 1 == t exactly, so this is the oracle's branchy form bit for bit; written
+        // as branches hipcc if-converts it into three IEEE divisions (~10 instructions each) and two selects
+        const float t0 = ay / ax;
+        const bool big = t0 > 2.414213562373095f, mid = t0 > 0.4142135623730950f;
+        const float y0 = big ? 1.5707963267948966f : (mid ? 0.7853981633974483f : 0.0f);
+        const float num = big ? -1.0f : (mid ? t0 - 1.0f : t0), den = big ? t0 : (mid ? t0 + 1.0f : 1.0f);
+        const float t = num / den;
         const float z = t * t;
         a = y0 + ((((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * t + t);
     }
@@ -1900,7 +1906,12 @@ __device__ __forceinline__ void private_issue(const RvParams &p, const PrivateWi
     const int n_full = th / rpi, n_last = th - n_full * rpi;           // whole groups of rpi rows, rows of the last group
     const unsigned dstep = (unsigned)(rpi * tw4) * 16u, vstep = (unsigned)__umul24(rpi, p.wq) * 16u;
     const unsigned lds_end = lds0 + (unsigned)n_full * dstep;
+#ifdef RV_X_SPANFRAC   // TIMING EXPERIMENT ONLY (tools/build_diag.py X_SPAN*): a fixed share of every row's chunks is not copied -- wrong results
+    const bool keep = lc * 100 < tw4 * RV_X_SPANFRAC;
+    const unsigned long long m_full = __builtin_amdgcn_ballot_w64(lr < rpi && keep), m_last = __builtin_amdgcn_ballot_w64(lr < n_last && keep);
+#else
     const unsigned long long m_full = __builtin_amdgcn_ballot_w64(lr < rpi), m_last = __builtin_amdgcn_ballot_w64(lr < n_last);
+#endif
     unsigned long long saved;
     unsigned m0_saved;
     asm volatile(
@@ -2901,11 +2912,24 @@ __device__ __forceinline__ void reduce_log_partials(const RvParams &p, float *ld
     const unsigned latest = *reinterpret_cast<volatile unsigned *>(p.log_counter + 1);
     constexpr int GROUPS = THREADS / 16;
     const int word = tid & 15, grp = tid >> 4;
+    // rows w = grp, grp + GROUPS, ... summed in that order; sixteen rows' loads are issued together (a loop of dependent
+    // load -> add rounds paid one memory latency per row: ~4 us for the 1024 rows of 4096 envs).  A row past the end contributes
+    // +0, which leaves the sum as it is (the sum starts at +0 and can never be -0).
     float acc = 0.0f;
-    for (int w = grp; w < n_waves; w += GROUPS) {
-        const float tag = log_partial[(size_t)w * ROVER_LOG_WORDS + 15];
-        const float v = log_partial[(size_t)w * ROVER_LOG_WORDS + word];
-        acc += __float_as_uint(tag) == latest ? v : 0.0f;
+    constexpr int U = 16;
+    for (int w0 = grp; w0 < n_waves; w0 += GROUPS * U) {
+        unsigned tag[U];
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int w = w0 + u * GROUPS;
+            const bool in = w < n_waves;
+            const size_t row = (size_t)(in ? w : grp) * ROVER_LOG_WORDS;
+            tag[u] = in ? __float_as_uint(log_partial[row + 15]) : 0u;   // tags start at 1: 0 never matches
+            v[u] = log_partial[row + word];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += (tag[u] == latest) ? v[u] : 0.0f;
     }
     lds[grp * 16 + word] = acc;
     __syncthreads();
@@ -3939,10 +3963,19 @@ static int ready(rover_sim *sim)
     if (!sim->state) return fail(ROVER_ERR_STATE, "rover_bind has not been called");
     return ROVER_OK;
 }
+// Between rover_step_begin and rover_step_finish the state holds a step whose reset / command update / observation rows are still
+// owed: anything that advances the call counter, runs physics or resets envs there would reduce log rows under the wrong tag and
+// step un-reset envs -- a caller bug that must not become silent state corruption.
+static int closed(rover_sim *sim, const char *what)
+{
+    if (sim->phase_open) return fail(ROVER_ERR_STATE, "%s between rover_step_begin and rover_step_finish", what);
+    return ROVER_OK;
+}
 
 int rover_reset(rover_sim *sim, float *obs, void *stream)
 {
     if (int rc = ready(sim)) return rc;
+    if (int rc = closed(sim, "rover_reset")) return rc;
     if (!obs) return fail(ROVER_ERR_INVALID, "obs is NULL");
     DeviceGuard guard(sim->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -3959,6 +3992,7 @@ int rover_reset_with_draws(rover_sim *sim, const uint8_t *mask, const int32_t *s
                            const float *theta_u, const float *heading_u, float *obs, void *stream)
 {
     if (int rc = ready(sim)) return rc;
+    if (int rc = closed(sim, "rover_reset_with_draws")) return rc;
     if (!spawn_row || !yaw_u || !theta_u || !heading_u || !obs) return fail(ROVER_ERR_INVALID, "NULL buffer");
     DeviceGuard guard(sim->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -3980,6 +4014,7 @@ int rover_get_counter(const rover_sim *sim, uint64_t *counter)
 int rover_set_counter(rover_sim *sim, uint64_t counter)
 {
     if (!sim) return fail(ROVER_ERR_INVALID, "sim is NULL");
+    if (int rc = closed(sim, "rover_set_counter")) return rc;
     sim->counter = counter;
     return ROVER_OK;
 }
@@ -3996,6 +4031,7 @@ int rover_step(rover_sim *sim, const float *action, float *obs, float *reward, u
                float *force, float *log, void *stream)
 {
     if (int rc = ready(sim)) return rc;
+    if (int rc = closed(sim, "rover_step")) return rc;
     if (!action || !obs || !reward || !terminated || !truncated || !log) return fail(ROVER_ERR_INVALID, "NULL buffer");
     DeviceGuard guard(sim->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -4013,6 +4049,7 @@ int rover_step_begin(rover_sim *sim, const float *action, float *reward, uint8_t
                      void *stream)
 {
     if (int rc = ready(sim)) return rc;
+    if (int rc = closed(sim, "rover_step_begin")) return rc;
     if (!action || !reward || !terminated || !truncated || !force) return fail(ROVER_ERR_INVALID, "NULL buffer (the two-phase step needs the force rows)");
     DeviceGuard guard(sim->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -4105,6 +4142,7 @@ int rover_profile_step(rover_sim *sim, const float *action, float *obs, float *r
 {
     // Same two launches as rover_step, bracketed by HIP events on `stream`; synchronises (profiling only).
     if (int rc = ready(sim)) return rc;
+    if (int rc = closed(sim, "rover_profile_step")) return rc;
     if (!action || !obs || !reward || !terminated || !truncated || !log || !ms_step_kernel || !ms_scan_kernel)
         return fail(ROVER_ERR_INVALID, "NULL buffer");
     DeviceGuard guard(sim->device);

@@ -11,10 +11,13 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
+DEBUG_HEADER = "rover_debug.h"      # test-only / measurement-only hooks: declared, exported, not part of the boundary
+
+
+def declared_symbols(debug=False):
     names = set()
     for hdr in sorted(os.listdir(os.path.join(ROOT, "include"))):
-        if hdr.endswith(".h"):
+        if hdr.endswith(".h") and (hdr == DEBUG_HEADER) == debug:
             src = open(os.path.join(ROOT, "include", hdr)).read()
             src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
             names |= set(re.findall(r"\b(rover_[a-z0-9_]+)\s*\(", src))
@@ -30,6 +33,16 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/*.h but not exported"
     assert sorted(_lib.EXPORTS) == names, "python binding and header disagree on the entry points"
+    # ... and the converse: the library exports NOTHING that no header declares -- the boundary headers plus the
+    # hooks of include/rover_debug.h (marked test-only there)
+    import subprocess
+    debug = declared_symbols(debug=True)
+    assert debug == ["rover_debug_set_fused", "rover_debug_set_scan_form", "rover_lift_debug_set_lanes", "rover_lift_debug_set_pipeline"]
+    for n in debug:
+        assert hasattr(lib, n), f"{n} declared in include/{DEBUG_HEADER} but not exported"
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(l.split()[-1] for l in nm.splitlines() if len(l.split()) == 3 and l.split()[1] in "TW" and l.split()[-1].startswith("rover_"))
+    assert exported == sorted(names + debug), sorted(set(exported) ^ set(names + debug))
     assert lib.rover_config_bytes() == C.sizeof(_lib.RoverConfig)
     assert lib.rover_state_words() == 72
     assert b"gfx950" in lib.rover_version()

@@ -83,3 +83,64 @@ def test_two_rank_gloo_rollout_gather(tmp_path, oracle):
     assert ws.env_id_offset == 5 * 4096 and ws.global_num_envs == 32768
     with pytest.raises(ValueError):
         rd.shard_envs(2, 0, 4)
+
+
+def test_config3_arithmetic_eight_ranks_of_4096(oracle):
+    """BASELINE config 3 (num_envs = 32768 sharded over 8 GPUs) has never met eight devices; its only arithmetic that no other test
+    touches is pinned here on the CPU: `weak_shard(4096, r, 8)`, a spawn table of 2 x 32768 rows
+    (terrain_utils.py:123-124: n_spawns = 2 * num_envs, GLOBAL), and the per-call affine spawn permutation -- every rank derives the
+    same (a, b) from (seed, call counter) without communication, and the rows of the 32768 global env ids are pairwise distinct
+    across ALL ranks, for the reset call and for a later step call."""
+    from isaac_rover_orbit_amd import distributed as rd
+    from helpers import flat
+    ro = oracle
+    world, per_rank = 8, 4096
+    shards = [rd.weak_shard(per_rank, r, world) for r in range(world)]
+    assert [s.env_id_offset for s in shards] == [r * per_rank for r in range(world)]
+    assert all(s.global_num_envs == 32768 and s.local_num_envs == per_rank for s in shards)
+    n_global = shards[0].global_num_envs
+    n_spawns = 2 * n_global
+    # a spawn table whose x coordinate IS the row index: the row an env drew can be read back from its position
+    table = np.stack([np.arange(n_spawns, dtype=np.float32) * 0.001 + 20.0, np.full(n_spawns, 25.0, np.float32),
+                      np.zeros(n_spawns, np.float32)], 1)
+    ter = flat()
+    t = ro.TerrainData(ter.height, ter.obstacle, ter.safe_mask if hasattr(ter, "safe_mask") else ter.safe_rock_mask, ter.resolution,
+                       ter.min_x, ter.min_y, table)
+    for counter in (0, 7):                      # the reset call of a fresh env; some later call
+        rows_all = []
+        for s in shards[::3] + [shards[-1]]:    # ranks 0, 3, 6, 7: a 32768-env oracle reset per rank would only repeat the arithmetic
+            cfg = ro.default_config(seed_lo=11)
+            cfg.counter_lo = counter
+            S = ro.new_state(512)               # the first 512 ids of the rank's range (the bijection is over ids, not over batches)
+            ro.reset_all(cfg, t, S, env_id_offset=s.env_id_offset)
+            rows = np.rint((S[:, 0].astype(np.float64) - 20.0) / 0.001).astype(np.int64)
+            assert rows.min() >= 0 and rows.max() < n_spawns
+            rows_all.append((s.env_id_offset, rows))
+        # the same (a, b) on every rank: row = (a * gid + b) mod n_spawns -- recover (a, b) from rank 0 and predict the others
+        off0, r0 = rows_all[0]
+        b = int(r0[0])                                      # gid 0
+        a = int((r0[1] - r0[0]) % n_spawns)                 # gid 1
+        assert np.gcd(a, n_spawns) == 1                     # a bijection of Z / n_spawns
+        for off, rows in rows_all:
+            gid = off + np.arange(rows.size, dtype=np.int64)
+            assert np.array_equal(rows, (a * gid + b) % n_spawns), (counter, off)
+        # hence distinct over the WHOLE global batch (n_spawns >= global num_envs: gid -> row is injective)
+        all_rows = (a * np.arange(n_global, dtype=np.int64) + b) % n_spawns
+        assert np.unique(all_rows).size == n_global
+    # the product refuses the configuration that would break it: a spawn table shorter than the global batch (checked on the host
+    # in RoverEnv and in rover_set_terrain; here: the rule itself)
+    assert n_spawns >= shards[-1].env_id_offset + per_rank
+
+
+def test_bench_sharding_arguments_for_eight_ranks():
+    """bench.py's rank -> shard -> cfg path with WORLD_SIZE = 8 (no process group, no GPU): ids, global env count and the size of
+    the spawn table it would build."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    from isaac_rover_orbit_amd import distributed as rd
+    for rank in (0, 5, 7):
+        shard = rd.weak_shard(4096, rank, 8)
+        cfg, n_spawns = bench.shard_cfg(4096, shard, config=2)
+        assert cfg.scene.num_envs == 4096 and cfg.env_id_offset == 4096 * rank and cfg.global_num_envs == 32768
+        assert n_spawns == 2 * 32768

@@ -165,6 +165,19 @@ def test_forward_pair_equals_two_forwards():
         a2, v2 = forward_pair(actor, critic, obs)
         assert a2.shape == (n, 2) and v2.shape == (n, 1)
         assert torch.equal(a1, a2) and torch.equal(v1, v2), n
+    # an actor with a wider head (6 outputs: its padded last-layer bias is 8 floats, the critic's 4) and two weight
+    # replicas -- the critic's replica stride is its own, not the actor's
+    wa6, ba6 = random_policy_weights(seed=9, out_dim=6)
+    actor6 = RoverNet(wa6, ba6, n_enc=2, final_act="tanh", n_copies=2)
+    critic2 = RoverNet(wc, bc, n_enc=2, final_act="none", n_copies=2)
+    obs = torch.from_numpy(synthetic_obs(333, seed=5)).cuda()
+    a1, v1 = actor6(obs), critic2(obs)
+    a2, v2 = forward_pair(actor6, critic2, obs)
+    assert a2.shape == (333, 6) and torch.equal(a1, a2) and torch.equal(v1, v2) and torch.equal(v1, critic(obs))
+    # different hidden-layer slopes: refused by the pair entry (ROVER_ERR_UNSUPPORTED), the binding falls back to two launches
+    leaky = RoverNet(wc, bc, n_enc=2, final_act="none", leaky_slope=0.2)
+    s1, s2 = forward_pair(actor, leaky, obs)
+    assert torch.equal(s1, actor(obs)) and torch.equal(s2, leaky(obs)) and not torch.equal(s2, critic(obs))
     # a non-reference architecture takes the two-call path (same results by construction)
     rng = np.random.RandomState(0)
     ws = [rng.uniform(-1, 1, (24, 4)).astype(np.float32) / 2, rng.uniform(-1, 1, (3, 24)).astype(np.float32) / 5]

@@ -295,10 +295,56 @@ def test_observation_noise_clip_scale_follow_orbit_order(terrain):
         e.close()
 
 
+def test_calls_between_the_two_halves_of_a_step_are_refused(terrain):
+    """between rover_step_begin and rover_step_finish the state owes a reset / command update / observation rows:
+    rover_step, rover_profile_step, rover_reset, rover_reset_with_draws, rover_set_counter and a second rover_step_begin answer
+    ROVER_ERR_STATE (2) instead of stepping un-reset envs under a wrong log tag; rover_step_finish closes the phase."""
+    import ctypes as C
+    from isaac_rover_orbit_amd import _lib
+    n = 256
+    env = _make(n, terrain)
+    env.reset()
+    lib, h = env._lib, env._h
+    vp = C.c_void_p
+    a = torch.zeros(n, 2, device=env.device)
+    obs = torch.zeros(n, env.obs_dim, device=env.device)
+    rew = torch.zeros(n, device=env.device)
+    flags = torch.zeros(2, n, dtype=torch.uint8, device=env.device)
+    force = torch.zeros(39, n, device=env.device)
+    log = torch.zeros(16, device=env.device)
+    ms0, ms1 = C.c_float(0.0), C.c_float(0.0)
+    st = vp(torch.cuda.current_stream(env.device).cuda_stream)
+    p = lambda t: vp(t.data_ptr())      # noqa: E731
+    assert lib.rover_step_begin(h, p(a), p(rew), p(flags[0]), p(flags[1]), p(force), st) == 0
+    counter0 = C.c_uint64()
+    assert lib.rover_get_counter(h, C.byref(counter0)) == 0
+    ERR_STATE = 2
+    assert lib.rover_step(h, p(a), p(obs), p(rew), p(flags[0]), p(flags[1]), p(force), p(log), st) == ERR_STATE
+    assert b"between rover_step_begin and rover_step_finish" in lib.rover_last_error()
+    assert lib.rover_profile_step(h, p(a), p(obs), p(rew), p(flags[0]), p(flags[1]), p(force), p(log), st, C.byref(ms0), C.byref(ms1)) == ERR_STATE
+    assert lib.rover_reset(h, p(obs), st) == ERR_STATE
+    z = torch.zeros(n * 32, device=env.device)
+    zi = torch.zeros(n, dtype=torch.int32, device=env.device)
+    assert lib.rover_reset_with_draws(h, None, p(zi), p(z), p(z), p(z), p(obs), st) == ERR_STATE
+    assert lib.rover_set_counter(h, C.c_uint64(5)) == ERR_STATE
+    assert lib.rover_step_begin(h, p(a), p(rew), p(flags[0]), p(flags[1]), p(force), st) == ERR_STATE
+    c1 = C.c_uint64()
+    lib.rover_get_counter(h, C.byref(c1))
+    assert c1.value == counter0.value                                    # nothing advanced
+    mask = torch.zeros(n, dtype=torch.uint8, device=env.device)
+    assert lib.rover_step_finish(h, p(mask), p(obs), p(force), p(log), st) == 0
+    assert lib.rover_step(h, p(a), p(obs), p(rew), p(flags[0]), p(flags[1]), p(force), p(log), st) == 0   # the phase is closed again
+    torch.cuda.synchronize()
+    assert torch.isfinite(obs[:, :4]).all()
+    env.close()
+
+
 def test_log_values_on_the_host_are_the_device_values(terrain):
     """``cfg.log_values = "host"``: the entries of extras["log"] are 0-d CPU tensors (views of a pinned mirror refreshed by the first
     read after a step) holding exactly what the device entries hold; the reference trainer's read loop (skrl_utils.py:139-142) works
     on them unchanged; switching back restores the device views."""
+    from helpers import oracle_config_from, oracle_terrain
+    from oracle import rover_oracle as ro
     n = 2048
     dev_env, host_env = _make(n, terrain), _make(n, terrain)
     host_env.set_log_values("host")
@@ -306,20 +352,31 @@ def test_log_values_on_the_host_are_the_device_values(terrain):
     S = dev_env.get_state()
     S[::23, 51] = torch.tensor([745], dtype=torch.int32).view(torch.float32).item()      # time-outs within a few steps
     dev_env.set_state(S); host_env.set_state(S)
+    # the oracle on the same state and actions says in WHICH steps envs reset -- the steps in which extras["log"] is rewritten
+    # (the reference rebuilds it only inside _reset_idx, rover_env.py:27-39)
+    ocfg, oter = oracle_config_from(ro, dev_env._native_cfg), oracle_terrain(ro, terrain)
+    So = S.cpu().numpy().copy()
+    olog = np.zeros(16, np.float32)
     g = torch.Generator(device=dev_env.device).manual_seed(9)
-    changed = 0
-    prev = None
+    changed, expected = [], []
+    prev, oprev = None, None
     for k in range(12):
         a = torch.rand(n, 2, device=dev_env.device, generator=g) * 2 - 1
         info_d = dev_env.step(a)[4]; info_h = host_env.step(a)[4]
+        olog = ro.step(ocfg, oter, So, a.cpu().numpy(), log=olog)[5]      # (bumps the config's call counter like the handle's)
         vals = []
         for (kd, vd), (kh, vh) in zip(info_d["episode"].items(), info_h["episode"].items()):
             assert kd == kh and vh.device.type == "cpu" and vd.device.type == "cuda" and vh.numel() == 1
             assert vh.item() == vd.item(), (k, kd)
             vals.append(vh.item())
-        changed += int(prev is not None and vals != prev)
-        prev = vals
-    assert changed >= 1                                   # the log moved while we watched (the time-outs of step 5)
+        if prev is not None and vals != prev:
+            changed.append(k)
+        if oprev is not None and not np.array_equal(olog[:13], oprev):
+            expected.append(k)
+        assert np.allclose(vals, olog[:13], rtol=1e-5, atol=1e-7), k      # different summation order only
+        prev, oprev = vals, olog[:13].copy()
+    # exactly the steps the oracle says -- among them step index 4, where the counters set to 745 reach 750 (mdp.time_out)
+    assert changed == expected and 4 in expected, (changed, expected)
     host_env.set_log_values("device")
     assert all(v.device.type == "cuda" for v in host_env.extras["log"].values())
     dev_env.close(); host_env.close()

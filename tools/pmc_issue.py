@@ -22,6 +22,20 @@ def short_name(name):
     return "".join(out).strip()
 
 
+def stamp():
+    """What the counters belong to: sha256[:16] of the librover_hip.so of this checkout and the solver / mass settings of the run
+    (QB_ITERS / QB_MASS of tools/pmc_run.py, else the cfg defaults) -- bench.py prints a summary only beside the build it describes."""
+    import hashlib, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from isaac_rover_orbit_amd.cfg import RoverEnvCfg
+    c = RoverEnvCfg()
+    lib = os.path.join(root, "isaac_rover_orbit_amd", "librover_hip.so")
+    return {"_lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16],
+            "_solver_iterations": int(os.environ.get("QB_ITERS") or c.solver_iterations),
+            "_mass_model": os.environ.get("QB_MASS") or c.mass_model}
+
+
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
@@ -31,7 +45,7 @@ for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
 out = {"_how": "rocprofv3 --kernel-trace --pmc (three separate passes, tools/r04_counters.sh) -- python3 tools/pmc_run.py 4096 20; "
                "per-launch means over launches 3..20, N = 4096, 1x MI355X.  SQ_*_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_* count in units "
                "of 4 shader cycles summed over waves; simds = 4 per CU x 256 CUs.",
-       "_build": sys.argv[3] if len(sys.argv) > 3 else ""}
+       "_build": sys.argv[3] if len(sys.argv) > 3 else "", **stamp()}
 for k, d in acc.items():
     out[k] = {"simds": 1024}
     for c, v in d.items():

@@ -41,6 +41,20 @@ def per_kernel(d):
     return out
 
 
+def stamp():
+    """What the counters belong to: sha256[:16] of the librover_hip.so of this checkout and the solver / mass settings of the run
+    (QB_ITERS / QB_MASS of tools/pmc_run.py, else the cfg defaults) -- bench.py prints a summary only beside the build it describes."""
+    import hashlib, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from isaac_rover_orbit_amd.cfg import RoverEnvCfg
+    c = RoverEnvCfg()
+    lib = os.path.join(root, "isaac_rover_orbit_amd", "librover_hip.so")
+    return {"_lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16],
+            "_solver_iterations": int(os.environ.get("QB_ITERS") or c.solver_iterations),
+            "_mass_model": os.environ.get("QB_MASS") or c.mass_model}
+
+
 for d in sys.argv[1:4]:
     if not glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         sys.exit(f"{d}: no *counter_collection.csv (run rocprofv3 with --output-format csv)")
@@ -52,7 +66,7 @@ res = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT
                "tile staging is 16 B/lane global_load_lds); the step kernels' 4-byte gathers are an uncalibrated width -> raw "
                "value.  Keys = kernel names exactly as rocprofv3 prints them (minus qualifiers / parameter list) = "
                "rover_kernel_names().",
-       "round": 4, "_build": sys.argv[5] if len(sys.argv) > 5 else ""}
+       "round": 5, "_build": sys.argv[5] if len(sys.argv) > 5 else "", **stamp()}
 # The one-launch kernel (rover_step_scan_kernel) contains both read streams: the step phase's 4-byte terrain gathers (raw value)
 # and the scan phase's 16-byte window staging (x 2).  Its corrected fetch = 2 x raw - the step phase's share, taken from the
 # two-launch step kernel measured in the same passes (tools/pmc_run.py with ROVER_FUSED=0 runs behind the product run).
