@@ -741,17 +741,29 @@ __device__ __forceinline__ void wheel_geometry(const RvParams &p, const StepCons
 // ---- solver arithmetic (operation for operation the one of oracle/rover_oracle.c, see the comment there) ---------------
 // The generalised velocity is held as four CHANNEL PAIRS {linear, angular}: c0 = (v.x, w.x), c1 = (v.y, w.y),
 // c2 = (v.z, w.z), c3 = (bogie rate, 0).  A wheel has two ROLES: A owns c0, c1; B owns c2, c3.  Every pair is one register
-// pair worked on by packed fp32 instructions (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32).
+// pair worked on by packed fp32 instructions (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32).  A role's channels in order:
+// ch0 = V[0].x, ch1 = V[0].y, ch2 = V[1].x, ch3 = V[1].y.  Row velocities (round 5, 44 instead of 48 instructions per iteration):
+//   normal row     pn = p.x + p.y,  p = fma2(Jn[1], V[1], fma2(Jn[0], V[0], Cn)),   Cn = (-bias, 0) in role A, (0, 0) in role B
+//   t and s rows   (pt, ps) = ONE packed chain over ch0 .. ch3: fma2(Jts[c], (ch_c, ch_c), .) starting from Cts = (-rim speed, 0) / (0, 0)
+//   un' = pn_A + pn_B = J_n . V - bias,  ut' = pt_A + pt_B = J_t . V - rim speed,  us = ps_A + ps_B
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 struct RoleRows {
-    f2 Jn[2], Jt[2], Js[2];  // Jacobian pairs of the role's two channels
-    f2 Mn[2], Mt[2], Ms[2];  // the same times the inverse mass pair of the channel
+    f2 Jn[2];                // normal row, by channel pair
+    f2 Jts[4];               // (J_t, J_s) of channel ch0 .. ch3
+    f2 Cn, Cts;              // constants of the chains
+    f2 Mn[2], Mt[2], Ms[2];  // Jacobian pairs times the inverse mass pair of the channel
 };
-__device__ __forceinline__ float row_partial(const f2 *J, const f2 *V)
+__device__ __forceinline__ void role_partials(const RoleRows &r, const f2 *V, float &pn, float &pt, float &ps)
 {
-    const f2 pr = fma2(J[1], V[1], J[0] * V[0]);
-    return pr.x + pr.y;
+    const f2 p = fma2(r.Jn[1], V[1], fma2(r.Jn[0], V[0], r.Cn));
+    pn = p.x + p.y;
+    f2 ts = fma2(r.Jts[0], (f2){V[0].x, V[0].x}, r.Cts);
+    ts = fma2(r.Jts[1], (f2){V[0].y, V[0].y}, ts);
+    ts = fma2(r.Jts[2], (f2){V[1].x, V[1].x}, ts);
+    ts = fma2(r.Jts[3], (f2){V[1].y, V[1].y}, ts);
+    pt = ts.x;
+    ps = ts.y;
 }
 __device__ __forceinline__ void role_outputs(const RoleRows &r, float dn, float dt, float ds, f2 *o)
 {
@@ -772,11 +784,19 @@ __device__ __forceinline__ void make_role_row(const float *dir, const float *ja,
     M[0] = J[0] * minv0;
     M[1] = J[1] * minv1;
 }
-__device__ __forceinline__ void make_role(const Contact &ct, bool role_b, const f2 &minv0, const f2 &minv1, RoleRows &r)
+// cw = the rim speed the (stiff) motor prescribes (role A carries it, and the row's bias, in its chain constants)
+__device__ __forceinline__ void make_role(const Contact &ct, bool role_b, const f2 &minv0, const f2 &minv1, float cw, RoleRows &r)
 {
+    f2 Jt[2], Js[2];
     make_role_row(ct.n, ct.jn_a, ct.jn_b, role_b, minv0, minv1, r.Jn, r.Mn);
-    make_role_row(ct.t, ct.jt_a, ct.jt_b, role_b, minv0, minv1, r.Jt, r.Mt);
-    make_role_row(ct.s, ct.js_a, ct.js_b, role_b, minv0, minv1, r.Js, r.Ms);
+    make_role_row(ct.t, ct.jt_a, ct.jt_b, role_b, minv0, minv1, Jt, r.Mt);
+    make_role_row(ct.s, ct.js_a, ct.js_b, role_b, minv0, minv1, Js, r.Ms);
+    r.Jts[0] = (f2){Jt[0].x, Js[0].x};
+    r.Jts[1] = (f2){Jt[0].y, Js[0].y};
+    r.Jts[2] = (f2){Jt[1].x, Js[1].x};
+    r.Jts[3] = (f2){Jt[1].y, Js[1].y};
+    r.Cn = (f2){role_b ? 0.0f : -ct.bias, 0.0f};
+    r.Cts = (f2){role_b ? 0.0f : -cw, 0.0f};
 }
 // max / min / symmetric clamp as single instructions (v_max_f32 / v_min_f32 / v_med3_f32: total order with -0 < +0, which
 // the oracle's max_ord / min_ord / med3_sym restate)
@@ -787,7 +807,7 @@ __device__ __forceinline__ float med3_sym(float x, float lim) { return __builtin
 __device__ __forceinline__ void impulse_update(const StepConsts &k, Contact &ct, float mu, float un, float ut, float us,
                                                float &dn, float &dt, float &ds)
 {
-    const float ln = max_zero_ord(fmaf(ct.bias - un, ct.mn, ct.ln));
+    const float ln = max_zero_ord(fmaf(-un, ct.mn, ct.ln));   // un = J_n . V - bias (the bias rides in the row chain)
     dn = ln - ct.ln;
     ct.ln = ln;
     const float lim = mu * ln;
@@ -931,8 +951,8 @@ __device__ __forceinline__ void physics_substep(const RvParams &p, const StepCon
         C[s].ls = 0.0f;
         const f2 minvB1 = {K.b_winv[j], 0.0f};
         RoleRows ra, rb;
-        make_role(C[s], false, minvA0, minvA1, ra);
-        make_role(C[s], true, minvB0, minvB1, rb);
+        make_role(C[s], false, minvA0, minvA1, 0.0f, ra);
+        make_role(C[s], true, minvB0, minvB1, 0.0f, rb);
         oa[0][s] = ra.Mn[0].x * C[s].ln; oa[1][s] = ra.Mn[0].y * C[s].ln;
         oa[2][s] = ra.Mn[1].x * C[s].ln; oa[3][s] = ra.Mn[1].y * C[s].ln;
         ob0[0][s] = rb.Mn[0].x * C[s].ln; ob0[1][s] = rb.Mn[0].y * C[s].ln;
@@ -946,12 +966,14 @@ __device__ __forceinline__ void physics_substep(const RvParams &p, const StepCon
                 const int k = SLOT_WHEEL[s], j = s >> 1;
                 const f2 minvB1 = {K.b_winv[j], 0.0f};
                 RoleRows ra, rb;
-                make_role(C[s], false, minvA0, minvA1, ra);
-                make_role(C[s], true, minvB0, minvB1, rb);
+                const float cw = RV_WHEEL_CONTACT_RADIUS * S[ROVER_WHEEL_QD + k];   // rim speed prescribed by the (stiff) motor
+                make_role(C[s], false, minvA0, minvA1, cw, ra);
+                make_role(C[s], true, minvB0, minvB1, cw, rb);
                 const f2 VB[2] = {VB0, {bd[j], bdy[j]}};
-                const float un = row_partial(ra.Jn, VA) + row_partial(rb.Jn, VB);
-                const float ut = (row_partial(ra.Jt, VA) + row_partial(rb.Jt, VB)) - RV_WHEEL_CONTACT_RADIUS * S[ROVER_WHEEL_QD + k];
-                const float us = row_partial(ra.Js, VA) + row_partial(rb.Js, VB);
+                float pna, pta, psa, pnb, ptb, psb;
+                role_partials(ra, VA, pna, pta, psa);
+                role_partials(rb, VB, pnb, ptb, psb);
+                const float un = pna + pnb, ut = pta + ptb, us = psa + psb;
                 float dn, dt, ds;
                 impulse_update(K, C[s], mu, un, ut, us, dn, dt, ds);
                 f2 o[2];
@@ -1090,12 +1112,11 @@ __device__ __forceinline__ void slot_sum4(float &a0, float &a1, float &a2, float
 #define K1_LITE_F(k) do { } while (0)
 #endif
 // the projected-Jacobi iterations of one lane (wheel slot x role): see the arithmetic contract above RoleRows
-__device__ __forceinline__ void solver_iteration_generic(const StepConsts &K, Contact &ct, const RoleRows &rr, f2 *V, float cw,
-                                                         float mu)
+__device__ __forceinline__ void solver_iteration_generic(const StepConsts &K, Contact &ct, const RoleRows &rr, f2 *V, float mu)
 {
-    float un = row_partial(rr.Jn, V), ut = row_partial(rr.Jt, V), us = row_partial(rr.Js, V);
+    float un, ut, us;
+    role_partials(rr, V, un, ut, us);
     cross_role_sum3(un, ut, us);
-    ut -= cw;
     float dn, dt, ds;
     impulse_update(K, ct, mu, un, ut, us, dn, dt, ds);
     f2 o[2];
@@ -1115,41 +1136,42 @@ __device__ __forceinline__ void solver_iteration_generic(const StepConsts &K, Co
 // packed ops.  Temporaries that are used both as 32-bit and as (even-aligned) 64-bit operands live in v[238:255].
 #define RV_DPP_FULL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
 #define RV_DPP_LANES_A " row_mask:0xf bank_mask:0x3 bound_ctrl:1\n\t"
+// One iteration = 44 instructions (round 4: 48): the row constants ride in the chains, the t and s rows share one packed chain with
+// the channel broadcast by op_sel, the normal row finishes first (its cross-role add needs two wait states after the VALU write of
+// its operand: the last two links of the (t, s) chain fill them).
+#define RV_BC_LO " op_sel_hi:[1,0,1]\n\t"                  /* src1.lo for both halves */
+#define RV_BC_HI " op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"   /* src1.hi for both halves */
 #define RV_SOLVER_HALF(LN_IN, LN_OUT, LT_IN, LT_OUT, LS_IN, LS_OUT, FILLER)                                            \
-    "v_pk_mul_f32 v[240:241], %[jn0], %[v0]\n\t"                                                                      \
-    "v_pk_mul_f32 v[242:243], %[jt0], %[v0]\n\t"                                                                      \
-    "v_pk_mul_f32 v[244:245], %[js0], %[v0]\n\t"                                                                      \
-    "v_pk_fma_f32 v[240:241], %[jn1], %[v1], v[240:241]\n\t"                                                          \
-    "v_pk_fma_f32 v[242:243], %[jt1], %[v1], v[242:243]\n\t"                                                          \
-    "v_pk_fma_f32 v[244:245], %[js1], %[v1], v[244:245]\n\t"                                                          \
-    "v_add_f32 v240, v240, v241\n\t"                                                                                   \
-    "v_add_f32 v242, v242, v243\n\t"                                                                                   \
-    "v_add_f32 v244, v244, v245\n\t"                                                                                   \
-    "v_add_f32_dpp v240, v240, v240 row_ror:8" RV_DPP_FULL                                                             \
-    "v_add_f32_dpp v242, v242, v242 row_ror:8" RV_DPP_FULL                                                             \
-    "v_add_f32_dpp v244, v244, v244 row_ror:8" RV_DPP_FULL                                                             \
-    "v_sub_f32 v241, %[bias], v240\n\t"                    /* bias - un                                             */ \
-    "v_sub_f32 v242, v242, %[cw]\n\t"                      /* ut - rim speed                                        */ \
-    "v_fma_f32 v243, v241, %[mn], " LN_IN "\n\t"                                                                       \
-    "v_max_f32 " LN_OUT ", 0, v243\n\t"                    /* ln                                                    */ \
+    "v_pk_fma_f32 v[240:241], %[jn0], %[v0], %[cn]\n\t"                                                              \
+    "v_pk_fma_f32 v[242:243], %[jts0], %[v0], %[cts]" RV_BC_LO                                                       \
+    "v_pk_fma_f32 v[240:241], %[jn1], %[v1], v[240:241]\n\t"                                                         \
+    "v_pk_fma_f32 v[242:243], %[jts1], %[v0], v[242:243]" RV_BC_HI                                                   \
+    "v_add_f32 v240, v240, v241\n\t"                     /* own share of un'                                       */ \
+    "v_pk_fma_f32 v[242:243], %[jts2], %[v1], v[242:243]" RV_BC_LO                                                   \
+    "v_pk_fma_f32 v[242:243], %[jts3], %[v1], v[242:243]" RV_BC_HI                                                   \
+    "v_add_f32_dpp v240, v240, v240 row_ror:8" RV_DPP_FULL   /* un' = J_n . V - bias                                  */ \
+    "v_fma_f32 v245, -v240, %[mn], " LN_IN "\n\t"                                                                    \
+    "v_add_f32_dpp v242, v242, v242 row_ror:8" RV_DPP_FULL   /* ut' = J_t . V - rim speed                             */ \
+    "v_add_f32_dpp v243, v243, v243 row_ror:8" RV_DPP_FULL   /* us                                                    */ \
+    "v_max_f32 " LN_OUT ", 0, v245\n\t"                    /* ln                                                    */ \
     "v_sub_f32 v246, " LN_OUT ", " LN_IN "\n\t"            /* dn                                                    */ \
     "v_mul_f32 v245, %[mu], " LN_OUT "\n\t"                /* lim = mu * ln                                         */ \
-    "v_pk_mul_f32 v[252:253], %[mn0], v[246:247] op_sel_hi:[1,0]\n\t"                                                  \
-    "v_fmac_f32 v242, %[ant], v246\n\t"                    /* ut + a_nt * dn                                        */ \
-    "v_pk_mul_f32 v[254:255], %[mn1], v[246:247] op_sel_hi:[1,0]\n\t"                                                  \
+    "v_pk_mul_f32 v[252:253], %[mn0], v[246:247] op_sel_hi:[1,0]\n\t"                                                \
+    "v_fmac_f32 v242, %[ant], v246\n\t"                    /* ut' + a_nt * dn                                       */ \
+    "v_pk_mul_f32 v[254:255], %[mn1], v[246:247] op_sel_hi:[1,0]\n\t"                                                \
     "v_min_f32 v247, %[ltm], v245\n\t"                     /* lmax = min(lim, lt_motor)                             */ \
-    "v_fmac_f32 v244, %[ans], v246\n\t"                    /* us + a_ns * dn                                        */ \
-    "v_fma_f32 v243, -v242, %[mt], " LT_IN "\n\t"                                                                      \
-    "v_med3_f32 " LT_OUT ", v243, -v247, v247\n\t"         /* lt                                                    */ \
+    "v_fmac_f32 v243, %[ans], v246\n\t"                    /* us + a_ns * dn                                        */ \
+    "v_fma_f32 v244, -v242, %[mt], " LT_IN "\n\t"                                                                    \
+    "v_med3_f32 " LT_OUT ", v244, -v247, v247\n\t"         /* lt                                                    */ \
     "v_sub_f32 v248, " LT_OUT ", " LT_IN "\n\t"            /* dt                                                    */ \
-    "v_fmac_f32 v244, %[ats], v248\n\t"                    /* ... + a_ts * dt                                       */ \
-    "v_pk_fma_f32 v[252:253], %[mt0], v[248:249], v[252:253] op_sel_hi:[1,0,1]\n\t"                                    \
-    "v_fma_f32 v243, -v244, %[ms], " LS_IN "\n\t"                                                                      \
-    "v_pk_fma_f32 v[254:255], %[mt1], v[248:249], v[254:255] op_sel_hi:[1,0,1]\n\t"                                    \
-    "v_med3_f32 " LS_OUT ", v243, -v245, v245\n\t"         /* ls                                                    */ \
+    "v_fmac_f32 v243, %[ats], v248\n\t"                    /* ... + a_ts * dt                                       */ \
+    "v_pk_fma_f32 v[252:253], %[mt0], v[248:249], v[252:253] op_sel_hi:[1,0,1]\n\t"                                  \
+    "v_fma_f32 v244, -v243, %[ms], " LS_IN "\n\t"                                                                    \
+    "v_pk_fma_f32 v[254:255], %[mt1], v[248:249], v[254:255] op_sel_hi:[1,0,1]\n\t"                                  \
+    "v_med3_f32 " LS_OUT ", v244, -v245, v245\n\t"         /* ls                                                    */ \
     "v_sub_f32 v250, " LS_OUT ", " LS_IN "\n\t"            /* ds                                                    */ \
-    "v_pk_fma_f32 v[252:253], %[ms0], v[250:251], v[252:253] op_sel_hi:[1,0,1]\n\t"                                    \
-    "v_pk_fma_f32 v[254:255], %[ms1], v[250:251], v[254:255] op_sel_hi:[1,0,1]\n\t"                                    \
+    "v_pk_fma_f32 v[252:253], %[ms0], v[250:251], v[252:253] op_sel_hi:[1,0,1]\n\t"                                  \
+    "v_pk_fma_f32 v[254:255], %[ms1], v[250:251], v[254:255] op_sel_hi:[1,0,1]\n\t"                                  \
     FILLER                                                                                                             \
     "v_add_f32_dpp v252, v252, v252 quad_perm:[1,0,3,2]" RV_DPP_FULL                                                   \
     "v_add_f32_dpp v253, v253, v253 quad_perm:[1,0,3,2]" RV_DPP_FULL                                                   \
@@ -1163,11 +1185,11 @@ __device__ __forceinline__ void solver_iteration_generic(const StepConsts &K, Co
     "v_add_f32_dpp v253, v253, v253 row_half_mirror" RV_DPP_FULL                                                       \
     "v_add_f32_dpp v254, v254, v254 row_half_mirror" RV_DPP_LANES_A                                                    \
     "v_add_f32_dpp v255, v255, v255 row_half_mirror" RV_DPP_LANES_A                                                    \
-    "v_pk_add_f32 %[v0], %[v0], v[252:253]\n\t"                                                                        \
+    "v_pk_add_f32 %[v0], %[v0], v[252:253]\n\t"                                                                      \
     "v_pk_add_f32 %[v1], %[v1], v[254:255]\n\t"
 
-__device__ __forceinline__ void solver_iterations_group(const StepConsts &K, Contact &ct, const RoleRows &rr, f2 *V, float cw,
-                                                        float mu, int iterations)
+__device__ __forceinline__ void solver_iterations_group(const StepConsts &K, Contact &ct, const RoleRows &rr, f2 *V, float mu,
+                                                        int iterations)
 {
     int pairs = iterations >> 1;
     if (pairs > 0) {
@@ -1179,10 +1201,10 @@ __device__ __forceinline__ void solver_iterations_group(const StepConsts &K, Con
             RV_SOLVER_HALF("v249", "%[ln]", "v251", "%[lt]", "v238", "%[ls]", "s_cmp_lg_u32 %[cnt], 0\n\t")
             "s_cbranch_scc1 1b\n\t"
             : [v0] "+v"(v0), [v1] "+v"(v1), [ln] "+v"(ln), [lt] "+v"(lt), [ls] "+v"(ls), [cnt] "+s"(pairs)
-            : [jn0] "v"(rr.Jn[0]), [jn1] "v"(rr.Jn[1]), [jt0] "v"(rr.Jt[0]), [jt1] "v"(rr.Jt[1]), [js0] "v"(rr.Js[0]),
-              [js1] "v"(rr.Js[1]), [mn0] "v"(rr.Mn[0]), [mn1] "v"(rr.Mn[1]), [mt0] "v"(rr.Mt[0]), [mt1] "v"(rr.Mt[1]),
-              [ms0] "v"(rr.Ms[0]), [ms1] "v"(rr.Ms[1]), [bias] "v"(ct.bias), [mn] "v"(ct.mn), [mt] "v"(ct.mt), [ms] "v"(ct.ms),
-              [ant] "v"(ct.a_nt), [ans] "v"(ct.a_ns), [ats] "v"(ct.a_ts), [cw] "v"(cw), [mu] "s"(mu), [ltm] "s"(K.lt_motor)
+            : [jn0] "v"(rr.Jn[0]), [jn1] "v"(rr.Jn[1]), [jts0] "v"(rr.Jts[0]), [jts1] "v"(rr.Jts[1]), [jts2] "v"(rr.Jts[2]),
+              [jts3] "v"(rr.Jts[3]), [cn] "v"(rr.Cn), [cts] "v"(rr.Cts), [mn0] "v"(rr.Mn[0]), [mn1] "v"(rr.Mn[1]), [mt0] "v"(rr.Mt[0]),
+              [mt1] "v"(rr.Mt[1]), [ms0] "v"(rr.Ms[0]), [ms1] "v"(rr.Ms[1]), [mn] "v"(ct.mn), [mt] "v"(ct.mt), [ms] "v"(ct.ms),
+              [ant] "v"(ct.a_nt), [ans] "v"(ct.a_ns), [ats] "v"(ct.a_ts), [mu] "s"(mu), [ltm] "s"(K.lt_motor)
             : "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251",
               "v252", "v253", "v254", "v255", "scc");
         V[0] = v0;
@@ -1191,7 +1213,7 @@ __device__ __forceinline__ void solver_iterations_group(const StepConsts &K, Con
         ct.lt = lt;
         ct.ls = ls;
     }
-    if (iterations & 1) solver_iteration_generic(K, ct, rr, V, cw, mu);
+    if (iterations & 1) solver_iteration_generic(K, ct, rr, V, mu);
 }
 
 // LINK_ELSEWHERE: the lane's link-body sample point AND the obstacle-layer height under its wheel are evaluated by the lane's twin
@@ -1242,12 +1264,12 @@ __device__ __forceinline__ void physics_substep_group(const RvParams &p, const S
     const bool rb = g.role_b;
     RoleRows rr;
     {
-        make_role(ct, rb, g.minv0, g.minv1, rr);
+        const float cw = RV_WHEEL_CONTACT_RADIUS * g.wqd;  // rim speed prescribed by the (stiff) motor
+        make_role(ct, rb, g.minv0, g.minv1, cw, rr);
     }
     f2 V[2];
     V[0] = rb ? (f2){v[2], w[2]} : (f2){v[0], w[0]};
     V[1] = rb ? (f2){bd, 0.0f} : (f2){v[1], w[1]};
-    const float cw = RV_WHEEL_CONTACT_RADIUS * g.wqd;  // rim speed prescribed by the (stiff) motor
     {
         // warm start: contribution of the cached normal impulse alone
         const f2 l2 = {ct.ln, ct.ln};
@@ -1257,7 +1279,7 @@ __device__ __forceinline__ void physics_substep_group(const RvParams &p, const S
         V[0] += (f2){a0, a1};
         V[1] += (f2){a2, a3};
     }
-    solver_iterations_group(K, ct, rr, V, cw, mu, p.cfg.solver_iterations);
+    solver_iterations_group(K, ct, rr, V, mu, p.cfg.solver_iterations);
     {
         // both roles need the full velocity again: fetch the other role's two pairs
         const float p0x = dpp_ror8(V[0].x), p0y = dpp_ror8(V[0].y), p1x = dpp_ror8(V[1].x), p1y = dpp_ror8(V[1].y);
