@@ -914,7 +914,7 @@ __device__ __forceinline__ void physics_substep(const RvParams &p, const StepCon
         at_hi[j] = bq[j] >= RV_BOGIE_QLIM - 1.0e-5f;
         at_lo[j] = bq[j] <= -RV_BOGIE_QLIM + 1.0e-5f;
     }
-    if (p.cfg.mass_model == 1) {
+    {   // (cfg.mass_model = 0: the same operations with a zero coefficient, as in the group mapping and the oracle)
         constexpr float SUBTREE_COM[3][3] = RV_SUBTREE_COM_INIT;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -923,7 +923,7 @@ __device__ __forceinline__ void physics_substep(const RvParams &p, const StepCon
             const float cj[3] = {SUBTREE_COM[j][0], SUBTREE_COM[j][1], SUBTREE_COM[j][2]};
             float sb, cb;
             bogie_sincos(bq[j], &sb, &cb);
-            bd[j] = bogie_gravity(make_sub(cj, P, ax), R, sb, cb, K.bogie_gq[j], bd[j]);
+            bd[j] = bogie_gravity(make_sub(cj, P, ax), R, sb, cb, p.cfg.mass_model == 1 ? K.bogie_gq[j] : 0.0f, bd[j]);
         }
     }
     // ---- 3. contact geometry (slot order), warm start
@@ -1242,7 +1242,9 @@ __device__ __forceinline__ void physics_substep_group(const RvParams &p, const S
     mat_tvecf(R, g.angvel, w);
     const float bq = g.bq;
     float bd = g.bqd * g.bogie_keep;
-    if (p.cfg.mass_model == 1) {   // the subtree's weight on the bogie coordinate (wave-uniform branch)
+    {   // the subtree's weight on the bogie coordinate.  NO branch on cfg.mass_model: the lumped model runs the same ten instructions
+        // with a zero coefficient (g.bogie_gq; the oracle does the same) -- a wave-uniform branch here cost 1.35 us per step (the
+        // kernel sits at 256 VGPRs / ~100 SGPRs: the branch's extra live scalar state turned into scalar re-loads inside the substeps)
         float sb, cb;
         bogie_sincos(bq, &sb, &cb);
         bd = bogie_gravity(g.sub, R, sb, cb, g.bogie_gq, bd);
@@ -1737,7 +1739,7 @@ __device__ __forceinline__ GroupIds group_ids(int lane, const SlotConst &sc)
     return id;
 }
 __device__ __forceinline__ void group_load(const float *__restrict__ state, int N, int e, const GroupIds &id, const SlotConst &sc,
-                                           const StepConsts &K, GroupLane &g)
+                                           const StepConsts &K, GroupLane &g, int mass_model)
 {
 #pragma unroll
     for (int i = 0; i < 3; ++i) g.pos[i] = state[(size_t)(ROVER_POS + i) * N + e];
@@ -1773,7 +1775,7 @@ __device__ __forceinline__ void group_load(const float *__restrict__ state, int 
         float gq = K.bogie_gq[0];
 #pragma unroll
         for (int j = 1; j < 3; ++j) gq = (id.j == j) ? K.bogie_gq[j] : gq;
-        g.bogie_gq = gq;
+        g.bogie_gq = mass_model == 1 ? gq : 0.0f;
         g.sub = make_sub(sc.sc, sc.P, sc.ax);
     }
     g.steerable = id.si >= 0;
@@ -2479,7 +2481,7 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
 
     const StepConsts &K = p.K;
     GroupLane g;
-    group_load(state, N, e, id, sc, K, g);
+    group_load(state, N, e, id, sc, K, g, p.cfg.mass_model);
     // rover_env.py:62 ActionManager.process_action
     float act[2], prev[2];
     prev[0] = state[(size_t)(ROVER_ACTION + 0) * N + e];
@@ -2487,13 +2489,7 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
     const float2 a = reinterpret_cast<const float2 *>(action)[e];
     act[0] = a.x;
     act[1] = a.y;
-    // manager words: issued now so that their latency hides under the physics (the group mapping has registers to spare)
     float S[ROVER_STATE_WORDS];
-#pragma unroll
-    for (int i = ROVER_TARGET_W; i < ROVER_ACTION; ++i) S[i] = state[(size_t)i * N + e];
-#pragma unroll
-    for (int i = ROVER_TIME_LEFT; i < ROVER_LAMBDA_N; ++i) S[i] = state[(size_t)i * N + e];
-    S[ROVER_RESET_COUNT] = state[(size_t)ROVER_RESET_COUNT * N + e];
     {
         float processed[2], steer[4], rim[6];
         ackermann_core(c, act, processed, steer, rim);
@@ -2512,6 +2508,13 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
     f2 oxy[PRIVATE_ROUNDS];   // the scan phase's ray table (one-launch forms)
     K1_STAMP(1);
     for (int s = 0; s < c.decimation - 1; ++s) physics_substep_group<false>(p, K, g, nullptr, s);
+    // manager words: requested HERE, in front of the last substep, so that their latency hides under it -- requested at the top of the
+    // kernel (rounds 2 - 4) they held 26 VGPRs through all six substeps of a kernel that sits at 256 VGPRs (-0.4 us per step)
+#pragma unroll
+    for (int i = ROVER_TARGET_W; i < ROVER_ACTION; ++i) S[i] = state[(size_t)i * N + e];
+#pragma unroll
+    for (int i = ROVER_TIME_LEFT; i < ROVER_LAMBDA_N; ++i) S[i] = state[(size_t)i * N + e];
+    S[ROVER_RESET_COUNT] = state[(size_t)ROVER_RESET_COUNT * N + e];
     if constexpr (FUSE == 1 || FUSE == 2) {
         // copy-wave form: the link-body sample points of the contact report (evaluated at the pose of the last substep's START)
         // are the copy wave's work -- it is asleep until now; this wave goes straight into the substep
@@ -2843,7 +2846,7 @@ __global__ __launch_bounds__(RV_K1G_THREADS) void rover_physics_kernel_group(RvP
     const GroupIds id = group_ids(lane, sc);
     const StepConsts &K = p.K;
     GroupLane g;
-    group_load(state, N, e, id, sc, K, g);
+    group_load(state, N, e, id, sc, K, g, p.cfg.mass_model);
     g.steer_t = steer_t[4 * e + (id.si >= 0 ? id.si : 0)];
     g.wheel_t = wheel_t[6 * e + id.k];
     float Fw[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
