@@ -346,6 +346,10 @@ def main():
                     help="top-level `with_policy` leg (outside `value`): the rollout loop a trainer runs -- actor + critic forward "
                          "passes (fused MFMA kernel, reference architecture, random-init weights) + env.step() on one stream; the "
                          "default run carries the same leg as extra.rollout_loop")
+    ap.add_argument("--solver-iterations", type=int, default=None,
+                    help="override cfg.solver_iterations (default: the reference's 32, aau_rover_simple.py:33); a line measured with an "
+                         "override says so in config.solver_iterations and is NOT the headline")
+    ap.add_argument("--mass-model", default=None, choices=("lumped", "subtree_weights"), help="override cfg.mass_model (default subtree_weights)")
     ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5),
                     help="BASELINE.json config: 2 = headline (31x31 rays @0.1 m, sigma_z 0.15 m); "
                          "4 = dense scanner stress (32x32 rays @0.05 m, sigma_z 0.4 m); "
@@ -376,7 +380,8 @@ def main():
     n = args.num_envs
     shard = rd.weak_shard(n, rank, world)
     terrain_cache = {}
-    env, ter, cfg, sigma_z = make_rover(dev, n, args.config, shard=shard, no_forces=args.no_forces, terrain_cache=terrain_cache)
+    env, ter, cfg, sigma_z = make_rover(dev, n, args.config, shard=shard, no_forces=args.no_forces, terrain_cache=terrain_cache,
+                                        solver_iterations=args.solver_iterations, mass_model=args.mass_model)
 
     total = args.steps + args.warmup
     g = torch.Generator(device=dev).manual_seed(rank)          # torch's CUDA generator is Philox; seed 0 on rank 0
