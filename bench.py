@@ -55,12 +55,13 @@ def _load_json(name):
 
 
 def library_digest():
-    """sha256[:16] of the librover_hip.so this process loaded -- what tools/pmc_issue.py / tools/pmc_traffic.py record beside the
-    counters they collect (`_lib_sha256`): a committed counter summary is printed as measured only for the build it was measured on."""
-    import hashlib
-    from isaac_rover_orbit_amd import _lib
+    """Identity of the build this process runs: sha256[:16] over the HIP sources + headers (isaac_rover_orbit_amd.build.source_digest:
+    stable across rebuilds) and the file name of the loaded library (a tools/build_diag.py variant carries another name) -- what
+    tools/pmc_issue.py / tools/pmc_traffic.py record beside the counters they collect (`_lib_sha256`): a committed counter summary is
+    printed as measured only for the build it was measured on."""
+    from isaac_rover_orbit_amd import _lib, build
     try:
-        return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]
+        return build.source_digest() + ":" + os.path.basename(_lib.LIB_PATH)
     except Exception:
         return None
 

@@ -30,6 +30,19 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found (looked at $HIPCC, PATH, /opt/rocm/bin/hipcc)")
 
 
+def source_digest() -> str:
+    """sha256[:16] over the HIP sources and headers the library is built from -- the identity of a BUILD that survives a rebuild
+    (two hipcc runs on the same sources differ in their code-object ids, so the binary's own hash does not).  bench.py prints the
+    committed PMC summaries (profiles/*.json) only beside the sources they were measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        if os.path.exists(f):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def needs_build() -> bool:
     if not os.path.exists(OUTPUT):
         return True

@@ -23,15 +23,15 @@ def short_name(name):
 
 
 def stamp():
-    """What the counters belong to: sha256[:16] of the librover_hip.so of this checkout and the solver / mass settings of the run
+    """What the counters belong to: the source digest of this checkout's librover_hip.so and the solver / mass settings of the run
     (QB_ITERS / QB_MASS of tools/pmc_run.py, else the cfg defaults) -- bench.py prints a summary only beside the build it describes."""
     import hashlib, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     from isaac_rover_orbit_amd.cfg import RoverEnvCfg
     c = RoverEnvCfg()
-    lib = os.path.join(root, "isaac_rover_orbit_amd", "librover_hip.so")
-    return {"_lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16],
+    from isaac_rover_orbit_amd import build
+    return {"_lib_sha256": build.source_digest() + ":librover_hip.so",   # sources + headers: stable across rebuilds (bench.py: library_digest)
             "_solver_iterations": int(os.environ.get("QB_ITERS") or c.solver_iterations),
             "_mass_model": os.environ.get("QB_MASS") or c.mass_model}
 
