@@ -6,7 +6,7 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one ``RoverEnv.step()`` over the rank's batch of envs: the hot path's HIP kernel -- ONE launch per step at the
-benchmark's 4096 envs per GPU (step + height scan, DESIGN.md section 3.6), two launches below 2048 envs -- launched
+benchmark's 4096 envs per GPU (step + height scan, DESIGN.md section 3.2), two launches below 2048 envs -- launched
 through the C ABI (random actions pre-generated in HBM, in-kernel resets included).  The timed loop is the metric's
 random-action rollout of ``step()``: it does not read ``extras["log"]``, so the on-demand log reduction never runs inside it.
 The reference's TRAINER reads the log after every step (``skrl_utils.py:139-142``: ``.item()`` on every entry of
@@ -94,7 +94,7 @@ def lift_line(num_envs, steps, warmup, profile_steps, cpu_seconds):
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"FrankaCubeLift-v0 num_envs={n}, random U(-1,1) actions, 100 Hz x decimation 2, in-step resets "
                                   "(BASELINE config 5)", "baseline_config": 5, "num_envs_per_gpu": n}}
-    # ---- roofline leg.  Algorithmic bytes per env-step of this path: state read + write 2 x 4 x 64 B,
+    # ---- roofline leg.  Algorithmic bytes per env-step of this path (docs/history.md section 9, f-4): state read + write 2 x 4 x 64 B,
     #      observation row 36 x 4 B, action 8 x 4 B, reward + flags 6 B = 694 B.  The kernel is bound by the length of its waves'
     #      instruction streams (512 waves at 2048 envs), not by HBM: the fraction is structurally tiny and says so.
     #      Duration = ms_per_step: one kernel per step, so the step time bounds the kernel from above (event intervals minus the
@@ -116,7 +116,7 @@ def lift_line(num_envs, steps, warmup, profile_steps, cpu_seconds):
                                           "algorithmic_bytes": alg, "GB/s": alg / (ms_k * 1e-3) / 1e9}},
                        "note": "latency-bound by construction: 8 lanes per env, two pipelined waves per 8 envs = 512 waves on 1024 SIMDs "
                                "at 2048 envs; the time is the critical path arm substep 0 -> cube substeps 0, 1 -> managers "
-                               "(~35 k cycles), see DESIGN.md section 9"}
+                               "(~35 k cycles), see docs/history.md section 9"}
     out["config"]["parity"] = ("reward / observation term functions pinned by the reference fixture (lift_terms.npz); arm / cube / gripper "
                                "simulator is a documented model (PhysX in the reference), parity unpinned; HIP == the separately "
                                "written scalar oracle bit for bit")

@@ -6,7 +6,7 @@
 //   rover_envs/envs/manipulation/config/franka/joint_pos_env_cfg.py:25-82   Franka + 0.8-scale DexCube, joint-position action
 //                                                                  (scale 0.5, default offset), binary gripper, ee frame offset
 //   rover_envs/envs/manipulation/mdp/rewards.py:20-67, mdp/observations.py:19-31   the task's own term functions
-//   ORBIT (third-party, absent): RLTaskEnv.step ordering and the generic mdp terms; PhysX: replaced by the model of DESIGN.md
+//   ORBIT (third-party, absent): RLTaskEnv.step ordering and the generic mdp terms; PhysX: replaced by the model of docs/history.md
 //   section 9 (PARITY UNPINNED).  The CPU oracle (oracle/lift_oracle.c) is a separately written scalar restatement of the same
 //   specification; the two agree bit for bit because every floating-point operation order is part of the specification.
 //

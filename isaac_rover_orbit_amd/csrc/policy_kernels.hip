@@ -774,12 +774,16 @@ __device__ __forceinline__ void ref_pair_network(const rover_policy_desc &da, co
         asm volatile("" ::: "memory");   // the weight loads below stay BEHIND the copy in issue order (the counted wait relies on it)
         if (full1) {
             pq_preload<2 * T1, QD1>(q1, W1, lane);
+#ifndef POL_X_NOTILEWAIT   // TIMING EXPERIMENT ONLY (tools/build_diag.py P_NOTILEWAIT): layer 1 starts on whatever the tile holds -- wrong results
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QD1 * 2 * T1) : "memory");     // the copy, not the fragments queued behind it
+#endif
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
+#ifndef POL_X_NOTILEWAIT
     __syncthreads();   // the tile is complete
+#endif
     PSTAMP(1);
     const float prop = tid < POL_ROWS * PROP ? tile[(tid >> 2) * OBS + (tid & 3)] : 0.0f;   // models.py:93-96, saved before the tile is reused
 

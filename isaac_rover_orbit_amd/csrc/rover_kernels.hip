@@ -2008,7 +2008,7 @@ __device__ __forceinline__ void lds_cell4_issue(unsigned row0, unsigned row1, in
 // The TRIANGLE surface needs three of the four corners: 00, 11 and ONE of 01 / 10 -- fx >= fy (lower triangle) picks 01, and is known
 // before the reads are issued: the select moves from the value to the ADDRESS (`mid` = lower ? a0 : a0 + 2 pitch - 2, read at offset 2;
 // `r1m` = a0 + 2 pitch - 2, corner 11 at offset 4): three LDS instructions per ray instead of four, the same three operands into the
-// same arithmetic.  (The conflict cycles of a 64-lane 16-bit read are a property of the instruction, DESIGN.md: the lever is the COUNT.)
+// same arithmetic.  (The conflict cycles of a 64-lane 16-bit read are a property of the instruction, docs/history.md section 3.5: the lever is the COUNT.)
 __device__ __forceinline__ void lds_cell3_issue(unsigned a0, unsigned mid, unsigned r1m, int &h00, int &hm, int &h11)
 {
     asm volatile("ds_read_i16 %0, %3\n\t"
@@ -4254,7 +4254,7 @@ int rover_height_scan(rover_sim *sim, float *scan, void *stream)
 // measurement hook (tools/n_sweep.py): 0 = automatic choice, 1 = the generic scan kernel on the step path as well, 2 = the
 // step form with one env per iteration, 7 = the wave-private scan (the scan phase of the one-launch kernels) as a kernel of its
 // own behind the group-mapped step kernel.  (Forms 3 .. 6 -- 8 x 8 ray blocks per wave, XCD-aware pair dealing off / on -- were
-// round-3 experiments; their outcome is in DESIGN.md section 10, their code is gone.)
+// round-3 experiments; their outcome is in docs/history.md section 10, their code is gone.)
 int rover_debug_set_scan_form(rover_sim *sim, int form)
 {
     if (!sim || !(form == 0 || form == 1 || form == 2 || form == 7)) return ROVER_ERR_INVALID;

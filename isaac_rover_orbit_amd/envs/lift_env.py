@@ -5,7 +5,7 @@ Reference: gym id ``FrankaCubeLift-v0`` = ORBIT ``RLTaskEnv`` on ``FrankaCubeLif
 (``rover_envs/envs/manipulation/config/franka/__init__.py:6-14``, ``joint_pos_env_cfg.py:25-82``,
 ``manipulation_env_cfg.py:93-235``, ``mdp/rewards.py``, ``mdp/observations.py``).  ``step()`` is two HIP launches through the
 C ABI of ``include/rover_lift.h``; the model that stands in for PhysX (7-DOF arm dynamics, gripper, cube / table / finger
-contact) is specified in DESIGN.md section 9 and implemented in ``csrc/lift_kernels.hip`` (eight lanes per env) -- parity of
+contact) is specified in docs/history.md section 9 (f-4) and implemented in ``csrc/lift_kernels.hip`` (eight lanes per env) -- parity of
 that layer is unpinned.  No CPU fallback.
 """
 from __future__ import annotations

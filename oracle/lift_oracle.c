@@ -3,7 +3,7 @@
  *
  * Scalar CPU oracle of the FrankaCubeLift-v0 path (BASELINE config 5).  Written on its own: it includes
  * nothing from isaac_rover_orbit_amd/ and shares no source with the HIP kernel (csrc/lift_kernels.hip maps one env onto
- * eight lanes; here every env is a plain sequential loop).  What the two have in common is the SPECIFICATION: DESIGN.md
+ * eight lanes; here every env is a plain sequential loop).  What the two have in common is the SPECIFICATION: docs/history.md
  * section 9 (model) and the reference files cited below (MDP), including the order of every floating-point operation,
  * so that the GPU tests can demand bit equality.
  *
@@ -18,7 +18,7 @@
  *     PARITY UNPINNED.  Plausibility is tested separately (tests/test_lift_oracle.py, incl. a float64 Lagrangian
  *     re-derivation of the arm dynamics).
  *
- * Model in one paragraph (DESIGN.md section 9 has the details).  Arm: 7 revolute joints, modified-DH kinematics of the
+ * Model in one paragraph (docs/history.md section 9 has the details).  Arm: 7 revolute joints, modified-DH kinematics of the
  * Franka Emika Panda, M(q) qdd + c(q, qd) = tau.  EIGHT inverse-dynamics passes of the recursive Newton-Euler algorithm per
  * substep: pass j < 7 with (qd, qdd, g) = (0, e_j, 0) gives column j of M, pass 7 with (qd, 0, 9.81) gives c.  Implicit PD
  * actuators: (M + h Kd + h^2 Kp) v+ = M v + h (Kp (q* - q) - c), Cholesky; joints whose PD torque exceeds the effort

@@ -260,7 +260,7 @@ def set_num_threads(n: int):
 
 
 def set_model_variant(v: int):
-    """Study variants of the dynamics model (rover_oracle.c): bit 0 = wheel contact on the triangle surface,
+    """Study variants of the dynamics model (rover_oracle.c; DESIGN.md section 4, docs/history.md section 5): bit 0 = wheel contact on the triangle surface,
     bit 1 = coupled 9 x 9 mass matrix + sequential PGS.  0 = the model the HIP path implements (the only value tests use)."""
     lib().rvo_set_model_variant(int(v))
 

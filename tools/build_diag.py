@@ -29,11 +29,14 @@ VARIANTS = {"K1STAMP": ("rover_kernels.hip", "-DRV_K1_STAMP"),            # s_me
             **{f"SH_{a}_{b_}_{c}": ("rover_kernels.hip", f"-DRV_SHARE_1={a} -DRV_SHARE_2={b_} -DRV_SHARE_3={c}")
                for (a, b_, c) in ((12, 16, 12), (12, 16, 16), (8, 16, 12), (12, 16, 8), (8, 16, 8), (16, 16, 12), (12, 12, 12))},
             # policy pair kernel: round 3's sequential form; queue depths of the weight fragments
+            # timing experiment (WRONG results): the pair kernel's layer 1 does not wait for the observation tile -- the upper bound of what
+            # starting layer 1 on the landed part of the tile could gain
+            "P_NOTILEWAIT": ("policy_kernels.hip", "-DPOL_X_NOTILEWAIT"), "P_NOTILEWAIT_S": ("policy_kernels.hip", "-DPOL_X_NOTILEWAIT -DPOL_STAMP"),
             "P_SEQ": ("policy_kernels.hip", "-DPOL_PAIR_SEQUENTIAL"), "P_QD1_3": ("policy_kernels.hip", "-DPOL_STAMP -DPOL_QD1=3"),
             "P_QD4_8": ("policy_kernels.hip", "-DPOL_STAMP -DPOL_QD4=8 -DPOL_QD5=10")}
 # (The round-2 / round-3 timing builds of the two-launch scan kernel -- RV_K2_EMPTY / PROLOGUE_ONLY / NO_COPY / NO_RAYS / STORE4 /
 # NT_STORE / NOREDUCE / STAMP --, RV_K1_NOTERRAIN / CONSTS_IN_KERNEL and round 4's RV_X_NOLDS / NOSTORE / NOLINK / NODRAW have been
-# removed from the sources together with their variants here: what they measured is recorded in DESIGN.md sections 3.3 - 3.7 and 10.)
+# removed from the sources together with their variants here: what they measured is recorded in docs/history.md sections 3.3 - 3.7 and 10.)
 
 
 def main():

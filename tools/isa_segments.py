@@ -7,7 +7,7 @@ diagnostic build (-DRV_K1_STAMP) -- which phase of the step kernel holds how man
 
 Loops are counted once (the solver loop body holds two iterations and runs iterations / 2 times; the substep loop body runs
 decimation - 1 times): the listing is static.  8-byte encodings (VOP3 / packed / DPP / SDWA) are counted separately -- on
-gfx950 with one wave per SIMD they cost ~5.5 cycles of issue against ~4.5 for a 4-byte VOP1 / VOP2."""
+gfx950 with one wave per SIMD they cost ~5.5 cycles of issue against ~4.5 for a 4-byte VOP1 / VOP2 (docs/history.md 3.2)."""
 import re, sys, collections
 
 path, key = sys.argv[1], sys.argv[2]

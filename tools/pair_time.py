@@ -6,6 +6,9 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import random_policy_weights, synthetic_obs
+if os.environ.get("POLTAG"):   # a tools/build_diag.py variant of the policy kernels
+    from isaac_rover_orbit_amd import _lib
+    _lib.LIB_PATH = os.path.join(ROOT, "build", "abl", f"librover_abl{os.environ['POLTAG']}.so")
 from isaac_rover_orbit_amd.policy import RoverNet, forward_pair
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 ws, bs = random_policy_weights(seed=0, scale=3.0)
