@@ -434,7 +434,8 @@ struct Contact {
     float obst;
 };
 
-#define RV_SPLIT_C 6.0f  // contacts sharing the chassis (mass splitting)
+#define RV_SPLIT_C 3.0f  // mass splitting: a contact solves against 1/3 of the chassis (six share it; round 5: 3 instead of the textbook
+                         // 6 -- the angular / bogie terms dominate a row's split inverse mass, see oracle/rover_oracle.c SPLIT_C)
 #define RV_SPLIT_B 2.0f  // contacts sharing one bogie
 #define RV_TREE8(a) ((((a)[0] + (a)[1]) + ((a)[2] + (a)[3])) + (((a)[4] + (a)[5]) + ((a)[6] + (a)[7])))
 
@@ -565,7 +566,7 @@ __device__ __forceinline__ RowQ row_quantities(const StepConsts &k, const float 
     const bool lock = friction_row ? (at_hi || at_lo) : ((at_hi && jb > 0.0f) || (at_lo && jb < 0.0f));
     if (lock) jb = 0.0f;
     o.jb = jb;
-    // mass splitting: every contact sees 1/6 of the chassis and 1/2 of its bogie
+    // mass splitting: every contact sees 1/3 of the chassis (RV_SPLIT_C) and 1/2 of its bogie
     o.m = 1.0f / (RV_SPLIT_C * k.inv_m + RV_SPLIT_C * wdot3(o.ja, k.inv_I) + RV_SPLIT_B * (jb * jb * b_winv));
     return o;
 }

@@ -140,6 +140,7 @@ int rvo_num_threads(void);
 void rvo_set_num_threads(int n); /* 0 = OpenMP default */
 /* study variants of the dynamics model (rover_oracle.c: bit 0 triangle-surface wheel contact, bit 1 coupled 9 x 9 mass matrix + PGS);
  * 0 = the model the HIP path implements -- tests, smoke and bench never set anything else */
+void rvo_set_split(float split_c, float split_b);   /* study hook: mass-splitting factors (0 = the product's 3 / 2) */
 void rvo_set_model_variant(int v);
 int rvo_get_model_variant(void);
 

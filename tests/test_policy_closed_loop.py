@@ -14,18 +14,25 @@ pytestmark = pytest.mark.skipif(not os.path.exists(CKPT), reason="reference chec
 
 
 def test_pretrained_policy_reaches_targets_in_this_model(oracle):
+    """tools/policy_closed_loop.py's setup (BASELINE config-2 terrain, 256 envs x 300 steps; profiles/r05_policy_closed_loop.txt):
+    the Isaac-Sim-trained policy reaches targets in this model; with the observation conventions as implemented it reaches MORE of
+    them and hits FEWER rocks than under any deliberately wrong convention, and a flipped heading sign or random actions reach none."""
     import policy_closed_loop as pcl
-    from helpers import oracle_terrain, small_procedural
-    n, steps = 128, 220
-    ter = small_procedural()
-    t = oracle_terrain(oracle, ter, 2 * n)
+    from isaac_rover_orbit_amd import terrain as T
+    n, steps = 256, 300
+    ter = T.make_procedural_terrain((2048, 2048))
+    ter.make_spawns(2 * n)
+    t = oracle.TerrainData(ter.height, ter.obstacle, ter.safe_rock_mask, 0.05, ter.min_x, ter.min_y, ter.spawn_locations)
     pol = pcl.load_policy()
     rng = np.random.RandomState(0)
-    good = pcl.run(n, steps, lambda o: pol(o), t)
+
+    def wrong(v):
+        return lambda o: pol(pcl.variant(v, np.where(np.isfinite(o), o, 0)))
+    good = pcl.run(n, steps, lambda o: pol(o), t)          # [time_limit, success, far, collision]
     rand = pcl.run(n, steps, lambda o: rng.uniform(-1, 1, (n, 2)).astype(np.float32), t)
-    flipped = pcl.run(n, steps, lambda o: pol(pcl.variant("heading sign flipped", np.where(np.isfinite(o), o, 0))), t)
-    transposed = pcl.run(n, steps, lambda o: pol(pcl.variant("scan transposed (y fastest)", np.where(np.isfinite(o), o, 0))), t)
-    # [time_limit, success, far, collision]
-    assert good[1] >= 20, good                       # the Isaac-Sim-trained policy drives this model to its targets
-    assert rand[1] == 0 and flipped[1] == 0          # ... which neither random actions nor a flipped heading sign do
-    assert good[1] > 1.3 * transposed[1] and good[3] < transposed[3]   # the ORBIT ray order (x fastest) is the right one
+    flipped = pcl.run(n, steps, wrong("heading sign flipped"), t)
+    assert good[1] >= 150 and good[1] / good.sum() > 0.35, good        # round 5 model: 257 of 600 episodes (0.43); round 4: 0.34
+    assert rand[1] == 0 and flipped[1] == 0
+    for v in ("scan transposed (y fastest)", "scan flipped in x", "scan flipped in y", "scan zeroed"):
+        bad = pcl.run(n, steps, wrong(v), t)
+        assert good[1] > 1.15 * bad[1] and good[3] < 0.9 * bad[3], (v, good, bad)     # 257 vs 204 / 210 / 179 / 135 successes, 276 vs 324 / 417 / 315 / 483 collisions

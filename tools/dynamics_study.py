@@ -17,7 +17,7 @@ import policy_closed_loop as pcl  # noqa: E402
 
 VARIANTS = [  # name, study-variant bits (rvo_set_model_variant), solver iterations, friction, cfg.mass_model
     ("PRODUCT (round 5): subtree weights on the bogie coordinates (cfg.mass_model = 1), split-mass Jacobi, 32 iterations", 0, 32, 0.75, 1),
-    ("round 4's product: lumped mass (cfg.mass_model = 0), 16 iterations", 0, 16, 0.75, 0),
+    ("lumped mass (cfg.mass_model = 0), 16 iterations [round 4's product apart from the chassis split factor: profiles/r05_dynamics_study_split6.txt]", 0, 16, 0.75, 0),
     ("lumped mass, 32 iterations", 0, 32, 0.75, 0),
     ("subtree weights, 16 iterations", 0, 16, 0.75, 1),
     ("subtree weights, 64 iterations", 0, 64, 0.75, 1),
