@@ -1196,7 +1196,11 @@ __device__ __forceinline__ void solver_iterations_group(const StepConsts &K, Con
     if (pairs > 0) {
         f2 v0 = V[0], v1 = V[1];
         float ln = ct.ln, lt = ct.lt, ls = ct.ls;
+        // (the loop head on a 32-byte boundary: with one wave per SIMD nothing hides an instruction fetch that straddles a line --
+        // two builds that differed in ONE float constant measured 40.4 and 41.1 us per step because the loops had moved from
+        // offsets 0 / 32 to 24 / 60 of their 64-byte lines; the padding is at most seven s_nop per substep)
         asm volatile(
+            ".p2align 5\n\t"
             "1:\n\t"
             RV_SOLVER_HALF("%[ln]", "v249", "%[lt]", "v251", "%[ls]", "v238", "s_sub_u32 %[cnt], %[cnt], 1\n\t")
             RV_SOLVER_HALF("v249", "%[ln]", "v251", "%[lt]", "v238", "%[ls]", "s_cmp_lg_u32 %[cnt], 0\n\t")
