@@ -1189,35 +1189,46 @@ __device__ __forceinline__ void solver_iteration_generic(const StepConsts &K, Co
     "v_pk_add_f32 %[v0], %[v0], v[252:253]\n\t"                                                                      \
     "v_pk_add_f32 %[v1], %[v1], v[254:255]\n\t"
 
+// UNROLL = iterations per loop trip (2 or 4): the impulses ping-pong between two register sets, so a trip is an even number of halves.
+#define RV_SOLVER_ASM(TRIPS, BODY)                                                                                                \
+    asm volatile(                                                                                                                 \
+        ".p2align 5\n\t"                                                                                                        \
+        "1:\n\t" BODY "s_cbranch_scc1 1b\n\t"                                                                                  \
+        : [v0] "+v"(v0), [v1] "+v"(v1), [ln] "+v"(ln), [lt] "+v"(lt), [ls] "+v"(ls), [cnt] "+s"(TRIPS)                            \
+        : [jn0] "v"(rr.Jn[0]), [jn1] "v"(rr.Jn[1]), [jts0] "v"(rr.Jts[0]), [jts1] "v"(rr.Jts[1]), [jts2] "v"(rr.Jts[2]),          \
+          [jts3] "v"(rr.Jts[3]), [cn] "v"(rr.Cn), [cts] "v"(rr.Cts), [mn0] "v"(rr.Mn[0]), [mn1] "v"(rr.Mn[1]), [mt0] "v"(rr.Mt[0]), \
+          [mt1] "v"(rr.Mt[1]), [ms0] "v"(rr.Ms[0]), [ms1] "v"(rr.Ms[1]), [mn] "v"(ct.mn), [mt] "v"(ct.mt), [ms] "v"(ct.ms),        \
+          [ant] "v"(ct.a_nt), [ans] "v"(ct.a_ns), [ats] "v"(ct.a_ts), [mu] "s"(mu), [ltm] "s"(K.lt_motor)                         \
+        : "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251",         \
+          "v252", "v253", "v254", "v255", "scc")
+#define RV_HALF_A(FILLER) RV_SOLVER_HALF("%[ln]", "v249", "%[lt]", "v251", "%[ls]", "v238", FILLER)
+#define RV_HALF_B(FILLER) RV_SOLVER_HALF("v249", "%[ln]", "v251", "%[lt]", "v238", "%[ls]", FILLER)
+#ifndef RV_SOLVER_UNROLL
+#define RV_SOLVER_UNROLL 4
+#endif
 __device__ __forceinline__ void solver_iterations_group(const StepConsts &K, Contact &ct, const RoleRows &rr, f2 *V, float mu,
                                                         int iterations)
 {
-    int pairs = iterations >> 1;
-    if (pairs > 0) {
-        f2 v0 = V[0], v1 = V[1];
-        float ln = ct.ln, lt = ct.lt, ls = ct.ls;
-        // (the loop head on a 32-byte boundary: with one wave per SIMD nothing hides an instruction fetch that straddles a line --
-        // two builds that differed in ONE float constant measured 40.4 and 41.1 us per step because the loops had moved from
-        // offsets 0 / 32 to 24 / 60 of their 64-byte lines; the padding is at most seven s_nop per substep)
-        asm volatile(
-            ".p2align 5\n\t"
-            "1:\n\t"
-            RV_SOLVER_HALF("%[ln]", "v249", "%[lt]", "v251", "%[ls]", "v238", "s_sub_u32 %[cnt], %[cnt], 1\n\t")
-            RV_SOLVER_HALF("v249", "%[ln]", "v251", "%[lt]", "v238", "%[ls]", "s_cmp_lg_u32 %[cnt], 0\n\t")
-            "s_cbranch_scc1 1b\n\t"
-            : [v0] "+v"(v0), [v1] "+v"(v1), [ln] "+v"(ln), [lt] "+v"(lt), [ls] "+v"(ls), [cnt] "+s"(pairs)
-            : [jn0] "v"(rr.Jn[0]), [jn1] "v"(rr.Jn[1]), [jts0] "v"(rr.Jts[0]), [jts1] "v"(rr.Jts[1]), [jts2] "v"(rr.Jts[2]),
-              [jts3] "v"(rr.Jts[3]), [cn] "v"(rr.Cn), [cts] "v"(rr.Cts), [mn0] "v"(rr.Mn[0]), [mn1] "v"(rr.Mn[1]), [mt0] "v"(rr.Mt[0]),
-              [mt1] "v"(rr.Mt[1]), [ms0] "v"(rr.Ms[0]), [ms1] "v"(rr.Ms[1]), [mn] "v"(ct.mn), [mt] "v"(ct.mt), [ms] "v"(ct.ms),
-              [ant] "v"(ct.a_nt), [ans] "v"(ct.a_ns), [ats] "v"(ct.a_ts), [mu] "s"(mu), [ltm] "s"(K.lt_motor)
-            : "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251",
-              "v252", "v253", "v254", "v255", "scc");
-        V[0] = v0;
-        V[1] = v1;
-        ct.ln = ln;
-        ct.lt = lt;
-        ct.ls = ls;
+    // (the loop head on a 32-byte boundary: with one wave per SIMD nothing hides an instruction fetch that straddles a line --
+    // two builds that differed in ONE float constant measured 40.4 and 41.1 us per step because the loops had moved from
+    // offsets 0 / 32 to 24 / 60 of their 64-byte lines; the padding is at most seven s_nop per substep)
+    f2 v0 = V[0], v1 = V[1];
+    float ln = ct.ln, lt = ct.lt, ls = ct.ls;
+    int rest = iterations;
+    if (RV_SOLVER_UNROLL == 4) {
+        int quads = rest >> 2;
+        rest &= 3;
+        if (quads > 0)   // four iterations per trip: the taken branch at the end of a trip is a fetch bubble nothing hides
+            RV_SOLVER_ASM(quads, RV_HALF_A("s_sub_u32 %[cnt], %[cnt], 1\n\t") RV_HALF_B("s_nop 0\n\t") RV_HALF_A("s_nop 0\n\t")
+                                     RV_HALF_B("s_cmp_lg_u32 %[cnt], 0\n\t"));
     }
+    int pairs = rest >> 1;
+    if (pairs > 0) RV_SOLVER_ASM(pairs, RV_HALF_A("s_sub_u32 %[cnt], %[cnt], 1\n\t") RV_HALF_B("s_cmp_lg_u32 %[cnt], 0\n\t"));
+    V[0] = v0;
+    V[1] = v1;
+    ct.ln = ln;
+    ct.lt = lt;
+    ct.ls = ls;
     if (iterations & 1) solver_iteration_generic(K, ct, rr, V, mu);
 }
 
