@@ -1995,6 +1995,18 @@ __device__ __forceinline__ void private_windows(const ScanWindow &sw, PrivateWin
         w.pk[j] = __builtin_amdgcn_readlane(pk, 16 * j);
     }
 }
+// the same windows, declared wave-uniform to the compiler (values merged from two wave-uniform paths lose that property in its
+// divergence analysis, and private_issue's scalar operands need it)
+__device__ __forceinline__ void uniform_windows(PrivateWindows &w)
+{
+    auto uf = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        w.px[j] = uf(w.px[j]); w.py[j] = uf(w.py[j]); w.pz[j] = uf(w.pz[j]); w.cy[j] = uf(w.cy[j]); w.sy[j] = uf(w.sy[j]);
+        w.i_lo[j] = __builtin_amdgcn_readfirstlane(w.i_lo[j]); w.j_lo[j] = __builtin_amdgcn_readfirstlane(w.j_lo[j]);
+        w.pk[j] = __builtin_amdgcn_readfirstlane(w.pk[j]);
+    }
+}
 #define RV_FUSED_ATTR __attribute__((target("no-unaligned-access-mode")))
 constexpr int PRIVATE_ROUNDS = 16, PRIVATE_GROUP = 4;   // a pipeline group is a quad of rounds (one 16-byte store per lane)
 // Ray -> (round m, lane): ray = 256 (m >> 2) + 4 lane + (m & 3).  A lane's four rays of a QUAD of rounds are neighbours in the
@@ -2317,7 +2329,7 @@ __device__ __forceinline__ void scan_single_tile_wave(const RvParams &p, int16_t
 // The reset is decided by the step wave right after the physics (mdp_terminations: the other termination terms are functions of
 // words loaded before the physics), so the windows handed over are those of the FINAL pose; the copy wave stages the first two and
 // casts env 0 under the step wave's manager tail.  Windows travel through LDS (win[wave][env][8 words]); SIX workgroup barriers,
-// executed by all eight waves on every path (no path depends on whether an env reset):
+// executed by all eight waves on every path (no path depends on whether an env reset; round 5: A2 is a polled LDS word, FIVE barriers):
 //   L   pose + bogie angles of the last substep's start written | copy: link-point forces, obstacle heights | step: the last substep
 //   A   link forces written                                     | step: contact report, collision flag, reset decision, final windows
 //   A2  final windows written | copy: stage windows 0, 1, wait, rays of env 0, wait       | step: manager tail, ray table
@@ -2428,13 +2440,50 @@ __device__ __forceinline__ void scan_copy_wave(const RvParams &p, const float *_
         const_cast<float *>(lk)[192 + lane] = link_sample_obstacle(ws);
     }
     K1_LITE(0);
-    __syncthreads();                                                    // A
+    __syncthreads();                                                    // A: the step wave has left the pose the physics produced
     K1_LITE(1);
-    __syncthreads();                                                    // A2: the windows of the FINAL poses (resets decided)
-    K1_LITE(2);
-    windows_from_lds(win, w);
-    if (n_env > 0) private_issue(p, w, 0, tile0, lane);
-    if (n_env > 1) private_issue(p, w, 1, tile1, lane);
+    {   // the windows of that pose, derived HERE (this wave's lanes 16 j speak for env j), and the first two requested at once: in all
+        // but ~0.1 % of the cases they are the final ones, and they travel while the step wave still gathers the contact report
+        float *lk = const_cast<float *>(fused_link(lds, p, partner));
+        const float4 d = reinterpret_cast<const float4 *>(lk + 48 + (lane >> 4) * 4)[0];
+        const float4 q = reinterpret_cast<const float4 *>(lk + 304 + (lane >> 4) * 4)[0];
+        const float pf[3] = {d.x, d.y, d.z}, qf[4] = {q.x, q.y, q.z, q.w};
+        const ScanWindow sw = scan_window(p, pf, qf);
+        private_windows(sw, w);
+        if (n_env > 0) private_issue(p, w, 0, tile0, lane);
+        if (n_env > 1) private_issue(p, w, 1, tile1, lane);
+        // the step wave's decision (it does not wait for this wave: no barrier): poll the word of this lane's env.  Bounded -- a
+        // protocol error must end as a wrong observation the parity tests catch, not as a hung GPU
+        float flag = 0.0f;
+        for (int spin = 0; spin < (1 << 20); ++spin) {
+            flag = *reinterpret_cast<volatile float *>(lk + 48 + (lane >> 4) * 4 + 3);
+            if (__builtin_amdgcn_ballot_w64(flag == 0.0f) == 0ull) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        K1_LITE(2);
+        const bool resets = flag == 2.0f;
+        const unsigned long long rmask = __builtin_amdgcn_ballot_w64(resets);
+        if (rmask != 0ull) {   // wave-uniform, rare: an env of this wave resets -> the window of the spawn pose this wave drew for it
+            float pr[3] = {pf[0], pf[1], pf[2]}, qr[4] = {qf[0], qf[1], qf[2], qf[3]};
+            if (resets) {
+                const float4 *o = reinterpret_cast<const float4 *>(lk + 256 + (lane >> 4) * 12);
+                const float4 o0 = o[0], o1 = o[1];
+                pr[0] = o0.x; pr[1] = o0.y; pr[2] = o0.z;
+                qr[0] = o0.w; qr[1] = 0.0f; qr[2] = 0.0f; qr[3] = o1.x;
+            }
+            const ScanWindow swr = scan_window(p, pr, qr);   // (the same function of the same pose for the lanes that do not reset)
+            private_windows(swr, w);
+            uniform_windows(w);
+            windows_to_lds(const_cast<float *>(win), swr, lane);
+            // restage what was requested for a pose that is no longer the final one: the earlier copy into the same tile must have
+            // landed first (two LDS-DMA streams into one tile would interleave)
+            if (n_env > 0 && (rmask & 0x1ull)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); private_issue(p, w, 0, tile0, lane); }
+            if (n_env > 1 && (rmask & 0x10000ull)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); private_issue(p, w, 1, tile1, lane); }
+        } else {
+            windows_to_lds(const_cast<float *>(win), sw, lane);
+        }
+        uniform_windows(w);
+    }
     K1_LITE(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     K1_LITE(4);
@@ -2551,6 +2600,16 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
     K1_STAMP(20);
     K1_LITE(1);
     if constexpr (FUSE == 1 || FUSE == 2) {
+        // the pose the physics left: handed to the copy wave, which derives the scan windows itself and requests the first two right
+        // behind barrier A -- two thousand cycles before the reset decision (A2); an env that then resets (rare) gets its window restaged
+        const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        float *lk = fused_link(lds, p, wv);
+        if ((lane & 15) == 0) {
+            float4 *d = reinterpret_cast<float4 *>(lk + 48 + (lane >> 4) * 4);      // [48, 64): position (x, y, z, -)
+            float4 *q = reinterpret_cast<float4 *>(lk + 304 + (lane >> 4) * 4);     // [304, 320): quaternion
+            d[0] = make_float4(g.pos[0], g.pos[1], g.pos[2], 0.0f);
+            q[0] = make_float4(g.quat[0], g.quat[1], g.quat[2], g.quat[3]);
+        }
         __syncthreads();                                                // A
         if (c.decimation > 0) {
             const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -2598,15 +2657,11 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
         coll_known = coll ? 1 : 0;
         bool term_e[ROVER_NUM_TERM];
         mdp_terminations(c, S + ROVER_CMD_B, __float_as_int(S[ROVER_EP_LEN]) + 1, coll, term_e);
-        float pf[3] = {g.pos[0], g.pos[1], g.pos[2]}, qf[4] = {g.quat[0], g.quat[1], g.quat[2], g.quat[3]};
-        if (term_e[0] | term_e[1] | term_e[2] | term_e[3]) {
-            const float4 *d = reinterpret_cast<const float4 *>(fused_link(lds, p, wv) + 256 + (lane >> 4) * 12);
-            const float4 d0 = d[0], d1 = d[1];
-            pf[0] = d0.x; pf[1] = d0.y; pf[2] = d0.z;
-            qf[0] = d0.w; qf[1] = 0.0f; qf[2] = 0.0f; qf[3] = d1.x;
-        }
-        windows_to_lds(fused_win(lds, p, wv), scan_window(p, pf, qf), lane);
-        __syncthreads();                                                // A2
+        // the decision goes to the copy wave, which owns the windows: one word per env (word 3 of the position slot; 0 = not decided
+        // yet -- written with the pose before barrier A --, 1 = the pose stands, 2 = the env resets).  NO barrier here: the copy wave is
+        // busy issuing its window requests (a wave's global_load_lds issue is blocking) and polls the word when it is done
+        if ((lane & 15) == 0)
+            *reinterpret_cast<volatile float *>(fused_link(lds, p, wv) + 48 + (lane >> 4) * 4 + 3) = (term_e[0] | term_e[1] | term_e[2] | term_e[3]) ? 2.0f : 1.0f;
         K1_LITE(2);
         // the ray table of the scan phase: requested now, so that it arrives under the manager tail
 #pragma unroll
@@ -2788,14 +2843,14 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
         float *win = fused_win(lds, p, wv);
         const int n_scan = max(0, min(4, p.n - wave * 4));
         const int e_base = wave * 4;
-        // the windows of the final poses: written by this wave before barrier A2 (the reset was decided there)
-        PrivateWindows pw;
-        windows_from_lds(win, pw);
         K1_LITE(3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the ray table
         K1_LITE(4);
         __syncthreads();                                                // B: the copy wave has cast env 0 and requested window 2
         K1_LITE(5);
+        // the windows of the final poses: written by the copy wave behind barrier A2 (it owns them), read behind barrier B
+        PrivateWindows pw;
+        windows_from_lds(win, pw);
         K1_STAMP(27);
         if (n_scan > 1) private_cast<FUSE == 2, 0, SHARE_1>(p, pw, 1, tile1, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
