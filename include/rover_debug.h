@@ -6,7 +6,7 @@
  * another: tools/n_sweep.py, tools/lift_time.py).  No reference counterpart -- the reference has one code path
  * (rover_envs/envs/navigation/entrypoints/rover_env.py:42-102) and no notion of kernel forms.  A binding that only wants the
  * reference's behaviour includes rover_hip.h / rover_lift.h and ignores this header; tests/test_abi.py checks that the library
- * exports nothing beyond what include/*.h declare.
+ * exports nothing beyond what the headers under include/ declare.
  */
 #ifndef ROVER_DEBUG_H
 #define ROVER_DEBUG_H

@@ -1934,6 +1934,84 @@ __device__ __forceinline__ float private_ray(const RvParams &p, const int16_t *t
 // compare-and-branch on M0 -- five instructions.  (hipcc's loop around the builtin took fifteen per load -- a mask and a branch
 // around every load, a 64-bit address add, M0 through a move and a nop -- and one wave per SIMD issues them one by one: 2.5 k
 // cycles per window, which round 3 read as the cost of the LDS-DMA instruction itself.)
+#ifdef RV_ROW_SPANS
+// Round 5, MEASURED AND NOT THE PRODUCT FORM (tools/build_diag.py SPANS; DESIGN.md section 6: bit-exact, fewer bytes, +1.0 us per
+// step -- the copy wave's instruction issue is what the staging phase costs, not its bytes): PER-ROW SPANS.  The staged box is the
+// bounding box of the yaw-rotated ray pattern (1.64 x its area averaged over the yaw): a chunk (eight cells of one row) is requested only where a ray can need it.  The LDS layout stays the dense tile the cast
+// addresses -- a lane that is switched off simply does not write its 16 bytes -- so nothing changes for the rays.  Which rows a
+// CHUNK COLUMN needs is an interval (the pattern's rectangle is convex): every lane derives, once per window, the iterations
+// [first, first + span] of the copy loop in which its (row-in-group, chunk) is wanted, and an iteration is the old five instructions
+// plus a subtract, an unsigned compare, two exec moves and a counter -- ten instructions for five, and ~70 per window to set up.
+//   rectangle: centre (uc, vc) in window cells, half extents (Hx, Hy), rotation (c, s);  a ray at (u, v) reads columns floor(u),
+//   floor(u) + 1 and rows floor(v), floor(v) + 1.  For the strip du in [da, db] of a chunk column (one cell + half a cell of slack
+//   each side) the rows' extent is bounded by  max_i min(l_i(da), l_i(db)) .. min_i max(h_i(da), h_i(db))  over the two edge pairs
+//   l_1/h_1 = -(c / s) du -/+ Hx / |s|,  l_2/h_2 = (s / c) du -/+ Hy / |c|  (a pair whose divisor is ~0 is dropped): an OUTER bound,
+//   whatever the rounding (v_rcp is enough); one more row of slack each side.  Windows that touch the map's edge (the cast clamps
+//   there) are copied whole.
+__device__ __forceinline__ void private_issue(const RvParams &p, const PrivateWindows &w, int j, int16_t *tile, int lane)
+{
+    const int th = w.pk[j] & 0x7FFF, tw4 = max(w.pk[j] >> 16, 1);
+    const int rpi = max(64 / tw4, 1);                                  // wave-uniform (tw4 <= 64: checked by the host)
+    const float inv_tw4 = 1.0f / (float)tw4;
+    const int lr = (int)(((float)lane + 0.5f) * inv_tw4);               // lane / tw4, exact
+    const int lc = lane - (int)__umul24(lr, tw4);
+    unsigned voff = (unsigned)(__umul24(lr, p.wq) + lc) * 16u;        // the lane's byte offset from the window's first chunk
+    const int16_t *base = p.height_q + ((size_t)w.i_lo[j] * p.W + w.j_lo[j]);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) int16_t *)tile;
+    const int groups = __builtin_amdgcn_readfirstlane((th + rpi - 1) / rpi);   // copy-loop iterations: rpi rows each, the last one partial
+    const unsigned dstep = (unsigned)(rpi * tw4) * 16u, vstep = (unsigned)__umul24(rpi, p.wq) * 16u;
+    const float inv_rpi = 1.0f / (float)rpi;
+    // rows this lane's chunk column needs (window rows), then the loop iterations k with row k * rpi + lr among them
+    int r_first = 0, r_last = th - 1;
+    if ((w.pk[j] >> 15) & 1) {   // interior window (wave-uniform)
+        const float uc = (w.px[j] - p.min_x) * p.inv_res - (float)w.j_lo[j], vc = (w.py[j] - p.min_y) * p.inv_res - (float)w.i_lo[j];
+        const float Hx = 0.5f * p.cfg.scan_size_x * p.inv_res, Hy = 0.5f * p.cfg.scan_size_y * p.inv_res;
+        const float c = w.cy[j], sn = w.sy[j];
+        const bool use1 = fabsf(sn) > 1.0e-3f, use2 = fabsf(c) > 1.0e-3f;
+        const float is = __builtin_amdgcn_rcpf(use1 ? sn : 1.0f), ic = __builtin_amdgcn_rcpf(use2 ? c : 1.0f);
+        const float m1 = use1 ? -c * is : 0.0f, w1 = use1 ? Hx * fabsf(is) : 1.0e9f;
+        const float m2 = use2 ? sn * ic : 0.0f, w2 = use2 ? Hy * fabsf(ic) : 1.0e9f;
+        const float da = (float)(8 * lc) - 1.5f - uc, db = (float)(8 * lc + 7) + 1.5f - uc;
+        const float pa = m1 * da, pb = m1 * db, qa = m2 * da, qb = m2 * db;
+        const float lo = fmaxf(fminf(pa, pb) - w1, fminf(qa, qb) - w2), hi = fminf(fmaxf(pa, pb) + w1, fmaxf(qa, qb) + w2);
+        // (slack: the slopes carry v_rcp's ulp and |du| <= ~110 cells: 1e-4 cells; one whole row each side on top of the +1 of floor(v) + 1)
+        r_first = max((int)floorf(vc + lo) - 1, 0);
+        r_last = min((int)floorf(vc + hi) + 2, th - 1);
+    }
+    // k * rpi + lr in [r_first, r_last]:  k >= (r_first - lr) / rpi (floor: one group early at most),  k <= floor((r_last - lr) / rpi)
+    const int kf = max((int)floorf(((float)(r_first - lr) + 0.5f) * inv_rpi), 0);
+    const int kl = (int)floorf(((float)(r_last - lr) + 0.5f) * inv_rpi);
+    const bool never = lr >= rpi || kl < kf || r_last < r_first;
+    const unsigned first = never ? 0x7FFFFFFFu : (unsigned)kf, span = never ? 0u : (unsigned)(kl - kf);
+    unsigned long long saved;
+    unsigned t;
+    unsigned m0_saved;
+    unsigned k = 0u;
+    asm volatile(
+        "s_mov_b64 %[saved], exec\n\t"
+        "s_mov_b32 %[m0s], m0\n\t"
+        "s_mov_b32 m0, %[lds0]\n\t"
+        "s_cmp_lt_u32 %[k], %[groups]\n\t"
+        "s_cbranch_scc0 2f\n"
+        "1:\n\t"
+        "v_sub_u32 %[t], %[k], %[first]\n\t"
+        "v_cmp_le_u32 vcc, %[t], %[span]\n\t"
+        "s_and_b64 exec, %[saved], vcc\n\t"
+        "global_load_lds_dwordx4 %[voff], %[base]\n\t"
+        "s_mov_b64 exec, %[saved]\n\t"
+        "v_add_u32 %[voff], %[vstep], %[voff]\n\t"
+        "s_add_u32 m0, m0, %[dstep]\n\t"
+        "s_add_u32 %[k], %[k], 1\n\t"
+        "s_cmp_lt_u32 %[k], %[groups]\n\t"
+        "s_cbranch_scc1 1b\n"
+        "2:\n\t"
+        "s_mov_b32 m0, %[m0s]"
+        : [saved] "=&s"(saved), [m0s] "=&s"(m0_saved), [voff] "+v"(voff), [k] "+s"(k), [t] "=&v"(t)
+        : [lds0] "s"(lds0), [groups] "s"((unsigned)groups), [base] "s"(base), [vstep] "s"(vstep), [dstep] "s"(dstep),
+          [first] "v"(first), [span] "v"(span)
+        : "memory", "scc", "vcc");
+}
+#else
 __device__ __forceinline__ void private_issue(const RvParams &p, const PrivateWindows &w, int j, int16_t *tile, int lane)
 {
     const int th = w.pk[j] & 0x7FFF, tw4 = max(w.pk[j] >> 16, 1);
@@ -1946,12 +2024,7 @@ __device__ __forceinline__ void private_issue(const RvParams &p, const PrivateWi
     const int n_full = th / rpi, n_last = th - n_full * rpi;           // whole groups of rpi rows, rows of the last group
     const unsigned dstep = (unsigned)(rpi * tw4) * 16u, vstep = (unsigned)__umul24(rpi, p.wq) * 16u;
     const unsigned lds_end = lds0 + (unsigned)n_full * dstep;
-#ifdef RV_X_SPANFRAC   // TIMING EXPERIMENT ONLY (tools/build_diag.py X_SPAN*): a fixed share of every row's chunks is not copied -- wrong results
-    const bool keep = lc * 100 < tw4 * RV_X_SPANFRAC;
-    const unsigned long long m_full = __builtin_amdgcn_ballot_w64(lr < rpi && keep), m_last = __builtin_amdgcn_ballot_w64(lr < n_last && keep);
-#else
     const unsigned long long m_full = __builtin_amdgcn_ballot_w64(lr < rpi), m_last = __builtin_amdgcn_ballot_w64(lr < n_last);
-#endif
     unsigned long long saved;
     unsigned m0_saved;
     asm volatile(
@@ -1979,6 +2052,7 @@ __device__ __forceinline__ void private_issue(const RvParams &p, const PrivateWi
           [dstep] "s"(dstep)
         : "memory", "scc");
 }
+#endif
 // (Measured and not kept: the same copy through registers -- 16-byte global loads issued before the rays of the env that still
 // occupies the tile, LDS writes afterwards.  A single wave issues one global_load_lds_dwordx4 every ~145 cycles, 2.6 k cycles per
 // window during which nothing else of the wave issues; the register route was slower still: 53.0 us per step against 48.3 us.

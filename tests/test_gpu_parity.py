@@ -466,6 +466,63 @@ def test_private_scan_kernel_measurement_form(oracle):
     env.close()
 
 
+@pytest.mark.parametrize("form,scan", [("group", (0.1, 3.0, 3.0)), ("group", (0.1, 4.0, 1.0)), ("group", (0.2, 1.2, 5.0)), ("group2", (0.1, 3.0, 3.0))])
+def test_window_spans_cover_every_yaw(oracle, form, scan):
+    """Round 5: the window copy of the wave-private scan requests, per chunk column, only the rows the yaw-rotated pattern can
+    touch (rover_kernels.hip: private_issue).  A chunk dropped wrongly leaves stale LDS under a ray -- on rough terrain that is
+    a wrong scan value.  Poses at sub-cell offsets, headings at and around every degenerate direction (axis-aligned: one edge
+    pair of the rectangle is dropped below |sin|, |cos| = 1e-3; diagonal), a sweep, and a random rest; square and elongated
+    patterns; one step with zero action, observation bit-exact against the oracle.  "group2" + form 7 = the same copy in the
+    stand-alone scan kernel."""
+    import ctypes as C
+    from isaac_rover_orbit_amd import terrain as T
+    ter = T.make_procedural_terrain((1024, 1024), seed=13, sigma_z=0.5, n_rocks=200)
+    n = 1024
+    res, sx, sy = scan
+    from isaac_rover_orbit_amd.cfg import RoverEnvCfg
+    from isaac_rover_orbit_amd.envs import RoverEnv
+    cfg = RoverEnvCfg()
+    cfg.scene.num_envs, cfg.terrain.kind, cfg.seed = n, "custom", 3
+    cfg.height_scanner.resolution, cfg.height_scanner.size = res, (sx, sy)
+    cfg.step_mapping = "group"
+    if form == "group2":
+        cfg.log_reduction = "every_step"
+    env = RoverEnv(cfg, terrain=ter)
+    if form == "group2":
+        _set_fused(env, 0)
+        fn = C.CDLL(env._lib._name).rover_debug_set_scan_form
+        fn.argtypes = [C.c_void_p, C.c_int]
+        assert fn(env._h, 7) == 0
+    else:
+        _set_fused(env, 1)
+    env.reset()
+    ocfg, oter = oracle_side(oracle, env)
+    rng = np.random.RandomState(17)
+    So = state_np(env)
+    base = np.concatenate([np.arange(8) * (np.pi / 4), np.arctan2([1.0, 3.0, sy, sx], [3.0, 1.0, sx, sy])])
+    eps = np.array([0.0, 1e-6, -1e-6, 9e-4, -9e-4, 1.1e-3, -1.1e-3, 5e-3, -5e-3, 3e-2, -3e-2])
+    special = (base[:, None] + eps[None, :]).ravel()
+    sweep = np.linspace(-np.pi, np.pi, 360, endpoint=False)
+    yaw = np.concatenate([special, sweep, rng.uniform(-np.pi, np.pi, n)])[:n]
+    So[:, oracle.POS:oracle.POS + 2] = rng.uniform(18.0, 33.0, (n, 2))
+    k = np.arange(n) % 5                                                     # some exactly on cell corners / chunk boundaries
+    So[k == 0, oracle.POS:oracle.POS + 2] = np.round(So[k == 0, oracle.POS:oracle.POS + 2] / 0.4) * 0.4
+    So[k == 1, oracle.POS] = np.round(So[k == 1, oracle.POS] / 0.05) * 0.05
+    So[:, oracle.QUAT] = np.cos(yaw / 2); So[:, oracle.QUAT + 1:oracle.QUAT + 3] = 0; So[:, oracle.QUAT + 3] = np.sin(yaw / 2)
+    So[:, oracle.LINVEL:oracle.LINVEL + 6] = 0
+    So = So.astype(np.float32)
+    env.set_state(torch.from_numpy(So))
+    a = np.zeros((n, 2), np.float32)
+    Sw = So.copy()
+    for _ in range(2):
+        obs, rew, term, trunc, info = env.step(torch.from_numpy(a).to(env.device))
+        obs_o, rew_o, term_o, trunc_o, force_o, log_o = oracle.step(ocfg, oter, Sw, a)
+        assert np.array_equal(term.cpu().numpy().astype(np.uint8), term_o)
+        assert_close(obs["policy"].cpu().numpy(), obs_o, 0, 0, "observation (scan through the span-limited window copy)")
+    assert_close(state_np(env), Sw, 0, 0, "state")
+    env.close()
+
+
 def test_sharding_invariance_gpu(oracle):
     """Two shards with env_id_offset reproduce the corresponding rows of one big env (RNG keyed by global id)."""
     ter = small_procedural()

@@ -23,8 +23,8 @@ VARIANTS = {"K1STAMP": ("rover_kernels.hip", "-DRV_K1_STAMP"),            # s_me
             "LIFTSTAMP": ("lift_kernels.hip", "-DLF_STAMP"),               # ... in the lift step kernel (tools/lift_stamps.py)
             "POLSTAMP": ("policy_kernels.hip", "-DPOL_STAMP"),             # ... in the policy kernels (tools/policy_stamps.py [pair])
             "NOSLP": ("rover_kernels.hip", "-fno-slp-vectorize"),
-            # timing experiments (WRONG results): 70 % / 50 % of every window row's chunks copied -- is the window copy bound by bytes?
-            "X_SPAN70": ("rover_kernels.hip", "-DRV_X_SPANFRAC=70"), "X_SPAN50": ("rover_kernels.hip", "-DRV_X_SPANFRAC=50"),
+            # the window copy limited to the rows each chunk column needs (bit-exact; fewer bytes, more instructions: measured slower)
+            "SPANS": ("rover_kernels.hip", "-DRV_ROW_SPANS"),
             # rounds (whole quads) of envs 1 / 2 / 3 cast by the step wave, the rest by its copy wave (tools/quick_bench.py)
             **{f"SH_{a}_{b_}_{c}": ("rover_kernels.hip", f"-DRV_SHARE_1={a} -DRV_SHARE_2={b_} -DRV_SHARE_3={c}")
                for (a, b_, c) in ((12, 16, 12), (12, 16, 16), (8, 16, 12), (12, 16, 8), (8, 16, 8), (16, 16, 12), (12, 12, 12))},

@@ -22,8 +22,22 @@ if os.environ.get("ROVER_SCAN_FORM"):   # 3 = 8 x 8 ray blocks per wave, 4 = lin
     import ctypes as C
     fn = C.CDLL(env._lib._name).rover_debug_set_scan_form; fn.argtypes = [C.c_void_p, C.c_int]
     assert fn(env._h, int(os.environ["ROVER_SCAN_FORM"])) == 0
+def cluster_by_xcd(env, n):
+    """QB_CLUSTER=1 (experiment): permute the envs' states after the reset so that the envs of the workgroups one XCD runs (workgroup
+    b = envs 16 b .. 16 b + 15 runs on XCD b mod 8) stand in one x-strip of the terrain -- what the L2 fetch would be if env -> XCD
+    followed the rovers' positions."""
+    S = env.get_state()
+    order = torch.argsort(S[:, 0]).view(8, -1)                       # eight strips by x, n / 8 envs each
+    xcd = (torch.arange(n, device=S.device) // 16) % 8
+    slot = torch.zeros(n, dtype=torch.long, device=S.device)
+    for k in range(8):
+        slot[xcd == k] = order[k]
+    env.set_state(S[slot].contiguous())
+
+
 def run(env):
     env.reset()
+    if os.environ.get("QB_CLUSTER"): cluster_by_xcd(env, n)
     g = torch.Generator(device="cuda").manual_seed(0)
     acts = torch.rand(min(steps, 64), n, 2, device="cuda", generator=g) * 2 - 1
     for k in range(steps):

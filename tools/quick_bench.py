@@ -17,8 +17,22 @@ ter = T.make_procedural_terrain((2048, 2048), seed=1234, n_rocks=400); ter.make_
 cfg = RoverEnvCfg(); cfg.scene.num_envs = n; cfg.terrain.kind = "custom"
 if os.environ.get("QB_ITERS"): cfg.solver_iterations = int(os.environ["QB_ITERS"])
 if os.environ.get("QB_MASS"): cfg.mass_model = os.environ["QB_MASS"]
+def cluster_by_xcd(env, n):
+    """QB_CLUSTER=1 (experiment): permute the envs' states after the reset so that the envs of the workgroups one XCD runs (workgroup
+    b = envs 16 b .. 16 b + 15 runs on XCD b mod 8) stand in one x-strip of the terrain -- what the L2 fetch would be if env -> XCD
+    followed the rovers' positions."""
+    S = env.get_state()
+    order = torch.argsort(S[:, 0]).view(8, -1)                       # eight strips by x, n / 8 envs each
+    xcd = (torch.arange(n, device=S.device) // 16) % 8
+    slot = torch.zeros(n, dtype=torch.long, device=S.device)
+    for k in range(8):
+        slot[xcd == k] = order[k]
+    env.set_state(S[slot].contiguous())
+
+
 env = RoverEnv(cfg, terrain=ter)
 env.reset()
+if os.environ.get("QB_CLUSTER"): cluster_by_xcd(env, n)
 g = torch.Generator(device="cuda").manual_seed(0)
 acts = torch.rand(256, n, 2, device="cuda", generator=g) * 2 - 1
 res = []
@@ -27,4 +41,4 @@ for rep in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for k in range(steps): env.step(acts[k % 256])
     torch.cuda.synchronize(); res.append((time.perf_counter() - t0) / steps * 1e6)
-print(os.environ.get("ABLTAG", "product"), f"iters={cfg.solver_iterations} mass={cfg.mass_model}", env.kernel_names()[0], "us per step:", " ".join(f"{r:.2f}" for r in res), f"-> {n / min(res):.1f} M env-steps/s")
+print(os.environ.get("ABLTAG", "product") + (" clustered" if os.environ.get("QB_CLUSTER") else ""), f"iters={cfg.solver_iterations} mass={cfg.mass_model}", env.kernel_names()[0], "us per step:", " ".join(f"{r:.2f}" for r in res), f"-> {n / min(res):.1f} M env-steps/s")
