@@ -659,13 +659,15 @@ template <bool WANT_OBST, bool GROUP_ROLE = false>
 __device__ __forceinline__ void wheel_geometry(const RvParams &p, const StepConsts &k, const float R[3][3], const float *pos,
                                                const float *com_w, const ArmConsts &arm, const float *P, const float *ax,
                                                float b_winv, float bq, bool at_hi, bool at_lo, bool steerable, float steer_q,
-                                               Contact &ct, bool role_b = false)
+                                               Contact &ct, bool role_b = false, const float *bogie_sc = nullptr)
 {
     const float *d0 = arm.d0, *axd = arm.axd;
     const float ad = arm.ad;
     float sb, cb;
-    if (fabsf(bq) < 0.75f) rv_sincosf_small(bq, &sb, &cb);   // always, for states the integrator produced (|bq| <= 10 deg)
-    else rv_sincosf(bq, &sb, &cb);
+    // bogie_sc: (sin, cos)(bq) the caller already holds (the group mapping evaluates them once per substep for the subtree's
+    // weight: hipcc does not merge two evaluations that each sit behind their own |bq| < 0.75 branch -- 33 instructions per substep)
+    if (bogie_sc) { sb = bogie_sc[0]; cb = bogie_sc[1]; }
+    else bogie_sincos(bq, &sb, &cb);   // the small-angle form always, for states the integrator produced (|bq| <= 10 deg)
     float cen_b[3], cen_w[3], piv_w[3], ax_w[3], tmp[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) cen_b[i] = P[i] + fmaf(ax[i], ad * (1.0f - cb), fmaf(axd[i], sb, d0[i] * cb));
@@ -700,11 +702,10 @@ __device__ __forceinline__ void wheel_geometry(const RvParams &p, const StepCons
 #pragma unroll
     for (int i = 0; i < 3; ++i) { r[i] = cp[i] - com_w[i]; rp[i] = cp[i] - piv_w[i]; }
     cross3f(ax_w, rp, x);   // bogie rows: ax . (rp x d) = d . (ax x rp) -- one cross product shared by the three directions
-    if (gap > 0.0f) {
-        ct.bias = -gap * k.inv_h;  // speculative contact while separated
-    } else {
+    {   // (one select: as an if / else hipcc built two exec-mask regions around two instructions each)
+        const float sep = -gap * k.inv_h;                            // speculative contact while separated
         const float push = RV_BAUMGARTE * (-gap) * k.inv_h;
-        ct.bias = fminf(push, RV_MAX_DEPENETRATION_VEL);   // = push < cap ? push : cap for finite push, one v_min_f32
+        ct.bias = gap > 0.0f ? sep : fminf(push, RV_MAX_DEPENETRATION_VEL);   // fminf = push < cap ? push : cap for finite push, one v_min_f32
     }
     if (!GROUP_ROLE) {
         const RowQ qn = row_quantities(k, R, r, x, ct.n, false, at_hi, at_lo, b_winv);
@@ -868,12 +869,11 @@ __device__ __forceinline__ void chassis_integrate(float h, const float R[3][3], 
 
 __device__ __forceinline__ void bogie_integrate(float h, float bq0, float bdv, float &q_out, float &qd_out)
 {
-    float q = fmaf(h, bdv, bq0);
-    float qd = bdv;
-    if (q > RV_BOGIE_QLIM) { q = RV_BOGIE_QLIM; if (qd > 0.0f) qd = 0.0f; }
-    if (q < -RV_BOGIE_QLIM) { q = -RV_BOGIE_QLIM; if (qd < 0.0f) qd = 0.0f; }
-    q_out = q;
-    qd_out = qd;
+    // (selects, not branches: hipcc turned the nested ifs into four exec-mask regions per substep)
+    const float q = fmaf(h, bdv, bq0);
+    const bool hi = q > RV_BOGIE_QLIM, lo = q < -RV_BOGIE_QLIM;
+    q_out = hi ? RV_BOGIE_QLIM : (lo ? -RV_BOGIE_QLIM : q);
+    qd_out = ((hi && bdv > 0.0f) || (lo && bdv < 0.0f)) ? 0.0f : bdv;
 }
 
 // ---- "lane" mapping: one physics substep of one env, S = the env's state words in registers.  Same arithmetic as the
@@ -915,6 +915,7 @@ __device__ __forceinline__ void physics_substep(const RvParams &p, const StepCon
         at_hi[j] = bq[j] >= RV_BOGIE_QLIM - 1.0e-5f;
         at_lo[j] = bq[j] <= -RV_BOGIE_QLIM + 1.0e-5f;
     }
+    float bsc[3][2];   // (sin, cos) of the three bogie angles: once per substep, for the subtrees' weights and the wheels' geometry
     {   // (cfg.mass_model = 0: the same operations with a zero coefficient, as in the group mapping and the oracle)
         constexpr float SUBTREE_COM[3][3] = RV_SUBTREE_COM_INIT;
 #pragma unroll
@@ -922,9 +923,8 @@ __device__ __forceinline__ void physics_substep(const RvParams &p, const StepCon
             const float P[3] = {BOGIE_PIVOT[j][0], BOGIE_PIVOT[j][1], BOGIE_PIVOT[j][2]};
             const float ax[3] = {BOGIE_AXIS[j][0], BOGIE_AXIS[j][1], BOGIE_AXIS[j][2]};
             const float cj[3] = {SUBTREE_COM[j][0], SUBTREE_COM[j][1], SUBTREE_COM[j][2]};
-            float sb, cb;
-            bogie_sincos(bq[j], &sb, &cb);
-            bd[j] = bogie_gravity(make_sub(cj, P, ax), R, sb, cb, p.cfg.mass_model == 1 ? K.bogie_gq[j] : 0.0f, bd[j]);
+            bogie_sincos(bq[j], &bsc[j][0], &bsc[j][1]);
+            bd[j] = bogie_gravity(make_sub(cj, P, ax), R, bsc[j][0], bsc[j][1], p.cfg.mass_model == 1 ? K.bogie_gq[j] : 0.0f, bd[j]);
         }
     }
     // ---- 3. contact geometry (slot order), warm start
@@ -946,7 +946,7 @@ __device__ __forceinline__ void physics_substep(const RvParams &p, const StepCon
         const float ax[3] = {BOGIE_AXIS[j][0], BOGIE_AXIS[j][1], BOGIE_AXIS[j][2]};
         const ArmConsts arm = make_arm(wb, P, ax);
         wheel_geometry<RECORD_FORCE>(p, K, R, S + ROVER_POS, com_w, arm, P, ax, K.b_winv[j], bq[j], at_hi[j], at_lo[j], si >= 0,
-                                     S[ROVER_STEER_Q + (si >= 0 ? si : 0)], C[s]);
+                                     S[ROVER_STEER_Q + (si >= 0 ? si : 0)], C[s], false, bsc[j]);
         C[s].ln = RV_WARM_START * S[ROVER_LAMBDA_N + k];
         C[s].lt = 0.0f;
         C[s].ls = 0.0f;
@@ -1258,18 +1258,17 @@ __device__ __forceinline__ void physics_substep_group(const RvParams &p, const S
     mat_tvecf(R, g.angvel, w);
     const float bq = g.bq;
     float bd = g.bqd * g.bogie_keep;
-    {   // the subtree's weight on the bogie coordinate.  NO branch on cfg.mass_model: the lumped model runs the same ten instructions
-        // with a zero coefficient (g.bogie_gq; the oracle does the same) -- a wave-uniform branch here cost 1.35 us per step (the
-        // kernel sits at 256 VGPRs / ~100 SGPRs: the branch's extra live scalar state turned into scalar re-loads inside the substeps)
-        float sb, cb;
-        bogie_sincos(bq, &sb, &cb);
-        bd = bogie_gravity(g.sub, R, sb, cb, g.bogie_gq, bd);
-    }
+    float bsc[2];   // (sin, cos) of the bogie angle: once per substep, for the subtree's weight and for the wheel's geometry
+    bogie_sincos(bq, &bsc[0], &bsc[1]);
+    // the subtree's weight on the bogie coordinate.  NO branch on cfg.mass_model: the lumped model runs the same ten instructions
+    // with a zero coefficient (g.bogie_gq; the oracle does the same) -- a wave-uniform branch here cost 1.35 us per step (the
+    // kernel sits at 256 VGPRs / ~100 SGPRs: the branch's extra live scalar state turned into scalar re-loads inside the substeps)
+    bd = bogie_gravity(g.sub, R, bsc[0], bsc[1], g.bogie_gq, bd);
     const bool at_hi = bq >= RV_BOGIE_QLIM - 1.0e-5f, at_lo = bq <= -RV_BOGIE_QLIM + 1.0e-5f;
     Contact ct;
     LinkSample ls;
     if (RECORD_FORCE && !LINK_ELSEWHERE) ls = link_point_fetch(p, R, g.pos, g.P, g.ax, bq, g.lp);      // pose of the substep's start, like the wheel rows
-    wheel_geometry<RECORD_FORCE && !LINK_ELSEWHERE, true>(p, K, R, g.pos, com_w, g.arm, g.P, g.ax, g.b_winv, bq, at_hi, at_lo, g.steerable, g.sq, ct, g.role_b);
+    wheel_geometry<RECORD_FORCE && !LINK_ELSEWHERE, true>(p, K, R, g.pos, com_w, g.arm, g.P, g.ax, g.b_winv, bq, at_hi, at_lo, g.steerable, g.sq, ct, g.role_b, bsc);
     if (RECORD_FORCE && !LINK_ELSEWHERE) link_point_eval(ls, p.inv_res, Fw + 3);
     K1_STAMP(3 + 3 * sidx);
     ct.ln = RV_WARM_START * g.lam;
