@@ -547,8 +547,16 @@ __device__ __forceinline__ float bogie_gravity(const SubConsts &sub, const float
 }
 __device__ __forceinline__ void bogie_sincos(float bq, float *sb, float *cb)
 {
-    if (fabsf(bq) < 0.75f) rv_sincosf_small(bq, sb, cb);   // always, for states the integrator produced (|bq| <= 10 deg)
-    else rv_sincosf(bq, sb, cb);
+    // the small-angle form for every lane, always right for states the integrator produced (|bq| <= 10 deg); the general form only
+    // in a wave that holds some other angle (a state written by the caller) -- a wave-uniform branch that is not taken, instead of
+    // a per-lane if / else whose unused side is jumped over in every substep (a taken branch costs one wave per SIMD ~15 cycles)
+    rv_sincosf_small(bq, sb, cb);
+    const bool wide = !(fabsf(bq) < 0.75f);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(wide) != 0ull, 0)) {
+        float s2, c2;
+        rv_sincosf(bq, &s2, &c2);
+        if (wide) { *sb = s2; *cb = c2; }
+    }
 }
 // One contact row of a wheel: angular Jacobian R^T (r x dir) in the body frame, bogie Jacobian dir . (ax x rp) with the
 // unilateral lock of a bogie that sits on a stop (normal row: only against the stop; friction rows: fully), split effective mass
@@ -586,11 +594,11 @@ struct LinkSample {
     float h00, h01, h10, h11, o00, o01, o10, o11, fx, fy, z;
 };
 __device__ __forceinline__ LinkSample link_point_fetch(const RvParams &p, const float R[3][3], const float *pos, const float *P,
-                                                       const float *ax, float bq, const float *p0)
+                                                       const float *ax, float bq, const float *p0, const float *bogie_sc = nullptr)
 {
     float sb, cb;
-    if (fabsf(bq) < 0.75f) rv_sincosf_small(bq, &sb, &cb);
-    else rv_sincosf(bq, &sb, &cb);
+    if (bogie_sc) { sb = bogie_sc[0]; cb = bogie_sc[1]; }   // (sin, cos)(bq) the caller already holds
+    else bogie_sincos(bq, &sb, &cb);
     const float d0[3] = {p0[0] - P[0], p0[1] - P[1], p0[2] - P[2]};
     float axd[3], pt_b[3], tmp[3];
     cross3f(ax, d0, axd);
@@ -831,7 +839,7 @@ __device__ __forceinline__ void chassis_integrate(float h, const float R[3][3], 
     // speed cap.  sqrt is monotonic, so |v|^2 <= cap^2 implies sqrt(|v|^2) <= cap: the square root and the division are only
     // evaluated by waves in which some lane may exceed the cap (a wave-uniform branch; same results as testing every lane)
     const float v2 = dot3f(v, v);
-    if (__builtin_amdgcn_ballot_w64(v2 > RV_MAX_LINEAR_VEL * RV_MAX_LINEAR_VEL) != 0ull) {
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(v2 > RV_MAX_LINEAR_VEL * RV_MAX_LINEAR_VEL) != 0ull, 0)) {
         const float sp = sqrtf(v2);
         if (sp > RV_MAX_LINEAR_VEL) {
             const float sc = RV_MAX_LINEAR_VEL / sp;
@@ -1267,7 +1275,7 @@ __device__ __forceinline__ void physics_substep_group(const RvParams &p, const S
     const bool at_hi = bq >= RV_BOGIE_QLIM - 1.0e-5f, at_lo = bq <= -RV_BOGIE_QLIM + 1.0e-5f;
     Contact ct;
     LinkSample ls;
-    if (RECORD_FORCE && !LINK_ELSEWHERE) ls = link_point_fetch(p, R, g.pos, g.P, g.ax, bq, g.lp);      // pose of the substep's start, like the wheel rows
+    if (RECORD_FORCE && !LINK_ELSEWHERE) ls = link_point_fetch(p, R, g.pos, g.P, g.ax, bq, g.lp, bsc);      // pose of the substep's start, like the wheel rows
     wheel_geometry<RECORD_FORCE && !LINK_ELSEWHERE, true>(p, K, R, g.pos, com_w, g.arm, g.P, g.ax, g.b_winv, bq, at_hi, at_lo, g.steerable, g.sq, ct, g.role_b, bsc);
     if (RECORD_FORCE && !LINK_ELSEWHERE) link_point_eval(ls, p.inv_res, Fw + 3);
     K1_STAMP(3 + 3 * sidx);
@@ -2502,9 +2510,11 @@ __device__ __forceinline__ void scan_copy_wave(const RvParams &p, const float *_
 #pragma unroll
         for (int i = 0; i < 3; ++i) lp[i] = role_b ? sc.lp[1][i] : sc.lp[0][i];
         const float bq = lk[64 + lane];
-        const LinkSample ls = link_point_fetch(p, R, pos, P, ax, bq, lp);
+        float bsc[2];
+        bogie_sincos(bq, &bsc[0], &bsc[1]);
+        const LinkSample ls = link_point_fetch(p, R, pos, P, ax, bq, lp, bsc);
         const float wbp[3] = {sc.wb[0], sc.wb[1], sc.wb[2]};
-        const LinkSample ws = link_point_fetch(p, R, pos, P, ax, bq, wbp);   // the wheel centre rides on the bogie like a link point
+        const LinkSample ws = link_point_fetch(p, R, pos, P, ax, bq, wbp, bsc);   // the wheel centre rides on the bogie like a link point
         float f3[3];
         link_point_eval(ls, p.inv_res, f3);
         const_cast<float *>(lk)[320 + lane] = f3[0];
