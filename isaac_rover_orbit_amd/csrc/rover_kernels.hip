@@ -357,7 +357,9 @@ __device__ __forceinline__ void update_command_one(const float *pos, const float
     const float dt = qv[0] * v[0] + qv[1] * v[1] + qv[2] * v[2];
 #pragma unroll
     for (int i = 0; i < 3; ++i) cmd_b[i] = v[i] * s - cr[i] * yw * 2.0f + qv[i] * dt * 2.0f;
-    *heading_b = wrap_to_pi(heading_cmd_w - (heading_w ? *heading_w : heading_of(quat)));
+    // heading_of(quat) is the SAME expression as `yaw` above (same operands, same operations): one atan2, not two -- hipcc does
+    // not merge the two evaluations, each sits behind its own `x == 0` branch
+    *heading_b = wrap_to_pi(heading_cmd_w - (heading_w ? *heading_w : yaw));
 }
 
 // ------------------------------------------------------------------------------------------------ (a9-a11) mdp terms
@@ -2546,7 +2548,7 @@ __device__ __forceinline__ void scan_copy_wave(const RvParams &p, const float *_
         K1_LITE(2);
         const bool resets = flag == 2.0f;
         const unsigned long long rmask = __builtin_amdgcn_ballot_w64(resets);
-        if (rmask != 0ull) {   // wave-uniform, rare: an env of this wave resets -> the window of the spawn pose this wave drew for it
+        if (__builtin_expect(rmask != 0ull, 0)) {   // wave-uniform, rare: an env of this wave resets -> the window of the spawn pose this wave drew for it
             float pr[3] = {pf[0], pf[1], pf[2]}, qr[4] = {qf[0], qf[1], qf[2], qf[3]};
             if (resets) {
                 const float4 *o = reinterpret_cast<const float4 *>(lk + 256 + (lane >> 4) * 12);
@@ -2709,7 +2711,7 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
     for (int i = 0; i < ROVER_NUM_BODIES * 3; ++i) F[i] = 0.0f;
     // (the link points' z component only: penetration is what makes any component of a point force non-zero)
     const bool any_force = __ballot(Fw[0] != 0.0f || Fw[1] != 0.0f || Fw[2] != 0.0f || Fw[5] != 0.0f) != 0ull;
-    if (any_force) {
+    if (__builtin_expect(any_force, 0)) {   // (rare paths out of line: the common case falls through, a taken branch costs ~15 cycles)
         constexpr int BODY_SLOT[6] = {1, 3, 0, 2, 4, 5};  // bodies 7..12 = CL, CR, FL, FR, RL, RR -> solver slot
         const int base = lane & ~15;
 #pragma unroll
@@ -2825,7 +2827,7 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
     // so lane r of the group forms word r of its env's contribution itself -- no transposition, ONE value per lane to reduce
     const bool any_reset = __ballot(do_reset && writer) != 0ull;
     float lgx = 0.0f;
-    if (do_reset && active) {
+    if (__builtin_expect(any_reset, 0) && do_reset && active) {
         const float lgv[14] = {S[ROVER_EP_SUM + 0], S[ROVER_EP_SUM + 1], S[ROVER_EP_SUM + 2], S[ROVER_EP_SUM + 3], S[ROVER_EP_SUM + 4],
                                S[ROVER_EP_SUM + 5], S[ROVER_EP_SUM + 6], term[0] ? 1.0f : 0.0f, term[1] ? 1.0f : 0.0f,
                                term[2] ? 1.0f : 0.0f, term[3] ? 1.0f : 0.0f, S[ROVER_METRIC_POS], S[ROVER_METRIC_HEAD], 1.0f};
@@ -2834,7 +2836,7 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
         lgx = (lane & 15) < 14 ? x : 0.0f;
     }
     const uint32_t gid = (uint32_t)(p.env_id_offset + e);
-    if (do_reset) {
+    if (__builtin_expect(any_reset, 0) && do_reset) {   // (any_reset: some env of the wave resets -- wave-uniform, rare)
         if constexpr (FUSE == 1 || FUSE == 2) {   // drawn by the copy wave during the physics (scan_copy_wave)
             const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
             const float4 *d = reinterpret_cast<const float4 *>(fused_link(lds, p, wv) + 256 + (lane >> 4) * 12);
@@ -2873,7 +2875,7 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
     K1_STAMP(22);
     K1_LITE_F(16);
 
-    if (any_reset) {   // this wave's row of the log partials, tagged with the step, and the flag for the reduction
+    if (__builtin_expect(any_reset, 0)) {   // this wave's row of the log partials, tagged with the step, and the flag for the reduction
         // Sum over the wave's four envs in the order of the 64-lane butterfly this replaces -- (env 0 + env 2) + (env 1 + env 3),
         // then the butterfly's four additions of the other lanes' +0, which only ever turn a -0 into +0: one addition of +0.
         float x = lgx;
