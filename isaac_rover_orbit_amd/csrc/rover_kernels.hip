@@ -2031,15 +2031,20 @@ __device__ __forceinline__ void private_issue(const RvParams &p, const PrivateWi
 __device__ __forceinline__ void private_issue(const RvParams &p, const PrivateWindows &w, int j, int16_t *tile, int lane)
 {
     const int th = w.pk[j] & 0x7FFF, tw4 = max(w.pk[j] >> 16, 1);
-    const int rpi = max(64 / tw4, 1);                                  // wave-uniform (tw4 <= 64: checked by the host)
-    const int lr = (int)(((float)lane + 0.5f) * (1.0f / (float)tw4));  // lane / tw4, exact
+    // Quotients of small integers by v_rcp_f32 (a <= tile_dim <= 1024, b <= 64: the exact quotient's fractional part is 0 or >= 1 / 64,
+    // the product's error < 1e-4, so floor(a * rcp(b) + 1e-3) IS a / b): four instructions where hipcc's integer division takes ~25 --
+    // three quotients per window, on the copy wave's chain between barrier A and barrier B
+    const float inv_tw4 = __builtin_amdgcn_rcpf((float)tw4);
+    const int rpi = __builtin_amdgcn_readfirstlane(max((int)(64.0f * inv_tw4 + 1.0e-3f), 1));   // 64 / tw4: wave-uniform (tw4 <= 64: checked by the host)
+    const int lr = (int)(((float)lane + 0.5f) * inv_tw4);               // lane / tw4 (fractional part >= 0.5 / 64)
     const int lc = lane - (int)__umul24(lr, tw4);
     unsigned voff = (unsigned)(__umul24(lr, p.wq) + lc) * 16u;        // the lane's byte offset from the window's first chunk
     const int16_t *base = p.height_q + ((size_t)w.i_lo[j] * p.W + w.j_lo[j]);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) int16_t *)tile;
-    const int n_full = th / rpi, n_last = th - n_full * rpi;           // whole groups of rpi rows, rows of the last group
-    const unsigned dstep = (unsigned)(rpi * tw4) * 16u, vstep = (unsigned)__umul24(rpi, p.wq) * 16u;
-    const unsigned lds_end = lds0 + (unsigned)n_full * dstep;
+    const int n_full = __builtin_amdgcn_readfirstlane((int)((float)th * __builtin_amdgcn_rcpf((float)rpi) + 1.0e-3f));   // th / rpi: whole groups of rpi rows
+    const int n_last = th - n_full * rpi;                                                   // rows of the last group
+    const unsigned dstep = (unsigned)__builtin_amdgcn_readfirstlane((rpi * tw4) * 16), vstep = (unsigned)__umul24(rpi, p.wq) * 16u;
+    const unsigned lds_end = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)n_full * dstep));
     const unsigned long long m_full = __builtin_amdgcn_ballot_w64(lr < rpi), m_last = __builtin_amdgcn_ballot_w64(lr < n_last);
     unsigned long long saved;
     unsigned m0_saved;
