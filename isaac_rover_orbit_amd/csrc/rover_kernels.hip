@@ -2579,7 +2579,6 @@ __device__ __forceinline__ void scan_copy_wave(const RvParams &p, const float *_
         } else {
             windows_to_lds(const_cast<float *>(win), sw, lane);
         }
-        uniform_windows(w);
     }
     K1_LITE(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
