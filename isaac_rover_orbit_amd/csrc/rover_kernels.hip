@@ -2553,7 +2553,9 @@ __device__ __forceinline__ void scan_copy_wave(const RvParams &p, const float *_
         // protocol error must end as a wrong observation the parity tests catch, not as a hung GPU
         float flag = 0.0f;
         for (int spin = 0; spin < (1 << 20); ++spin) {
-            flag = *reinterpret_cast<volatile float *>(lk + 48 + (lane >> 4) * 4 + 3);
+            // (an LDS-address-space pointer: through a generic `volatile float *` hipcc emits a FLAT load -- it queues behind the
+            // window requests just issued and its s_waitcnt vmcnt(0) waits for all of them to land before the word is even seen)
+            flag = *(volatile __attribute__((address_space(3))) float *)(__attribute__((address_space(3))) float *)(lk + 48 + (lane >> 4) * 4 + 3);
             if (__builtin_amdgcn_ballot_w64(flag == 0.0f) == 0ull) break;
             __builtin_amdgcn_s_sleep(1);
         }
@@ -2757,7 +2759,8 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
         // yet -- written with the pose before barrier A --, 1 = the pose stands, 2 = the env resets).  NO barrier here: the copy wave is
         // busy issuing its window requests (a wave's global_load_lds issue is blocking) and polls the word when it is done
         if ((lane & 15) == 0)
-            *reinterpret_cast<volatile float *>(fused_link(lds, p, wv) + 48 + (lane >> 4) * 4 + 3) = (term_e[0] | term_e[1] | term_e[2] | term_e[3]) ? 2.0f : 1.0f;
+            *(volatile __attribute__((address_space(3))) float *)(__attribute__((address_space(3))) float *)(fused_link(lds, p, wv) + 48 + (lane >> 4) * 4 + 3) =
+                (term_e[0] | term_e[1] | term_e[2] | term_e[3]) ? 2.0f : 1.0f;   // (ds_write: a generic volatile pointer gives a FLAT store)
         K1_LITE(2);
         // the ray table of the scan phase: requested now, so that it arrives under the manager tail
 #pragma unroll
