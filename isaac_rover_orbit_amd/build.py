@@ -20,7 +20,11 @@ HEADERS = [os.path.join(_PKG, "csrc", "rover_model.hpp"), os.path.join(_PKG, "cs
 OBJ_DIR = os.path.join(os.path.dirname(_PKG), "build", "obj")
 OUTPUT = os.path.join(_PKG, "librover_hip.so")
 # fp32 parity with the CPU oracle: no contraction, no fast-math (correctly rounded div / sqrt are hipcc defaults)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+# max-ilp: LLVM's AMDGPU scheduling strategy that schedules for instruction-level parallelism instead of occupancy -- these kernels run
+# ONE wave per SIMD by construction (256 VGPRs, 160 KB of LDS), nothing but the wave's own instruction stream hides a latency.  Measured
+# (round 5, profiles/r05_sched_strategy.txt): rover step 39.31 -> 39.06 us, policy pair 31.00 -> 30.44 us, lift 15.0 -> 14.9 us; same
+# arithmetic (the flag moves instructions, it does not change them; every parity test bit-exact).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 
 
 def hipcc_path() -> str:
@@ -36,6 +40,7 @@ def source_digest() -> str:
     committed PMC summaries (profiles/*.json) only beside the sources they were measured on."""
     import hashlib
     h = hashlib.sha256()
+    h.update(" ".join(FLAGS).encode())
     for f in sorted(SOURCES + HEADERS):
         if os.path.exists(f):
             h.update(os.path.basename(f).encode())
