@@ -28,6 +28,8 @@ VARIANTS = {"K1STAMP": ("rover_kernels.hip", "-DRV_K1_STAMP"),            # s_me
             # whole-file code generation switches (same arithmetic: -ffp-contract=off stays)
             "F_IFCVT": ("rover_kernels.hip", "-mllvm -amdgpu-early-ifcvt=1"), "F_NOLICM": ("rover_kernels.hip", "-mllvm -disable-machine-licm"),
             "F_MAXILP": ("rover_kernels.hip", "-mllvm -amdgpu-sched-strategy=max-ilp"), "F_PRELOAD": ("rover_kernels.hip", "-mllvm -amdgpu-kernarg-preload-count=16"),
+            "F_NOHRP": ("rover_kernels.hip", "-mllvm -amdgpu-disable-unclustered-high-rp-reschedule"), "F_NOCLO": ("rover_kernels.hip", "-mllvm -amdgpu-disable-clustered-low-occupancy-reschedule"),
+            "F_TRACK": ("rover_kernels.hip", "-mllvm -amdgpu-use-amdgpu-trackers"), "F_POSTRA0": ("rover_kernels.hip", "-mllvm -enable-post-misched=0"),
             "F_MAXMEM": ("rover_kernels.hip", "-mllvm -amdgpu-sched-strategy=max-memory-clause"),
             "P_MAXILP": ("policy_kernels.hip", "-mllvm -amdgpu-sched-strategy=max-ilp"), "L_MAXILP": ("lift_kernels.hip", "-mllvm -amdgpu-sched-strategy=max-ilp"),
             "UNROLL4": ("rover_kernels.hip", "-DRV_SOLVER_UNROLL=4"), "UNROLL2": ("rover_kernels.hip", "-DRV_SOLVER_UNROLL=2"),   # solver iterations per loop trip (default 8)
