@@ -25,13 +25,10 @@ VARIANTS = {"K1STAMP": ("rover_kernels.hip", "-DRV_K1_STAMP"),            # s_me
             "NOSLP": ("rover_kernels.hip", "-fno-slp-vectorize"),
             # the window copy limited to the rows each chunk column needs (bit-exact; fewer bytes, more instructions: measured slower)
             "SPANS": ("rover_kernels.hip", "-DRV_ROW_SPANS"),
-            # whole-file code generation switches (same arithmetic: -ffp-contract=off stays)
+            # whole-file code generation switches tried on top of the product flags (profiles/r05_sched_strategy.txt; the strategy itself,
+            # -amdgpu-sched-strategy=max-ilp, is a product flag since: isaac_rover_orbit_amd/build.py)
             "F_IFCVT": ("rover_kernels.hip", "-mllvm -amdgpu-early-ifcvt=1"), "F_NOLICM": ("rover_kernels.hip", "-mllvm -disable-machine-licm"),
-            "F_MAXILP": ("rover_kernels.hip", "-mllvm -amdgpu-sched-strategy=max-ilp"), "F_PRELOAD": ("rover_kernels.hip", "-mllvm -amdgpu-kernarg-preload-count=16"),
-            "F_NOHRP": ("rover_kernels.hip", "-mllvm -amdgpu-disable-unclustered-high-rp-reschedule"), "F_NOCLO": ("rover_kernels.hip", "-mllvm -amdgpu-disable-clustered-low-occupancy-reschedule"),
-            "F_TRACK": ("rover_kernels.hip", "-mllvm -amdgpu-use-amdgpu-trackers"), "F_POSTRA0": ("rover_kernels.hip", "-mllvm -enable-post-misched=0"),
-            "F_MAXMEM": ("rover_kernels.hip", "-mllvm -amdgpu-sched-strategy=max-memory-clause"),
-            "P_MAXILP": ("policy_kernels.hip", "-mllvm -amdgpu-sched-strategy=max-ilp"), "L_MAXILP": ("lift_kernels.hip", "-mllvm -amdgpu-sched-strategy=max-ilp"),
+            "F_PRELOAD": ("rover_kernels.hip", "-mllvm -amdgpu-kernarg-preload-count=16"),
             "UNROLL4": ("rover_kernels.hip", "-DRV_SOLVER_UNROLL=4"), "UNROLL2": ("rover_kernels.hip", "-DRV_SOLVER_UNROLL=2"),   # solver iterations per loop trip (default 8)
             # rounds (whole quads) of envs 1 / 2 / 3 cast by the step wave, the rest by its copy wave (tools/quick_bench.py)
             **{f"SH_{a}_{b_}_{c}": ("rover_kernels.hip", f"-DRV_SHARE_1={a} -DRV_SHARE_2={b_} -DRV_SHARE_3={c}")
