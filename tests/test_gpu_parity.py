@@ -265,6 +265,49 @@ def test_physics_substeps_match_oracle(oracle, mapping):
 
 
 @pytest.mark.parametrize("mapping", MAPPINGS)
+def test_rare_paths_of_the_substep_match_oracle(oracle, mapping):
+    """Round 5 moved the substep's rare paths behind wave-uniform branches that are normally NOT taken (rover_kernels.hip:
+    bogie_sincos, chassis_integrate): the general sin / cos of a bogie angle beyond 0.75 rad -- only a state the CALLER wrote can
+    hold one, the integrator clamps to +-10 deg -- and the linear speed cap.  States written through set_state with such values in
+    SOME lanes of a wave (the others take the common path beside them), bogies on both stops, chassis faster than the cap: physics
+    and a full step, bit-exact against the oracle."""
+    ter = small_procedural()
+    n = 203
+    env = make_env(n, ter, step_mapping=mapping)
+    env.reset()
+    ocfg, oter = oracle_side(oracle, env)
+    rng = np.random.RandomState(12)
+    So = state_np(env)
+    k = np.arange(n)
+    wide = (k % 7 == 0)                                     # one env in seven: bogie angles far outside the clamp, every sign
+    So[wide, oracle.BOGIE_Q:oracle.BOGIE_Q + 3] = rng.choice([-2.9, -1.3, -0.8, 0.76, 1.1, 3.1], (int(wide.sum()), 3))
+    stop = (k % 7 == 3)
+    So[stop, oracle.BOGIE_Q:oracle.BOGIE_Q + 3] = rng.choice([-0.17453292, 0.17453292], (int(stop.sum()), 3))
+    fast = (k % 5 == 1)                                     # beyond max_linear_velocity = 1.5 m/s (aau_rover_simple.py:25)
+    So[fast, oracle.LINVEL:oracle.LINVEL + 3] = rng.uniform(-3.0, 3.0, (int(fast.sum()), 3))
+    So = So.astype(np.float32)
+    steer = rng.uniform(-0.9, 0.9, (n, 4)).astype(np.float32)
+    wheel = rng.uniform(-8, 8, (n, 6)).astype(np.float32)
+    for sub in (1, 6):
+        env.set_state(torch.from_numpy(So))
+        Sw = So.copy()
+        f = env.physics(torch.from_numpy(steer), torch.from_numpy(wheel), sub).cpu().numpy()
+        fo = oracle.physics_step(ocfg, oter, Sw, steer, wheel, sub)
+        assert_close(state_np(env)[:, :39], Sw[:, :39], 0, 0, f"state after {sub} substeps from caller-written bogie angles / speeds")
+        assert_close(f, fo, 0, 0, "forces")
+    env.set_state(torch.from_numpy(So))
+    Sw = So.copy()
+    a = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+    obs, rew, term, trunc, info = env.step(torch.from_numpy(a).to(env.device))
+    obs_o, rew_o, term_o, trunc_o, force_o, log_o = oracle.step(ocfg, oter, Sw, a)
+    assert np.array_equal(term.cpu().numpy().astype(np.uint8), term_o)
+    assert_close(obs["policy"].cpu().numpy(), obs_o, 0, 0, "observation")
+    assert_close(rew.cpu().numpy(), rew_o, 0, 0, "reward")
+    assert_close(state_np(env), Sw, 0, 0, "state after the step")
+    env.close()
+
+
+@pytest.mark.parametrize("mapping", MAPPINGS)
 def test_link_bodies_report_contact(oracle, mapping):
     """The seven link bodies of the 13-body contact sensor (3 bogies, 4 steer links; rover_env_cfg.py:72-75): rovers placed at
     random poses over a field of 0.3 - 0.6 m posts narrower than the wheel gauge -- posts pass between the wheels and hit bogie
