@@ -2233,7 +2233,7 @@ __device__ __forceinline__ void private_cast(const RvParams &p, const PrivateWin
     const int pitch = (w.pk[j] >> 16) * CC;
     float *row = private_row(out, e_base + j, row_stride, col0);   // wave-uniform by construction (e_base is the wave's first env)
     if (M0 * 64 >= p.rays) return;
-    if (((w.pk[j] >> 15) & 1) && p.rays > 64 * (PRIVATE_ROUNDS - 1)) {
+    if (__builtin_expect(((w.pk[j] >> 15) & 1) && p.rays > 64 * (PRIVATE_ROUNDS - 1), 1)) {   // (the common case falls through)
         typedef const __attribute__((address_space(3))) int16_t *lds_cell_ptr;
         const f2 A = {w.cy[j], w.sy[j]}, BN = {-w.sy[j], w.cy[j]}, P = {w.px[j], w.py[j]}, NMIN = {-p.min_x, -p.min_y};
         const f2 IR = {p.inv_res, p.inv_res};
