@@ -482,7 +482,10 @@ def main():
                              "cycles_per_valu": wave_cycles / (c["SQ_INSTS_VALU"] / simds),
                              "valu_busy_frac": 4.0 * c["SQ_ACTIVE_INST_VALU"] / (simds * wave_cycles),
                              "waves_per_simd": c["SQ_WAVES"] / simds,
-                             "bound": "valu issue (4 cycles per wave64 instruction per SIMD)", "build": ic.get("_build"),
+                             "bound": "instruction issue of the one step wave per SIMD: a wave issues an instruction every ~4.4 (4-byte encoding) / ~5.4 cycles (8-byte) "
+                                      "whatever it is, while the SIMD takes a full-rate fp32 op every ~2 cycles and a packed / DPP / convert / select op every "
+                                      "~3.2 (profiles/r05_exec_probe.txt); valu_busy_frac = SQ_ACTIVE_INST_VALU (wave-cycles inside VALU instructions) per SIMD "
+                                      "and cycle of the wave life", "build": ic.get("_build"),
                              "lib_sha256": ic.get("_lib_sha256"),
                              "source": "profiles/issue_counters.json (rocprofv3 --pmc, tools/r05_measure.sh)"}
 
