@@ -2465,6 +2465,9 @@ __device__ __forceinline__ float *fused_win(float *lds, const RvParams &p, int w
 __device__ __forceinline__ float *fused_link(float *lds, const RvParams &p, int wv) { return fused_win(lds, p, 0) + 256 + wv * RV_HAND; }
 // Rounds (whole quads) of an env's sixteen cast by the STEP wave; the copy wave takes the rest.  Env 0 is the copy wave's alone
 // (cast under the manager tail, so that tile 0 is free for window 2 before barrier B); beside env 2 it stages window 3.
+#ifndef RV_OWN_TILES
+#define RV_OWN_TILES 1   // 1: each wave of a pair stages and casts two envs through its own tile, no barrier behind A; 0: the barrier form (B, C, D)
+#endif
 #ifndef RV_SHARE_1
 #define RV_SHARE_1 16
 #endif
@@ -2548,7 +2551,7 @@ __device__ __forceinline__ void scan_copy_wave(const RvParams &p, const float *_
         const ScanWindow sw = scan_window(p, pf, qf);
         private_windows(sw, w);
         if (n_env > 0) private_issue(p, w, 0, tile0, lane);
-        if (n_env > 1) private_issue(p, w, 1, tile1, lane);
+        if (!RV_OWN_TILES && n_env > 1) private_issue(p, w, 1, tile1, lane);
         // the step wave's decision (it does not wait for this wave: no barrier): poll the word of this lane's env.  Bounded -- a
         // protocol error must end as a wrong observation the parity tests catch, not as a hung GPU
         float flag = 0.0f;
@@ -2577,14 +2580,42 @@ __device__ __forceinline__ void scan_copy_wave(const RvParams &p, const float *_
             // restage what was requested for a pose that is no longer the final one: the earlier copy into the same tile must have
             // landed first (two LDS-DMA streams into one tile would interleave)
             if (n_env > 0 && (rmask & 0x1ull)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); private_issue(p, w, 0, tile0, lane); }
-            if (n_env > 1 && (rmask & 0x10000ull)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); private_issue(p, w, 1, tile1, lane); }
+            if (!RV_OWN_TILES && n_env > 1 && (rmask & 0x10000ull)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); private_issue(p, w, 1, tile1, lane); }
         } else {
             windows_to_lds(const_cast<float *>(win), sw, lane);
+        }
+        if (RV_OWN_TILES) {
+            // "the final windows stand in `win`": the reset word once more (0 -> 1 | 2 by the step wave -> 3 here; a wave's LDS operations
+            // complete in order).  The step wave polls it behind its tail and then stages and casts envs 1 and 3 from ITS tile
+            if ((lane & 15) == 0)
+                *(volatile __attribute__((address_space(3))) float *)(__attribute__((address_space(3))) float *)(lk + 48 + (lane >> 4) * 4 + 3) = 3.0f;
         }
     }
     K1_LITE(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     K1_LITE(4);
+    if (RV_OWN_TILES) {
+        // EACH WAVE OWNS A TILE (round 5): this wave stages and casts envs 0 and 2 through tile 0, the step wave envs 1 and 3 through tile 1,
+        // each at its own pace -- no barrier behind A.  (The barrier form below had this wave request all four windows and the two waves
+        // meet at B, C, D: the step wave idled ~4 k cycles at B behind its tail while this wave's chain ran.)
+        if (n_env > 0) private_cast<TRI, 0, PRIVATE_ROUNDS>(p, w, 0, tile0, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
+        K1_LITE(5);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wave's reads of tile 0 have returned: the tile is free
+        K1_LITE(6);
+        K1_LITE(7);
+        if (n_env > 2) private_issue(p, w, 2, tile0, lane);
+        K1_LITE(8);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        K1_LITE(9);
+        K1_LITE(10);
+        K1_LITE(11);
+        if (n_env > 2) private_cast<TRI, 0, PRIVATE_ROUNDS>(p, w, 2, tile0, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
+        K1_LITE(12);
+        K1_LITE(13);
+        K1_LITE(14);
+        K1_LITE(15);
+        return;
+    }
     // env 0 under the step wave's manager tail.  (Measured, us per step at 4096 envs: this order 33.8; window 2 requested before
     // barrier B as well 34.35 -- the step wave waits for the request's issue; window 1 requested only after env 0's cast 34.35.)
     if (n_env > 0) private_cast<TRI, 0, PRIVATE_ROUNDS>(p, w, 0, tile0, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
@@ -2945,6 +2976,43 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
         K1_LITE(3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the ray table
         K1_LITE(4);
+        if (RV_OWN_TILES) {
+            // this wave owns tile 1: envs 1 and 3, staged and cast here, at this wave's own pace (scan_copy_wave: envs 0 and 2 through tile 0).
+            // The windows are the copy wave's: read once its word says they stand (bounded poll: a protocol error ends as a wrong
+            // observation the parity tests catch, not as a hung GPU)
+            PrivateWindows pw;
+            {
+                const float *lk = fused_link(lds, p, wv);
+                for (int spin = 0; spin < (1 << 20); ++spin) {
+                    const float f = *(volatile __attribute__((address_space(3))) float *)(__attribute__((address_space(3))) float *)(const_cast<float *>(lk) + 48 + (lane >> 4) * 4 + 3);
+                    if (__builtin_amdgcn_ballot_w64(f != 3.0f) == 0ull) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            windows_from_lds(win, pw);
+            K1_LITE(5);
+            K1_STAMP(27);
+            if (n_scan > 1) {
+                private_issue(p, pw, 1, tile1, lane);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                private_cast<FUSE == 2, 0, PRIVATE_ROUNDS>(p, pw, 1, tile1, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's reads of tile 1 have returned: the tile is free
+            }
+            K1_STAMP(28);
+            K1_LITE(6);
+            K1_LITE(7);
+            if (n_scan > 3) {
+                private_issue(p, pw, 3, tile1, lane);
+                K1_LITE(8);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                K1_STAMP(29);
+                K1_LITE(9);
+                private_cast<FUSE == 2, 0, PRIVATE_ROUNDS>(p, pw, 3, tile1, lane, e_base, obs, p.obs_w, 4, oxy, ray_xy);
+            }
+            K1_STAMP(26);
+            K1_LITE(10);
+            return;
+        }
         __syncthreads();                                                // B: the copy wave has cast env 0 and requested window 2
         K1_LITE(5);
         // the windows of the final poses: written by the copy wave behind barrier A2 (it owns them), read behind barrier B
