@@ -25,6 +25,7 @@ VARIANTS = {"K1STAMP": ("rover_kernels.hip", "-DRV_K1_STAMP"),            # s_me
             "NOSLP": ("rover_kernels.hip", "-fno-slp-vectorize"),
             # the window copy limited to the rows each chunk column needs (bit-exact; fewer bytes, more instructions: measured slower)
             "SPANS": ("rover_kernels.hip", "-DRV_ROW_SPANS"),
+            "BARRIERS": ("rover_kernels.hip", "-DRV_OWN_TILES=0"),        # the one-launch kernel's scan phase in its barrier form (B, C, D: rounds 4 - 5)
             # whole-file code generation switches tried on top of the product flags (profiles/r05_sched_strategy.txt; the strategy itself,
             # -amdgpu-sched-strategy=max-ilp, is a product flag since: isaac_rover_orbit_amd/build.py)
             "F_IFCVT": ("rover_kernels.hip", "-mllvm -amdgpu-early-ifcvt=1"), "F_NOLICM": ("rover_kernels.hip", "-mllvm -disable-machine-licm"),

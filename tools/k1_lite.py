@@ -31,10 +31,10 @@ s = stamps.cpu().numpy().astype(np.float64)
 t0 = s[:, 0:1]
 step = {0: "start", 1: "physics done (before A)", 2: "reset decided, flag word set (no barrier)", 11: "ray table requested", 12: "group_store issued",
         13: "force rows stored", 14: "mdp terms", 15: "rewards + reset", 16: "command", 3: "tail done (log, final stores issued)", 4: "ray table / stores retired",
-        5: "after B", 6: "env 1 share cast", 7: "after C", 8: "env 2 cast", 9: "after D", 10: "end (env 3 share cast)"}
-copy = {0: "before A (link work done)", 1: "after A", 2: "windows derived, 0 and 1 requested, the step wave's flag polled", 3: "final windows written (restaged after a reset)", 4: "... landed", 5: "env 0 cast",
-        6: "... its stores retired", 7: "after B", 8: "window 2 requested (+ env 1 share cast)", 9: "... window 2 landed",
-        10: "after C", 11: "window 3 requested", 12: "env 2 share cast", 13: "... window 3 landed", 14: "after D", 15: "end (env 3 share cast)"}
+        5: "copy wave's word polled, windows read", 6: "window 1 requested, landed, env 1 cast (tile 1)", 8: "window 3 requested", 9: "... landed",
+        10: "end (env 3 cast)"}
+copy = {0: "before A (link work done)", 1: "after A", 2: "windows derived, window 0 requested, the step wave's flag polled", 3: "final windows written, word set",
+        4: "... window 0 landed", 5: "env 0 cast (tile 0)", 6: "... its LDS reads returned", 8: "window 2 requested", 9: "... landed", 12: "end (env 2 cast)"}
 print(env.kernel_names()[0])
 for name, off, labels in (("step wave", 0, step), ("copy wave", 32, copy)):
     print(name)

@@ -34,8 +34,8 @@ names.update({20: "physics done", 23: "state stored + force gathered", 24: "mdp 
 order = [0, 1] + [k for i in range(6) for k in (2 + 3 * i, 3 + 3 * i, 4 + 3 * i)] + [20, 23, 24, 21, 22, 25]
 fused = env.kernel_names()[0].startswith("rover_step_scan_kernel")
 if fused:
-    names.update({27: "scan: barrier B (the copy wave has cast env 0 under the tail)", 28: "scan: env 1 cast (both waves)",
-                  29: "scan: barrier C, env 2 cast", 26: "scan: barrier D, env 3 cast (both waves)"})
+    names.update({27: "scan: the copy wave's word polled, windows read", 28: "scan: window 1 requested + landed, env 1 cast (tile 1)",
+                  29: "scan: window 3 requested + landed", 26: "scan: env 3 cast"})
     order += [27, 28, 29, 26]
 keys = order
 prev = None
