@@ -2,7 +2,7 @@
 # Dev tool (GPU box): the round-5 measurement set (needs `python tools/build_diag.py K1STAMP K1LITE POLSTAMP LIFTSTAMP` first).  Every step
 # writes under gpurun_out/r05m; the chain stops at the first failing GPU step.  $1: 1 = counters / traces, 2 = bench lines / stamps.
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05m; mkdir -p $O
-TAG="r05 final build (hipcc -mllvm -amdgpu-sched-strategy=max-ilp): cfg.mass_model = 1 (bogie-subtree weights), chassis split 3, 32 solver iterations; solver loop 44 instructions per iteration, eight iterations per trip, loop heads 32-byte aligned; bogie sin/cos once per substep, rare paths as not-taken uniform branches; three LDS corner reads per ray; the copy wave derives and requests the first two windows right behind barrier A (five barriers, the reset decision through a polled LDS word read with ds_read)"
+TAG="r05 final build (hipcc -mllvm -amdgpu-sched-strategy=max-ilp): cfg.mass_model = 1 (bogie-subtree weights), chassis split 3, 32 solver iterations; solver loop 44 instructions per iteration, eight iterations per trip, loop heads 32-byte aligned; bogie sin/cos once per substep, rare paths as not-taken uniform branches; three LDS corner reads per ray; scan phase: each wave of a pair owns a tile (copy wave envs 0, 2; step wave envs 1, 3), barriers L and A only, the reset decision and the final windows through one polled LDS word per env"
 cd /tmp && export TMPDIR=/tmp
 if [ "${1:-1}" = "1" ]; then
 python3 -c "import sys; sys.path.insert(0,'$R'); import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1 && \
