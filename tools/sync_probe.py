@@ -1,0 +1,24 @@
+import os, sys, time, ctypes as C
+ROOT = "/root/repo" if os.path.exists("/root/repo/bench.py") else os.environ.get("GRAFT_REPO_ROOT", ".")
+sys.path.insert(0, ROOT)
+mode = sys.argv[1] if len(sys.argv) > 1 else "default"
+if mode == "spin":
+    hip = C.CDLL("libamdhip64.so")
+    print("hipSetDeviceFlags(spin) ->", hip.hipSetDeviceFlags(C.c_uint(1)))   # hipDeviceScheduleSpin = 0x1
+import torch
+from isaac_rover_orbit_amd import terrain as T
+from isaac_rover_orbit_amd.cfg import RoverEnvCfg
+from isaac_rover_orbit_amd.envs import RoverEnv
+n = 4096
+ter = T.make_procedural_terrain((2048, 2048), seed=1234, n_rocks=400); ter.make_spawns(2 * n, seed=41)
+cfg = RoverEnvCfg(); cfg.scene.num_envs = n; cfg.terrain.kind = "custom"
+env = RoverEnv(cfg, terrain=ter); env.reset()
+acts = torch.rand(256, n, 2, device="cuda") * 2 - 1
+for k in range(400): env.step(acts[k % 256])
+for K in (20, 100, 1000):
+    res = []
+    for rep in range(5):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for k in range(K): env.step(acts[k % 256])
+        torch.cuda.synchronize(); res.append((time.perf_counter() - t0) / K * 1e6)
+    print(mode, "K", K, "us per step:", " ".join(f"{r:.2f}" for r in res))
