@@ -2974,7 +2974,7 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
         const int n_scan = max(0, min(4, p.n - wave * 4));
         const int e_base = wave * 4;
         K1_LITE(3);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the ray table
+        if (!RV_OWN_TILES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ray table (own-tiles form: the cast's first use waits for it; the stores need not retire before the window request)
         K1_LITE(4);
         if (RV_OWN_TILES) {
             // this wave owns tile 1: envs 1 and 3, staged and cast here, at this wave's own pace (scan_copy_wave: envs 0 and 2 through tile 0).
