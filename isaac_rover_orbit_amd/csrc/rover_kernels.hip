@@ -2416,23 +2416,27 @@ __device__ __forceinline__ void scan_single_tile_wave(const RvParams &p, int16_t
     }
 }
 
-// ---- the fused step kernel's scan phase with COPY WAVES.  One wave issues a global_load_lds_dwordx4 every ~120 cycles and
-// nothing else meanwhile (2.3 k cycles per window: the CU's L2 port delivers ~33 B/clk to its four requesting waves), so the four
+// ---- the fused step kernel's scan phase with COPY WAVES.  One wave issues a global_load_lds_dwordx4 every ~145 cycles and
+// nothing else meanwhile (2.3 k cycles per window: the CU's memory pipeline delivers ~30 B/clk to its requesting waves), so the four
 // step waves of a workgroup are paired with four copy waves (waves 4..7, one per SIMD, asleep at a barrier during the physics):
-// copy wave k + 4 stages the windows of step wave k.  During the physics it draws what a reset of each env WOULD draw (reset_draw)
-// and, during the LAST substep, evaluates the link-body sample points and the wheels' obstacle look-ups of the contact report.
-// The reset is decided by the step wave right after the physics (mdp_terminations: the other termination terms are functions of
-// words loaded before the physics), so the windows handed over are those of the FINAL pose; the copy wave stages the first two and
-// casts env 0 under the step wave's manager tail.  Windows travel through LDS (win[wave][env][8 words]); SIX workgroup barriers,
-// executed by all eight waves on every path (no path depends on whether an env reset; round 5: A2 is a polled LDS word, FIVE barriers):
+// copy wave k + 4 serves step wave k.  During the physics it draws what a reset of each env WOULD draw (reset_draw) and, during
+// the LAST substep, evaluates the link-body sample points and the wheels' obstacle look-ups of the contact report.  The reset is
+// decided by the step wave right after the physics (mdp_terminations: the other termination terms are functions of words loaded
+// before the physics).  Windows travel through LDS (win[wave][env][8 words]).
+// Round 5, the product form (RV_OWN_TILES = 1): TWO workgroup barriers, executed by all eight waves on every path, and ONE polled
+// LDS word per env (word 3 of the env's position slot in the hand-over area):
 //   L   pose + bogie angles of the last substep's start written | copy: link-point forces, obstacle heights | step: the last substep
-//   A   link forces written                                     | step: contact report, collision flag, reset decision, final windows
-//   A2  final windows written | copy: stage windows 0, 1, wait, rays of env 0, wait       | step: manager tail, ray table
-//   B   env 0 cast, window 1 landed | copy: stage window 2 into tile 0, wait              | step: rays of env 1
-//   C   window 2 landed, tile 1 free | copy: stage window 3 into tile 1, wait             | step: rays of env 2
-//   D   window 3 landed                                         | both: rays of env 3 (rounds [0, SHARE_3) / [SHARE_3, 16))
-// A cast is bound by the SIMD's instruction issue, not by latency: two waves casting the same env together take as long as one
-// (16 rounds: 2.9 k cycles against 3.0 k; tools/k1_lite.py), so sharing an env pays only where the other wave would idle anyway.
+//   A   pose the physics left + link forces written (word = 0)  | step: contact report, collision flag, RESET DECISION -> word = 1 | 2,
+//       manager tail                                            | copy: windows of the four poses, window 0 requested at once into
+//       tile 0; polls the word; an env that resets: window from the spawn pose it drew (window 0 restaged); final windows -> `win`,
+//       word = 3
+//   then each wave OWNS A TILE and runs at its own pace, no barrier:
+//       copy wave, tile 0: wait, rays of env 0, request window 2, wait, rays of env 2
+//       step wave, tile 1: polls the word for 3, reads `win`, requests window 1, wait, rays of env 1, request window 3, wait, rays of env 3
+// The barrier form (RV_OWN_TILES = 0; rounds 4 - 5: the copy wave requests all four windows, the waves meet at barriers B, C, D and
+// split envs 1 - 3 by RV_SHARE_*) is kept as a build variant (tools/build_diag.py BARRIERS): 38.90 -> 37.77 us per step for the own-tiles form.
+// A single wave's cast is bound by its instruction issue (~5 cycles per instruction); all eight waves of a CU casting at once are bound
+// by the LDS array (three 16-bit reads per ray-round x 8 waves; profiles/r05_exec_probe.txt).
 __device__ __forceinline__ void windows_to_lds(float *win, const ScanWindow &sw, int lane)
 {
     if ((lane & 15) == 0) {
@@ -2490,7 +2494,7 @@ __device__ __forceinline__ void scan_copy_wave(const RvParams &p, const float *_
     const int n_env = max(0, min(4, p.n - e_base));
     PrivateWindows w;
     // the ray table: the same 8 KB for every wave of every step.  Requested NOW -- this wave has registers to spare during the
-    // physics -- and not behind barrier A2, where its sixteen loads would queue in front of env 0's cast with the window requests
+    // physics -- and not behind barrier A, where its sixteen loads would queue in front of env 0's cast with the window requests
     // (a load instruction costs ~120 cycles of the wave's issue there, whatever it carries)
     f2 oxy[PRIVATE_ROUNDS];
 #pragma unroll
@@ -2730,7 +2734,7 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
     K1_LITE(1);
     if constexpr (FUSE == 1 || FUSE == 2) {
         // the pose the physics left: handed to the copy wave, which derives the scan windows itself and requests the first two right
-        // behind barrier A -- two thousand cycles before the reset decision (A2); an env that then resets (rare) gets its window restaged
+        // behind barrier A -- before the reset decision exists; an env that then resets (rare) gets its window restaged
         const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         float *lk = fused_link(lds, p, wv);
         if ((lane & 15) == 0) {
@@ -3015,7 +3019,7 @@ __device__ __forceinline__ void step_group_body(const RvParams &p, float *__rest
         }
         __syncthreads();                                                // B: the copy wave has cast env 0 and requested window 2
         K1_LITE(5);
-        // the windows of the final poses: written by the copy wave behind barrier A2 (it owns them), read behind barrier B
+        // (barrier form) the windows of the final poses: written by the copy wave (it owns them), read behind barrier B
         PrivateWindows pw;
         windows_from_lds(win, pw);
         K1_STAMP(27);
