@@ -566,6 +566,19 @@ def test_window_spans_cover_every_yaw(oracle, form, scan):
     env.close()
 
 
+@pytest.mark.parametrize("n", [1, 5, 6, 7, 17])
+def test_one_launch_form_with_a_ragged_last_wave(oracle, n):
+    """The one-launch kernel's waves own their tiles behind barrier A (round 5): a last wave with 1, 2 or 3 envs skips the windows and
+    casts of the envs it does not have -- on BOTH waves of the pair, without a barrier to meet at.  Closed loop, bit-exact."""
+    ter = small_procedural()
+    env = make_env(n, ter, seed=9, step_mapping="group")
+    assert env.kernel_names()[0].startswith("rover_step_scan_kernel"), env.kernel_names()
+    rng = np.random.RandomState(n)
+    actions = rng.uniform(-1, 1, (8, n, 2)).astype(np.float32)
+    assert rollout_compare(oracle, env, 8, actions, 0.0, 0.0, resync=False) == 0
+    env.close()
+
+
 def test_sharding_invariance_gpu(oracle):
     """Two shards with env_id_offset reproduce the corresponding rows of one big env (RNG keyed by global id)."""
     ter = small_procedural()
