@@ -25,3 +25,15 @@ for K in (20, 100, 1000):
         for k in range(K): env.step(acts[k % 256])
         torch.cuda.synchronize(); res.append((time.perf_counter() - t0) / K * 1e6)
     print(mode, "K", K, "us per step:", " ".join(f"{r:.2f}" for r in res))
+
+# where the fixed cost sits: host-side launch loop, GPU-side span (events), final synchronise
+for K in (20,):
+    for rep in range(4):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter(); e0.record()
+        for k in range(K): env.step(acts[k % 256])
+        t1 = time.perf_counter(); e1.record()
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        print(mode, f"K {K}: launch loop {1e6 * (t1 - t0):.0f} us, + synchronise {1e6 * (t2 - t1):.0f} us = {1e6 * (t2 - t0):.0f} us; GPU span between the events {1e3 * e0.elapsed_time(e1):.0f} us "
+              f"({1e3 * e0.elapsed_time(e1) / K:.2f} per step)")
