@@ -338,9 +338,12 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=200)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--preroll", type=int, default=400,
-                    help="untimed env steps BEFORE the warm-up steps: the rollout reaches its steady state (episodes of mixed age, resets "
-                         "in every step) and the GPU its sustained clock -- the first ~150 steps after an idle device run ~5 %% slower")
+    ap.add_argument("--preroll", type=int, default=1500,
+                    help="untimed env steps BEFORE the warm-up steps, part of the initialisation like the construction and the reset: the rollout "
+                         "reaches its steady state (episodes of mixed age: the first time-outs come at step 750; resets in every step) and the "
+                         "device its sustained state -- measured (profiles/r05_preroll.txt): the first 200-step windows after construction run "
+                         "42.5 / 40.5 / 39.1 / 37.8 / 37.7 us per step, and a 20-step region behind 400 / 1500 / 4000 such steps reads "
+                         "40.5 / 39.3 / 39.3 us per step")
     ap.add_argument("--no-extra", action="store_true", help="skip the `extra` block (configs 4 / 5, rollout loop, log every step, 16 iterations)")
     ap.add_argument("--no-forces", action="store_true", help="do not materialise contact_sensor.force_matrix_w")
     ap.add_argument("--with-policy", action="store_true",
